@@ -1,0 +1,211 @@
+/*
+ * cm2_oracle.c -- CPU restatement (plain C, scalar, single thread) of the
+ * COSMOMAP2 PCG hot-path loops.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and bench.py's `cpu_baseline` leg may load it.  The
+ * product path (cosmomap2_amd/) never links, imports or calls anything here.
+ *
+ * Every function restates one serial loop of the reference and cites the
+ * reference file:line it follows (paths relative to /root/reference).  The
+ * loops are kept in the reference's evaluation order (same operand order, no
+ * reassociation; build with -ffp-contract=off so no FMA is formed) so that a
+ * deterministic device kernel can be compared bit for bit.
+ *
+ * Pinning status: the weave loops restated here (P, P^T, weight accumulation,
+ * flagging, M_BD pol=2/3) cannot be executed from the reference in this
+ * container (weave/blitz are absent), so they are pinned by reading plus the
+ * reference tests' algebraic invariants (tests/test_oracle_invariants.py);
+ * the NumPy-level pieces (Toeplitz product, BlockDiagonalLO, M_BD pol=1,
+ * repixelization, DeflationLO, CoarseLO, arnoldi, dgemm/norm2/scalprod) are
+ * pinned against outputs of the reference's own function bodies executed here
+ * (tests/golden/make_golden.py -> tests/golden/*.npz).
+ *
+ * Conventions: pix is int32, -1 = flagged sample; maps are pixel-interleaved
+ * [I0,Q0,U0,I1,...]; all values are IEEE double.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+/* ---- a2: P x  (interfaces/linearoperators.py:356-384, 411-438, 463-497) ---- */
+void orc_P_apply(int pol, int64_t nt, const int32_t *pix, const double *c,
+                 const double *s, const double *x, double *out)
+{
+    int64_t i;
+    memset(out, 0, (size_t)nt * sizeof(double));          /* x=np.zeros(nrows) */
+    if (pol == 1) {
+        for (i = 0; i < nt; ++i) {                        /* :371-374 */
+            if (pix[i] == -1) continue;
+            out[i] += x[pix[i]];
+        }
+    } else if (pol == 2) {
+        for (i = 0; i < nt; ++i) {                        /* :426-429 */
+            if (pix[i] == -1) continue;
+            out[i] += x[2 * (int64_t)pix[i]] * c[i] + x[2 * (int64_t)pix[i] + 1] * s[i];
+        }
+    } else {
+        for (i = 0; i < nt; ++i) {                        /* :485-488 */
+            if (pix[i] == -1) continue;
+            out[i] += x[3 * (int64_t)pix[i]] + x[3 * (int64_t)pix[i] + 1] * c[i]
+                      + x[3 * (int64_t)pix[i] + 2] * s[i];
+        }
+    }
+}
+
+/* ---- a3: P^T v  (interfaces/linearoperators.py:385-410, 439-462, 498-526) ---- */
+void orc_Pt_apply(int pol, int64_t nt, int64_t npix, const int32_t *pix,
+                  const double *c, const double *s, const double *v, double *out)
+{
+    int64_t i;
+    memset(out, 0, (size_t)(npix * pol) * sizeof(double));
+    if (pol == 1) {
+        for (i = 0; i < nt; ++i) {                        /* :396-400 */
+            if (pix[i] == -1) continue;
+            out[pix[i]] += v[i];
+        }
+    } else if (pol == 2) {
+        for (i = 0; i < nt; ++i) {                        /* :449-453 */
+            if (pix[i] == -1) continue;
+            out[2 * (int64_t)pix[i]]     += v[i] * c[i];
+            out[2 * (int64_t)pix[i] + 1] += v[i] * s[i];
+        }
+    } else {
+        for (i = 0; i < nt; ++i) {                        /* :511-516 */
+            if (pix[i] == -1) continue;
+            out[3 * (int64_t)pix[i]]     += v[i];
+            out[3 * (int64_t)pix[i] + 1] += v[i] * c[i];
+            out[3 * (int64_t)pix[i] + 2] += v[i] * s[i];
+        }
+    }
+}
+
+/* ---- a4: symmetric banded Toeplitz block times vector, zero boundary
+ *      (interfaces/linearoperators.py:582-595).  The NumPy code does
+ *        y = a0*v ; for i in 1..lambda-1: temp=a_i*v ; y[:-i]+=temp[i:] ; y[i:]+=temp[:-i]
+ *      i.e. per output k the terms are added in the order
+ *        a0 v_k, a1 v_{k+1}, a1 v_{k-1}, a2 v_{k+2}, a2 v_{k-2}, ...          ---- */
+void orc_toeplitz_apply(int64_t lambda, const double *a, int64_t n,
+                        const double *v, double *y)
+{
+    int64_t k, i;
+    for (k = 0; k < n; ++k) {
+        double acc = a[0] * v[k];
+        for (i = 1; i < lambda; ++i) {
+            if (k + i < n)  acc += a[i] * v[k + i];       /* y[:-i] += temp[i:]  */
+            if (k - i >= 0) acc += a[i] * v[k - i];       /* y[i:]  += temp[:-i] */
+        }
+        y[k] = acc;
+    }
+}
+
+/* ---- a6: per-pixel weight accumulation
+ *      (utilities/process_ces.py:480-487, 505-514, 527-539; same loops :125-186) ---- */
+void orc_weights_accumulate(int pol, int64_t nt, const int32_t *pix,
+                            const double *w, const double *c, const double *s,
+                            double *counts, double *cosine, double *sine,
+                            double *cos2, double *sin2, double *sincos)
+{
+    int64_t i;
+    for (i = 0; i < nt; ++i) {
+        int32_t p = pix[i];
+        if (p == -1) continue;
+        if (pol == 1) {
+            counts[p] += w[i];                            /* :485 */
+        } else if (pol == 2) {
+            cos2[p]   += w[i] * c[i] * c[i];              /* :510-512 */
+            sin2[p]   += w[i] * s[i] * s[i];
+            sincos[p] += w[i] * s[i] * c[i];
+        } else {
+            counts[p] += w[i];                            /* :532-537 */
+            cosine[p] += w[i] * c[i];
+            sine[p]   += w[i] * s[i];
+            cos2[p]   += w[i] * c[i] * c[i];
+            sin2[p]   += w[i] * s[i] * s[i];
+            sincos[p] += w[i] * s[i] * c[i];
+        }
+    }
+}
+
+/* ---- a7: sample flagging  (utilities/process_ces.py:411-418) ---- */
+void orc_flag_samples(int64_t nt, int32_t *pix, const int64_t *old2new)
+{
+    int64_t i;
+    for (i = 0; i < nt; ++i) {
+        int32_t p = pix[i];
+        if (p == -1) continue;
+        pix[i] = (int32_t)old2new[p];
+    }
+}
+
+/* ---- a8: M_BD x  (interfaces/linearoperators.py:775-841).
+ *      det and mask are computed by the NumPy lines :792-795 / :820-821 on the
+ *      Python side of the oracle and passed in (mask[j] != 0 <=> |det|>1e-5). ---- */
+void orc_bdprecond_apply(int pol, int64_t npix, const double *hits,
+                         const double *c, const double *s, const double *c2,
+                         const double *s2, const double *cs, const double *det,
+                         const uint8_t *mask, const double *x, double *y)
+{
+    int64_t j;
+    memset(y, 0, (size_t)(npix * pol) * sizeof(double));  /* y=x*0. */
+    if (pol == 1) {
+        for (j = 0; j < npix; ++j)                        /* :789-790 */
+            if (hits[j] > 0) y[j] = x[j] / hits[j];
+    } else if (pol == 2) {
+        for (j = 0; j < npix; ++j) {                      /* :823-827 */
+            if (!mask[j]) continue;
+            y[2 * j]     = (s2[j] * x[2 * j] - cs[j] * x[2 * j + 1]) / det[j];
+            y[2 * j + 1] = (-cs[j] * x[2 * j] + c2[j] * x[2 * j + 1]) / det[j];
+        }
+    } else {
+        for (j = 0; j < npix; ++j) {                      /* :797-802 */
+            if (!mask[j]) continue;
+            y[3 * j]     = ((c2[j] * s2[j] - cs[j] * cs[j]) * x[3 * j]
+                            + (s[j] * cs[j] - c[j] * s2[j]) * x[3 * j + 1]
+                            + (c[j] * cs[j] - s[j] * c2[j]) * x[3 * j + 2]) / det[j];
+            y[3 * j + 1] = ((s[j] * cs[j] - c[j] * s2[j]) * x[3 * j]
+                            + (hits[j] * s2[j] - s[j] * s[j]) * x[3 * j + 1]
+                            + (s[j] * c[j] - hits[j] * cs[j]) * x[3 * j + 2]) / det[j];
+            y[3 * j + 2] = ((c[j] * cs[j] - s[j] * c2[j]) * x[3 * j]
+                            + (-hits[j] * cs[j] + c[j] * s[j]) * x[3 * j + 1]
+                            + (hits[j] * c2[j] - c[j] * c[j]) * x[3 * j + 2]) / det[j];
+        }
+    }
+}
+
+/* ---- a9: (P^T diag(N^-1) P) x per pixel  (interfaces/linearoperators.py:728-746) ---- */
+void orc_bd_apply(int pol, int64_t npix, const double *hits, const double *c,
+                  const double *s, const double *c2, const double *s2,
+                  const double *cs, const double *x, double *y)
+{
+    int64_t p;
+    if (pol == 1) {
+        for (p = 0; p < npix; ++p) y[p] = x[p] * hits[p]; /* :735 */
+    } else if (pol == 2) {
+        for (p = 0; p < npix; ++p) {                      /* :743-745 */
+            y[2 * p]     = c2[p] * x[2 * p] + cs[p] * x[2 * p + 1];
+            y[2 * p + 1] = cs[p] * x[2 * p] + s2[p] * x[2 * p + 1];
+        }
+    } else {
+        for (p = 0; p < npix; ++p) {                      /* :737-741 */
+            y[3 * p]     = hits[p] * x[3 * p] + c[p] * x[3 * p + 1] + s[p] * x[3 * p + 2];
+            y[3 * p + 1] = c[p] * x[3 * p] + c2[p] * x[3 * p + 1] + cs[p] * x[3 * p + 2];
+            y[3 * p + 2] = s[p] * x[3 * p] + cs[p] * x[3 * p + 1] + s2[p] * x[3 * p + 2];
+        }
+    }
+}
+
+/* ---- CPU baseline leg: the reference's unfused diagonal-noise matvec
+ *      P^T (diag(w) (P x)) with a fresh output for every stage, as
+ *      interfaces/linearoperators.py:463-526 + linop DiagonalOperator do.
+ *      `tod` is caller-provided scratch of nt doubles.                        ---- */
+void orc_PtNP_diag(int pol, int64_t nt, int64_t npix, const int32_t *pix,
+                   const double *c, const double *s, const double *w,
+                   const double *x, double *tod, double *out)
+{
+    int64_t i;
+    orc_P_apply(pol, nt, pix, c, s, x, tod);
+    for (i = 0; i < nt; ++i) tod[i] = w[i] * tod[i];
+    orc_Pt_apply(pol, nt, npix, pix, c, s, tod, out);
+}

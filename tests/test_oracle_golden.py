@@ -1,0 +1,154 @@
+"""
+Pin the oracle (oracle/) against outputs of the reference's own function bodies
+executed in the build container (tests/golden/reference_golden.npz, made by
+tests/golden/make_golden.py).  CPU only.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+
+def test_blas_helpers(golden, oracle):
+    # utilities/linear_algebra_funcs.py:16-44
+    G = golden
+    assert np.array_equal(oracle.dgemm(G["la_A"], G["la_B"]).shape, G["la_dgemm"].shape)
+    np.testing.assert_allclose(oracle.dgemm(G["la_A"], G["la_B"]), G["la_dgemm"], rtol=1e-14)
+    np.testing.assert_allclose(oracle.dgemm(G["la_A"], G["la_B"]), G["la_A"].T @ G["la_B"].T,
+                               rtol=1e-14)
+    assert oracle.norm2(G["la_q"]) == pytest.approx(float(G["la_norm2"]), rel=1e-15)
+    assert oracle.scalprod(G["la_q"], G["la_q2"]) == pytest.approx(float(G["la_scalprod"]), rel=1e-14)
+
+
+def test_generators(golden, oracle):
+    # utilities/utilities_functions.py:99-107
+    np.testing.assert_array_equal(oracle.angles_gen(0.3, 50), golden["gen_angles"])
+
+
+@pytest.mark.parametrize("lam", [1, 2, 33])
+def test_toeplitz_bitexact(golden, oracle, lam):
+    # interfaces/linearoperators.py:582-595 -- same summation order => bit equal
+    a, v, y = golden["toep_a%d" % lam], golden["toep_v"], golden["toep_y%d" % lam]
+    np.testing.assert_array_equal(oracle.toeplitz_mult(a, v), y)
+    np.testing.assert_array_equal(oracle.toeplitz_mult_numpy(a, v.copy()), y)
+
+
+def test_toeplitz_band_longer_than_block(golden, oracle):
+    np.testing.assert_array_equal(
+        oracle.toeplitz_mult(golden["toep_a9"], golden["toep_vshort"]), golden["toep_yshort"])
+
+
+def _weights(G, npix_key="bd_counts"):
+    r = SimpleNamespace(counts=G["bd_counts"], cosine=G["bd_cos"], sine=G["bd_sin"],
+                        cos2=G["bd_cos2"], sin2=G["bd_sin2"], sincos=G["bd_sincos"])
+    r.new_npix = r.counts.shape[0]
+    return r
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_block_diagonal_lo_bitexact(golden, oracle, pol):
+    # interfaces/linearoperators.py:728-746
+    r = _weights(golden)
+    np.testing.assert_array_equal(oracle.bd_mult(pol, r, golden["bd_x%d" % pol]),
+                                  golden["bd_y%d" % pol])
+
+
+def test_bd_preconditioner_pol1(golden, oracle):
+    # interfaces/linearoperators.py:788-790
+    r = _weights(golden)
+    r.counts = golden["bdp1_counts"]
+    y = oracle.bd_precond_mult(1, r, golden["bdp1_x"])
+    np.testing.assert_array_equal(y, golden["bdp1_y"])
+    assert y[2] == 0.0 and y[11] == 0.0            # unobserved pixels -> 0
+
+
+def test_deflation(golden, oracle):
+    # interfaces/linearoperators.py:1041-1056
+    Z = golden["defl_Z"]
+    np.testing.assert_array_equal(oracle.deflation_mult(Z, golden["defl_y"]), golden["defl_Zy"])
+    np.testing.assert_allclose(oracle.deflation_rmult(Z, golden["defl_x"]), golden["defl_Ztx"],
+                               rtol=1e-14)
+
+
+def test_coarse(golden, oracle):
+    # interfaces/linearoperators.py:969-1027
+    Z, A, v = golden["defl_Z"], golden["coarse_A"], golden["coarse_v"]
+    Az = A @ Z
+    lu = oracle.Coarse(Z, Az, 4, apply='LU')
+    np.testing.assert_allclose(lu.E, golden["coarse_E"], rtol=1e-14)
+    np.testing.assert_allclose(lu.mult(v), golden["coarse_lu_x"], rtol=1e-12)
+    eig = oracle.Coarse(Z, Az, 4, apply='eig')
+    np.testing.assert_allclose(eig.invE, golden["coarse_invE"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(eig.mult(v), golden["coarse_eig_x"], rtol=1e-10)
+    # degenerate E: one eigenvalue dropped (:997-999)
+    Zd = Z.copy()
+    Zd[:, 3] = Zd[:, 0]
+    deg = oracle.Coarse(Zd, A @ Zd, 4, apply='eig')
+    np.testing.assert_allclose(deg.invE, golden["coarse_deg_invE"], rtol=1e-8, atol=1e-12)
+    assert np.linalg.matrix_rank(deg.invE, tol=1e-9) == 3
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_repixelization(golden, oracle, pol):
+    # utilities/process_ces.py:351-401 : old2new / compaction semantics
+    G = golden
+    mask = G["repix%d_mask" % pol]
+    nold = G["repix%d_old2new" % pol].shape[0]
+    keep = np.zeros(nold, dtype=bool)
+    keep[mask] = True
+    old2new = np.full(nold, -1, dtype=np.int64)
+    old2new[keep] = np.arange(keep.sum())
+    np.testing.assert_array_equal(old2new, G["repix%d_old2new" % pol])
+    assert int(keep.sum()) == int(G["repix%d_npix" % pol])
+    np.testing.assert_array_equal(np.arange(100, 100 + nold)[keep], G["repix%d_obspix" % pol])
+    keys = {1: ("counts",), 2: ("cos2", "sin2", "sincos"),
+            3: ("counts", "cosine", "sine", "cos2", "sin2", "sincos")}[pol]
+    for k in keys:
+        np.testing.assert_array_equal(G["repix%d_in_%s" % (pol, k)][keep],
+                                      G["repix%d_out_%s" % (pol, k)])
+
+
+def test_arnoldi_build_hess_build_Z(golden, oracle):
+    # interfaces/deflationlib.py:17-184
+    G = golden
+    A, b = G["arn_A"], G["arn_b"]
+    vs, hs, j = oracle.arnoldi(lambda x: A @ x, b, np.zeros_like(b), tol=1e-8, inner_m=30)
+    assert j == int(G["arn_j"])
+    np.testing.assert_allclose(np.asarray(vs), G["arn_V"], rtol=0, atol=1e-9)
+    H = oracle.build_hess(hs, j)
+    np.testing.assert_allclose(H, G["arn_H"], rtol=0, atol=1e-9)
+    z, y = np.linalg.eigh(H)
+    np.testing.assert_allclose(z, G["arn_ritz"], rtol=1e-8, atol=1e-10)
+    Z, r = oracle.build_Z(G["arn_ritz"], np.linalg.eigh(G["arn_H"])[1], G["arn_V"].T.copy(), 1e-2)
+    assert r == int(G["arn_r"])
+    np.testing.assert_allclose(Z, G["arn_Z"], rtol=1e-12, atol=1e-14)
+    assert int(G["arn_raises_at_inner_m"]) == 1
+    with pytest.raises(RuntimeError):
+        oracle.arnoldi(lambda x: A @ x, b, np.zeros_like(b), tol=1e-8, inner_m=3)
+    assert int(G["arn_nonfinite_raises"]) == 1
+    with pytest.raises(ValueError):
+        oracle.arnoldi(lambda x: A @ x, b * np.nan, np.zeros_like(b))
+    assert int(G["arn_zero_residual_returns_j0"]) == 1
+    assert oracle.arnoldi(lambda x: A @ x, A @ np.ones(30), np.ones(30), tol=1e-5)[2] == 0
+
+
+def test_cg_recurrence_equals_local_scipy(oracle):
+    # scipy.sparse.linalg.cg is the reference's PCG driver
+    # (tests/test_2level_preconditioner.py:52, src/test_BD_precond_onto_real_data.py:47)
+    rng = np.random.default_rng(5)
+    n = 60
+    S = rng.standard_normal((n, n))
+    A = S @ S.T + n * np.eye(n)
+    Minv = np.diag(1.0 / np.diag(A))
+    b = rng.standard_normal(n)
+    for x0 in (None, np.ones(n)):
+        its_s, its_o = [], []
+        xs, info_s = spla.cg(A, b, x0=x0, rtol=1e-8, M=Minv, callback=lambda x: its_s.append(1))
+        xo, info_o = oracle.cg(lambda v: A @ v, b, x0=x0, rtol=1e-8, M=lambda v: Minv @ v,
+                               callback=lambda x: its_o.append(1))
+        assert info_s == info_o == 0
+        assert len(its_s) == len(its_o)
+        np.testing.assert_array_equal(xs, xo)
+    x, info = oracle.cg(lambda v: A @ v, b, rtol=1e-14, maxiter=3)
+    assert info == 3
