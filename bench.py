@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""
+bench.py -- TOD samples/s through one P^T N^-1 P matvec (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
+
+A "step" is one application of A = P^T N^-1 P to a map-domain vector with all inputs
+already resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each
+rank owns a block-aligned TOD shard of the same size (weak scaling), a step is the local
+matvec followed by the RCCL all-reduce of the map.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs; synthetic inputs after utilities_functions.py:99-212:
+uniform-random pixel per sample, HWP angle ramp, d ~ U[0,1)):
+  c2  nside 128 IQU, 1e7 samples, diagonal N (100 blocks)        -> fused single kernel
+  c3  nside 128 IQU, 1e8 samples, banded-Toeplitz N, lambda 2048 -> P, overlap-save FFT, P^T
+  c4  nside 256 IQU, 1e8 samples/GPU, Toeplitz lambda 2048       -> the configuration the
+      north_star target (>= 40 % HBM roofline) is quoted on; DEFAULT.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    "c2": dict(nside=128, nt=10_000_000, nb=100, lam=0, label="C2 nside128 IQU 1e7 diag-N"),
+    "c3": dict(nside=128, nt=100_000_000, nb=100, lam=2048,
+               label="C3 nside128 IQU 1e8 Toeplitz(2048)"),
+    "c4": dict(nside=256, nt=100_000_000, nb=100, lam=2048,
+               label="C4 nside256 IQU 1e8/GPU Toeplitz(2048)"),
+}
+
+
+def toeplitz_band(lam, rng):
+    """SPD 1/f-like inverse-noise autocorrelation tapered to `lam` lags (build-defined
+    input): white level plus a decaying correlated part, diagonally dominant."""
+    k = np.arange(lam)
+    a = 0.5 * np.exp(-k / (0.15 * lam)) * np.cos(np.pi * k / (2.0 * lam))
+    a *= 0.45 / max(a[1:].sum() * 2.0, 1e-30)
+    a[0] = 1.0 + 0.1 * rng.random()
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.environ.get("CM2_BENCH_CONFIG", "c4"),
+                    choices=sorted(CONFIGS))
+    ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
+    ap.add_argument("--fft-len", type=int, default=0)
+    args = ap.parse_args()
+    if args.fft_len:
+        os.environ["CM2_FFT_LEN"] = str(args.fft_len)
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import cosmomap2_amd
+    from cosmomap2_amd import device as D
+    from cosmomap2_amd import _hip
+    from cosmomap2_amd.interfaces import SparseLO, BlockLO, BlockDiagonalPreconditionerLO
+    from cosmomap2_amd.utilities import ProcessTimeSamples
+    from cosmomap2_amd.sharding import ShardedLO, make_sync
+
+    cfg = dict(CONFIGS[args.config])
+    if args.nt:
+        cfg["nt"] = args.nt
+    pol = 3
+    npix = 12 * cfg["nside"] ** 2
+    nb = cfg["nb"]
+    nt = (cfg["nt"] // nb) * nb
+    bsize = nt // nb
+    lam = cfg["lam"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    # ---- synthetic shard, generated in HBM (seed differs per rank) -------------------
+    t_setup = time.time()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20161202 + 1000 * rank)
+    rng = np.random.default_rng(20161202 + 1000 * rank)
+    pix = torch.randint(0, npix, (nt,), generator=gen, device=dev, dtype=torch.int32)
+    theta0 = float(rng.uniform(0, np.pi))
+    phi = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+    d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
+    if lam:
+        bands = [toeplitz_band(lam, rng) for _ in range(nb)]
+        N = BlockLO(bsize, bands, offdiag=True, method=2)
+        w = None
+    else:
+        N = BlockLO(bsize, list(rng.random(nb) + 0.5), offdiag=False)
+        w = N._device_diag()
+    allred = None
+    if world > 1:
+        allred = lambda t: dist.all_reduce(t)
+    ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi, w=w, allreduce=allred)
+    del phi
+    npix_c = ces.get_new_pixel[0]
+    P = SparseLO(npix_c, nt, pix, pol=pol, angle_processed=ces)
+    Mbd = BlockDiagonalPreconditionerLO(ces, npix_c, pol=pol)
+    A_local = P.T * N * P
+    A = ShardedLO(A_local) if world > 1 else A_local
+    n = pol * npix_c
+    x = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(7), device=dev,
+                   dtype=torch.float64)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: W warmup + exactly K steps ------------------------------------
+    for _ in range(args.warmup):
+        y = A * x
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = A * x
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * nt / (elapsed / args.steps)
+
+    # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
+    def ev_time(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return float(np.mean(ts)), float(ts[len(ts) // 2])
+
+    reps = max(5, min(args.steps, 20))
+    stages = {}
+    map_bytes = 48.0 * npix_c
+    if lam:
+        tod = P * x
+        tod2 = N * tod
+        stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2)
+        stages["N^-1 (overlap-save rocFFT)"] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
+        stages["P^T (k_Pt_sell)"] = (ev_time(lambda: P.T * tod2, reps), 28.0 * nt + map_bytes / 2)
+        step_bytes = 72.0 * nt + map_bytes
+        del tod, tod2
+    else:
+        stages["P^T diag(w) P fused (k_PtNP_sell)"] = (ev_time(lambda: A_local * x, reps),
+                                                       28.0 * nt + map_bytes)
+        step_bytes = 28.0 * nt + map_bytes
+    dom = max(stages, key=lambda k: stages[k][0][0])
+    (dom_mean, dom_med), dom_bytes = stages[dom]
+    achieved = dom_bytes / (dom_mean * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes": dom_bytes,
+                "avg_launch_ms": round(dom_mean, 4)}
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    stage_report = {k: {"ms": round(v[0][0], 4), "GB/s": round(v[1] / (v[0][0] * 1e-3) / 1e9, 1)}
+                    for k, v in stages.items()}
+
+    # ---- PCG iterations to 1e-6 (outside the timed region) ----------------------------
+    pcg = None
+    if not args.no_pcg:
+        b = P.T * (N * d)
+        if world > 1:
+            dist.all_reduce(b)
+        its = []
+        tp = time.perf_counter()
+        xs, info = cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=500,
+                                    callback=lambda xk: its.append(1), sync=make_sync())
+        torch.cuda.synchronize()
+        pcg = {"rtol": 1e-6, "iters": len(its), "info": int(info),
+               "seconds": round(time.perf_counter() - tp, 3), "preconditioner": "block-diagonal"}
+
+    # ---- CPU baseline: the oracle (1 core, reference-unfused) on a bounded sample -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+        orc.build()
+        ns = min(nt, 1_000_000 if lam else 20_000_000)
+        ns = (ns // bsize) * bsize if ns >= bsize else ns
+        hp = pix[:ns].cpu().numpy()
+        hc, hs = ces._d_cos[:ns].cpu().numpy(), ces._d_sin[:ns].cpu().numpy()
+        hx = x.cpu().numpy()
+        tcpu0 = time.perf_counter()
+        repsc = 0
+        if lam:
+            nblk = max(1, ns // bsize)
+            hb = bands[:nblk]
+            while True:
+                todc = orc.sparse_mult(pol, hp, hc, hs, hx)
+                todc = orc.blocklo_mult(bsize if ns >= bsize else ns, hb, True, todc)
+                orc.sparse_rmult(pol, npix_c, hp, hc, hs, todc)
+                repsc += 1
+                if time.perf_counter() - tcpu0 > 10.0:
+                    break
+            sample = ("%d-sample slice of the same workload (%d block(s)), direct banded "
+                      "Toeplitz lambda=%d as interfaces/linearoperators.py:582-595, cost exactly "
+                      "linear in samples" % (ns, nblk, lam))
+        else:
+            hw = w[:ns].cpu().numpy()
+            while True:
+                orc.ptnp_diag(pol, npix_c, hp, hc, hs, hw, hx)
+                repsc += 1
+                if time.perf_counter() - tcpu0 > 10.0:
+                    break
+            sample = "%d-sample slice of the same workload, unfused P, diag(w), P^T" % ns
+        tcpu = time.perf_counter() - tcpu0
+        cpu = {"value": round(ns * repsc / tcpu, 1), "unit": "TOD samples/s", "cores": 1,
+               "kind": "port", "sample": sample, "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "TOD samples/s through P^T N^-1 P",
+            "value": value, "unit": "TOD samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["label"], "nside": cfg["nside"], "pol": pol,
+                       "nt_per_gpu": nt, "npix": int(npix_c), "noise": ("toeplitz" if lam else "diag"),
+                       "lambda": lam, "blocks_per_gpu": nb,
+                       "fft_len": (N.noise_info()["fft_len"] if lam else 0),
+                       "parallelism": "tod-shard x%d + map all-reduce" % world},
+            "roofline": roofline,
+            "step_algorithmic_GBps": round(step_gbs, 1),
+            "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
+            "stages": stage_report,
+            "pcg": pcg,
+            "cpu_baseline": cpu,
+            "setup_seconds": round(t_setup, 2),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""
+ctypes binding of libcosmomap2_hip.so (the C ABI in include/cosmomap2.h).
+
+There is NO CPU fallback: if the shared library has not been built
+(`python -m cosmomap2_amd.build`) or no GPU is present, the first call that needs
+the device raises.  Pointers are passed as integers (torch ``data_ptr()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcosmomap2_hip.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "cm2_last_error": [],
+    "cm2_abi_version": [],
+    "cm2_device_info": [_int, ctypes.c_char_p, ctypes.POINTER(_int), ctypes.POINTER(_dbl)],
+    "cm2_pointing_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _vp],
+    "cm2_pointing_destroy": [_vp],
+    "cm2_pointing_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_P_apply": [_vp, _vp, _vp, _vp],
+    "cm2_Pt_apply": [_vp, _vp, _vp, _vp],
+    "cm2_pointing_set_weights": [_vp, _vp, _vp],
+    "cm2_PtNP_diag_apply": [_vp, _vp, _vp, _vp],
+    "cm2_noise_create_diag": [ctypes.POINTER(_vp), ctypes.POINTER(_dbl), ctypes.POINTER(_i64), _i64],
+    "cm2_noise_create_toeplitz": [ctypes.POINTER(_vp), ctypes.POINTER(_dbl), _i64,
+                                  ctypes.POINTER(_i64), _i64, _int, _vp],
+    "cm2_noise_destroy": [_vp],
+    "cm2_noise_apply": [_vp, _vp, _vp, _vp],
+    "cm2_noise_expand_diag": [_vp, _vp, _vp],
+    "cm2_noise_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_weights_accumulate": [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cm2_pixel_mask": [_int, _i64, _vp, _vp, _vp, _vp, _dbl, _vp, _vp],
+    "cm2_pixel_compact": [_i64, _vp, _vp, ctypes.POINTER(_i64), _vp],
+    "cm2_compact_f64": [_i64, _vp, _vp, _vp, _vp],
+    "cm2_compact_i64": [_i64, _vp, _vp, _vp, _vp],
+    "cm2_flag_samples": [_i64, _vp, _vp, _vp],
+    "cm2_bd_det_mask": [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cm2_bdprecond_apply": [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cm2_bd_apply": [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cm2_reduce_work_doubles": [],
+    "cm2_dot": [_i64, _vp, _vp, _vp, _vp, _vp],
+    "cm2_axpy": [_i64, _dbl, _vp, _vp, _vp],
+    "cm2_scal": [_i64, _dbl, _vp, _vp],
+    "cm2_xmy": [_i64, _vp, _vp, _vp, _vp],
+    "cm2_pcg_update_p": [_i64, _vp, _vp, _vp, _vp, _vp],
+    "cm2_pcg_update_xr": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cm2_Zt_apply": [_i64, _int, _vp, _vp, _vp, _vp, _vp],
+    "cm2_Z_apply": [_i64, _int, _vp, _vp, _vp, _vp],
+    "cm2_gemm_tn_work_doubles": [_int, _int],
+    "cm2_gemm_tn": [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "cm2_small_matvec": [_int, _vp, _vp, _vp, _vp],
+    "cm2_gemm_atbt": [_i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "cm2_cos_sin_2phi": [_i64, _vp, _vp, _vp, _vp],
+    "cm2_m2_finish": [_int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                      _vp, _vp, _vp],
+}
+_RESTYPE = {"cm2_last_error": ctypes.c_char_p, "cm2_reduce_work_doubles": _i64,
+            "cm2_gemm_tn_work_doubles": _i64}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol of include/cosmomap2.h."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(
+                "libcosmomap2_hip.so is not built (%s); run `python -m cosmomap2_amd.build`. "
+                "There is no CPU fallback for the map-making kernels." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, _int)
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cm2_last_error()
+        raise HipError(msg.decode() if msg else "libcosmomap2_hip call failed (rc=%d)" % rc)
+
+
+def call(name, *args):
+    """Call an int-status entry point and raise HipError with cm2_last_error()."""
+    check(getattr(load(), name)(*args))

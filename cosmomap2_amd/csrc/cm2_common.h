@@ -1,0 +1,74 @@
+// cm2_common.h -- shared helpers for the gfx950 kernels behind include/cosmomap2.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/cosmomap2.h"
+
+namespace cm2 {
+
+void set_error(const char *fmt, ...);
+
+#define CM2_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            cm2::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),     \
+                           __FILE__, __LINE__);                                        \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+#define CM2_CHECK(cond, ...)                                                           \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            cm2::set_error(__VA_ARGS__);                                               \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+
+// launch-error check after a kernel launch (does not synchronise)
+#define CM2_LAUNCH_OK() CM2_HIP(hipGetLastError())
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // default workgroup: 4 waves
+constexpr int kNumCU = 256;        // MI355X
+constexpr uint32_t kInvalidSample = 0xFFFFFFFFu;
+
+// memory-bound grid: enough workgroups to fill 256 CUs x 8, grid-stride the rest
+static inline int grid_for(int64_t n, int block = kBlock, int max_blocks = kNumCU * 8)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// full-wave sum via DPP-friendly shuffles (64 lanes), result valid in lane 0
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum for 256-thread workgroups; result valid in thread 0.
+// fixed order: lanes tree-reduced per wave, then waves 0..3 added in order.
+__device__ __forceinline__ double block_sum_256(double v, double *lds4)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds4[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace cm2

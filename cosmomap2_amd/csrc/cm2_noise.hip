@@ -1,0 +1,385 @@
+// cm2_noise.hip -- the inverse noise operator N^-1 on the TOD stream.
+//
+// Reference code replaced:
+//   BlockLO / build_blocks            interfaces/linearoperators.py:655-690
+//   blk_matvec (per-block dispatch)   interfaces/blkop.py:178-208
+//   ToeplitzLO.mult                   interfaces/linearoperators.py:582-595
+//
+// Two block kinds, both block-diagonal over `nblocks` stationary intervals:
+//   * constant diagonal  t_b * I                       (offdiag=False)
+//   * symmetric banded Toeplitz with first row a_b[0..lambda-1], ZERO boundary at
+//     both ends of every block (the reference is not circulant, :592-593)
+//
+// Toeplitz is applied
+//   DIRECT  : y_k = a0 v_k + sum_i a_i v_{k+i} + a_i v_{k-i} in the reference's term
+//             order (bit-exact; O(n*lambda), used for short bands), or
+//   FFT     : overlap-save with rocFFT fp64 R2C/C2R of length L: each segment carries
+//             hop = L - 2(lambda-1) new samples plus a halo of lambda-1 on both sides,
+//             zero outside its block; spectrum of the band is real (symmetric kernel)
+//             and is evaluated in closed form H_k = (a0 + 2 sum_j a_j cos(2 pi j k/L))/L.
+// Algorithmic traffic 16 B/sample (read v, write y); the rocFFT route moves
+// ~7x that through HBM (pack, 2 FFTs, spectrum multiply, unpack) -- see DESIGN.md.
+#include "cm2_common.h"
+
+#include <rocfft/rocfft.h>
+
+#include <cstdlib>
+#include <vector>
+
+using namespace cm2;
+
+struct cm2_noise {
+    int64_t nt = 0, nb = 0, lambda = 0;
+    int method = 0;
+    bool equal_sizes = true;
+    int64_t bsize = 0;
+    int64_t *d_off = nullptr;    // [nb+1] block offsets
+    double *d_t = nullptr;       // [nb] diagonal values  | [nb*lambda] bands
+    // overlap-save state
+    int64_t L = 0, hop = 0, halo = 0, nseg = 0, nfreq = 0;
+    int64_t *d_seg = nullptr;    // [nseg*4]: out_start, out_len, blk_lo, blk_hi
+    int32_t *d_seg_blk = nullptr;
+    double *d_X = nullptr;       // [nseg][L]
+    double2 *d_F = nullptr;      // [nseg][L/2+1]
+    double *d_H = nullptr;       // [nb][L/2+1] real spectra, 1/L folded in
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *d_fftwork = nullptr;
+    size_t fftwork_bytes = 0;
+};
+
+#define CM2_FFT(call)                                                                  \
+    do {                                                                               \
+        rocfft_status s__ = (call);                                                    \
+        if (s__ != rocfft_status_success) {                                            \
+            cm2::set_error("%s failed: rocfft_status %d (%s:%d)", #call, (int)s__,     \
+                           __FILE__, __LINE__);                                        \
+            return 3;                                                                  \
+        }                                                                              \
+    } while (0)
+
+__device__ __forceinline__ int find_block(const int64_t *__restrict__ off, int nb, int64_t k,
+                                          bool equal, int64_t bsize)
+{
+    if (equal) return (int)(k / bsize);
+    int lo = 0, hi = nb;              // largest b with off[b] <= k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------- diagonal -------
+__global__ __launch_bounds__(256) void k_diag_apply(int64_t nt, int nb, bool equal, int64_t bsize,
+                                                     const int64_t *__restrict__ off,
+                                                     const double *__restrict__ t,
+                                                     const double *__restrict__ v,
+                                                     double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nt; k += stride) {
+        const int b = find_block(off, nb, k, equal, bsize);
+        out[k] = v ? t[b] * v[k] : t[b];     // lp.DiagonalOperator: diag * x
+    }
+}
+
+// --------------------------------------------------- Toeplitz, direct ---------
+// Term order of the NumPy loop linearoperators.py:587-593:
+//   a0 v_k, then for i = 1..lambda-1:  + a_i v_{k+i} (y[:-i]+=temp[i:]),  + a_i v_{k-i}
+__global__ __launch_bounds__(256) void k_toeplitz_direct(int64_t nt, int nb, bool equal,
+                                                          int64_t bsize, int64_t lambda,
+                                                          const int64_t *__restrict__ off,
+                                                          const double *__restrict__ bands,
+                                                          const double *__restrict__ v,
+                                                          double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nt; k += stride) {
+        const int b = find_block(off, nb, k, equal, bsize);
+        const int64_t lo = off[b], hi = off[b + 1];
+        const double *a = bands + (int64_t)b * lambda;
+        double acc = a[0] * v[k];
+        for (int64_t i = 1; i < lambda; ++i) {
+            if (k + i < hi) acc += a[i] * v[k + i];
+            if (k - i >= lo) acc += a[i] * v[k - i];
+        }
+        out[k] = acc;
+    }
+}
+
+// --------------------------------------------------- Toeplitz, overlap-save ---
+// H[b][k] = (a0 + 2 sum_{j>=1} a_j cos(2 pi (j k mod L) / L)) / L
+__global__ __launch_bounds__(256) void k_spectrum(int nb, int64_t lambda, int64_t L, int64_t nfreq,
+                                                   const double *__restrict__ bands,
+                                                   double *__restrict__ H)
+{
+    const int64_t total = (int64_t)nb * nfreq;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / nfreq, k = e % nfreq;
+        const double *a = bands + b * lambda;
+        double acc = 0.0;
+        for (int64_t j = lambda - 1; j >= 1; --j) {       // small terms first
+            const int64_t m = (j * k) % L;
+            acc += a[j] * cospi(2.0 * (double)m / (double)L);
+        }
+        H[e] = (a[0] + 2.0 * acc) / (double)L;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack(int64_t L, int64_t halo,
+                                               const int64_t *__restrict__ seg,
+                                               const double *__restrict__ v,
+                                               double *__restrict__ X)
+{
+    const int64_t s = blockIdx.y;
+    const int64_t out_start = seg[4 * s], lo = seg[4 * s + 2], hi = seg[4 * s + 3];
+    double *x = X + s * L;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = out_start - halo + j;
+        x[j] = (src >= lo && src < hi) ? v[src] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_spec_mul(int64_t nfreq, const int32_t *__restrict__ seg_blk,
+                                                   const double *__restrict__ H,
+                                                   double2 *__restrict__ F)
+{
+    const int64_t s = blockIdx.y;
+    const double *h = H + (int64_t)seg_blk[s] * nfreq;
+    double2 *f = F + s * nfreq;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nfreq;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        double2 z = f[k];
+        const double hk = h[k];
+        z.x *= hk;
+        z.y *= hk;
+        f[k] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack(int64_t L, int64_t halo,
+                                                 const int64_t *__restrict__ seg,
+                                                 const double *__restrict__ X,
+                                                 double *__restrict__ out)
+{
+    const int64_t s = blockIdx.y;
+    const int64_t out_start = seg[4 * s], out_len = seg[4 * s + 1];
+    const double *x = X + s * L + halo;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < out_len;
+         j += (int64_t)gridDim.x * blockDim.x)
+        out[out_start + j] = x[j];
+}
+
+// ------------------------------------------------------------------ C ABI ------
+static int noise_common(cm2_noise *n, const int64_t *h_sizes, int64_t nb,
+                        std::vector<int64_t> &off)
+{
+    CM2_CHECK(nb >= 1, "noise operator needs at least one block (nblocks=%lld)", (long long)nb);
+    off.assign(nb + 1, 0);
+    n->equal_sizes = true;
+    for (int64_t b = 0; b < nb; ++b) {
+        CM2_CHECK(h_sizes[b] > 0, "block %lld has non-positive size %lld", (long long)b,
+                  (long long)h_sizes[b]);
+        off[b + 1] = off[b] + h_sizes[b];
+        if (h_sizes[b] != h_sizes[0]) n->equal_sizes = false;
+    }
+    n->nb = nb;
+    n->nt = off[nb];
+    n->bsize = h_sizes[0];
+    CM2_HIP(hipMalloc(&n->d_off, sizeof(int64_t) * (nb + 1)));
+    CM2_HIP(hipMemcpy(n->d_off, off.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int cm2_noise_destroy(cm2_noise *n)
+{
+    if (!n) return 0;
+    if (n->fwd) rocfft_plan_destroy(n->fwd);
+    if (n->inv) rocfft_plan_destroy(n->inv);
+    if (n->info) rocfft_execution_info_destroy(n->info);
+    void *ptrs[] = {n->d_off, n->d_t, n->d_seg, n->d_seg_blk, n->d_X, n->d_F, n->d_H, n->d_fftwork};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete n;
+    return 0;
+}
+
+extern "C" int cm2_noise_create_diag(cm2_noise **out, const double *h_t, const int64_t *h_sizes,
+                                     int64_t nblocks)
+{
+    CM2_CHECK(out && h_t && h_sizes, "cm2_noise_create_diag: NULL argument");
+    *out = nullptr;
+    cm2_noise *n = new cm2_noise();
+    std::vector<int64_t> off;
+    if (int rc = noise_common(n, h_sizes, nblocks, off)) { cm2_noise_destroy(n); return rc; }
+    n->lambda = 0;
+    n->method = 0;
+    CM2_HIP(hipMalloc(&n->d_t, sizeof(double) * nblocks));
+    CM2_HIP(hipMemcpy(n->d_t, h_t, sizeof(double) * nblocks, hipMemcpyHostToDevice));
+    *out = n;
+    return 0;
+}
+
+static int64_t pick_fft_length(int64_t halo, int64_t max_block)
+{
+    if (const char *e = getenv("CM2_FFT_LEN")) {
+        const int64_t v = atoll(e);
+        if (v > 2 * halo + 1) return v;
+    }
+    int64_t L = 256;
+    while (L < 8 * halo) L <<= 1;                 // hop >= 3/4 L
+    int64_t need = 1;                             // but never longer than one padded block
+    while (need < max_block + 2 * halo) need <<= 1;
+    if (need < L) L = need;
+    if (L < 2 * halo + 2) L = 2 * (2 * halo + 2);
+    return L;
+}
+
+extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands, int64_t lambda,
+                                         const int64_t *h_sizes, int64_t nblocks, int method,
+                                         void *stream_)
+{
+    CM2_CHECK(out && h_bands && h_sizes, "cm2_noise_create_toeplitz: NULL argument");
+    CM2_CHECK(lambda >= 1, "cm2_noise_create_toeplitz: band length lambda=%lld < 1", (long long)lambda);
+    CM2_CHECK(method >= 0 && method <= 2, "cm2_noise_create_toeplitz: bad method %d", method);
+    *out = nullptr;
+    hipStream_t stream = as_stream(stream_);
+    cm2_noise *n = new cm2_noise();
+    std::vector<int64_t> off;
+    if (int rc = noise_common(n, h_sizes, nblocks, off)) { cm2_noise_destroy(n); return rc; }
+    n->lambda = lambda;
+    if (method == CM2_TOEPLITZ_AUTO) method = (lambda <= 32) ? CM2_TOEPLITZ_DIRECT : CM2_TOEPLITZ_FFT;
+    n->method = method;
+    CM2_HIP(hipMalloc(&n->d_t, sizeof(double) * nblocks * lambda));
+    CM2_HIP(hipMemcpy(n->d_t, h_bands, sizeof(double) * nblocks * lambda, hipMemcpyHostToDevice));
+    if (method == CM2_TOEPLITZ_DIRECT) {
+        *out = n;
+        return 0;
+    }
+    // ---- overlap-save plan ----
+    int64_t max_block = 0;
+    for (int64_t b = 0; b < nblocks; ++b) max_block = h_sizes[b] > max_block ? h_sizes[b] : max_block;
+    n->halo = lambda - 1;
+    n->L = pick_fft_length(n->halo, max_block);
+    n->hop = n->L - 2 * n->halo;
+    n->nfreq = n->L / 2 + 1;
+    std::vector<int64_t> seg;
+    std::vector<int32_t> seg_blk;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += n->hop) {
+            const int64_t len = (off[b + 1] - s0 < n->hop) ? off[b + 1] - s0 : n->hop;
+            seg.push_back(s0);
+            seg.push_back(len);
+            seg.push_back(off[b]);
+            seg.push_back(off[b + 1]);
+            seg_blk.push_back((int32_t)b);
+        }
+    }
+    n->nseg = (int64_t)seg_blk.size();
+    CM2_CHECK(n->nseg < 65536LL * 32768LL, "too many FFT segments (%lld)", (long long)n->nseg);
+    CM2_HIP(hipMalloc(&n->d_seg, sizeof(int64_t) * seg.size()));
+    CM2_HIP(hipMalloc(&n->d_seg_blk, sizeof(int32_t) * seg_blk.size()));
+    CM2_HIP(hipMemcpy(n->d_seg, seg.data(), sizeof(int64_t) * seg.size(), hipMemcpyHostToDevice));
+    CM2_HIP(hipMemcpy(n->d_seg_blk, seg_blk.data(), sizeof(int32_t) * seg_blk.size(),
+                      hipMemcpyHostToDevice));
+    CM2_HIP(hipMalloc(&n->d_X, sizeof(double) * n->nseg * n->L));
+    CM2_HIP(hipMalloc(&n->d_F, sizeof(double2) * n->nseg * n->nfreq));
+    CM2_HIP(hipMalloc(&n->d_H, sizeof(double) * nblocks * n->nfreq));
+    k_spectrum<<<grid_for(nblocks * n->nfreq), kBlock, 0, stream>>>((int)nblocks, lambda, n->L,
+                                                                   n->nfreq, n->d_t, n->d_H);
+    CM2_LAUNCH_OK();
+
+    static bool rocfft_ready = false;
+    if (!rocfft_ready) {
+        CM2_FFT(rocfft_setup());
+        rocfft_ready = true;
+    }
+    const size_t lengths[1] = {(size_t)n->L};
+    CM2_FFT(rocfft_plan_create(&n->fwd, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_forward, rocfft_precision_double, 1,
+                               lengths, (size_t)n->nseg, nullptr));
+    CM2_FFT(rocfft_plan_create(&n->inv, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_inverse, rocfft_precision_double, 1,
+                               lengths, (size_t)n->nseg, nullptr));
+    size_t w1 = 0, w2 = 0;
+    CM2_FFT(rocfft_plan_get_work_buffer_size(n->fwd, &w1));
+    CM2_FFT(rocfft_plan_get_work_buffer_size(n->inv, &w2));
+    n->fftwork_bytes = w1 > w2 ? w1 : w2;
+    CM2_FFT(rocfft_execution_info_create(&n->info));
+    if (n->fftwork_bytes) {
+        CM2_HIP(hipMalloc(&n->d_fftwork, n->fftwork_bytes));
+        CM2_FFT(rocfft_execution_info_set_work_buffer(n->info, n->d_fftwork, n->fftwork_bytes));
+    }
+    CM2_HIP(hipStreamSynchronize(stream));
+    *out = n;
+    return 0;
+}
+
+extern "C" int cm2_noise_info(const cm2_noise *n, int64_t *h_info)
+{
+    CM2_CHECK(n && h_info, "cm2_noise_info: NULL argument");
+    h_info[0] = n->nt; h_info[1] = n->nb; h_info[2] = n->lambda;
+    h_info[3] = n->method; h_info[4] = n->L;
+    return 0;
+}
+
+extern "C" int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream_)
+{
+    CM2_CHECK(n && d_w, "cm2_noise_expand_diag: NULL argument");
+    CM2_CHECK(n->lambda == 0, "cm2_noise_expand_diag: operator has off-diagonal terms");
+    k_diag_apply<<<grid_for(n->nt), kBlock, 0, as_stream(stream_)>>>(
+        n->nt, (int)n->nb, n->equal_sizes, n->bsize, n->d_off, n->d_t, nullptr, d_w);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, void *stream_)
+{
+    CM2_CHECK(n && d_v && d_out, "cm2_noise_apply: NULL argument");
+    CM2_CHECK(d_v != d_out, "cm2_noise_apply: in-place application is not supported");
+    hipStream_t stream = as_stream(stream_);
+    if (n->lambda == 0) {
+        k_diag_apply<<<grid_for(n->nt), kBlock, 0, stream>>>(n->nt, (int)n->nb, n->equal_sizes,
+                                                             n->bsize, n->d_off, n->d_t, d_v, d_out);
+        CM2_LAUNCH_OK();
+        return 0;
+    }
+    if (n->method == CM2_TOEPLITZ_DIRECT) {
+        k_toeplitz_direct<<<grid_for(n->nt), kBlock, 0, stream>>>(
+            n->nt, (int)n->nb, n->equal_sizes, n->bsize, n->lambda, n->d_off, n->d_t, d_v, d_out);
+        CM2_LAUNCH_OK();
+        return 0;
+    }
+    // overlap-save: pack -> R2C -> spectrum multiply -> C2R -> unpack
+    const int gx_L = (int)((n->L + kBlock * 4 - 1) / (kBlock * 4));
+    const int64_t per_launch = 65535;             // gridDim.y limit
+    for (int64_t s0 = 0; s0 < n->nseg; s0 += per_launch) {
+        const int ny = (int)((n->nseg - s0 < per_launch) ? n->nseg - s0 : per_launch);
+        k_pack<<<dim3(gx_L, ny), kBlock, 0, stream>>>(n->L, n->halo, n->d_seg + 4 * s0, d_v,
+                                                      n->d_X + s0 * n->L);
+        CM2_LAUNCH_OK();
+    }
+    CM2_FFT(rocfft_execution_info_set_stream(n->info, stream));
+    void *in1[1] = {n->d_X}, *out1[1] = {n->d_F};
+    CM2_FFT(rocfft_execute(n->fwd, in1, out1, n->info));
+    const int gx_F = (int)((n->nfreq + kBlock * 4 - 1) / (kBlock * 4));
+    for (int64_t s0 = 0; s0 < n->nseg; s0 += per_launch) {
+        const int ny = (int)((n->nseg - s0 < per_launch) ? n->nseg - s0 : per_launch);
+        k_spec_mul<<<dim3(gx_F, ny), kBlock, 0, stream>>>(n->nfreq, n->d_seg_blk + s0, n->d_H,
+                                                          n->d_F + s0 * n->nfreq);
+        CM2_LAUNCH_OK();
+    }
+    void *in2[1] = {n->d_F}, *out2[1] = {n->d_X};
+    CM2_FFT(rocfft_execute(n->inv, in2, out2, n->info));
+    const int gx_O = (int)((n->hop + kBlock * 4 - 1) / (kBlock * 4));
+    for (int64_t s0 = 0; s0 < n->nseg; s0 += per_launch) {
+        const int ny = (int)((n->nseg - s0 < per_launch) ? n->nseg - s0 : per_launch);
+        k_unpack<<<dim3(gx_O, ny), kBlock, 0, stream>>>(n->L, n->halo, n->d_seg + 4 * s0,
+                                                        n->d_X + s0 * n->L, d_out);
+        CM2_LAUNCH_OK();
+    }
+    return 0;
+}

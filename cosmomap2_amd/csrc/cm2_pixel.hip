@@ -1,0 +1,357 @@
+// cm2_pixel.hip -- per-pixel kernels: weight accumulation, pixel mask, compaction,
+// sample flagging (ProcessTimeSamples, utilities/process_ces.py:58-555) and the 1x1 /
+// 2x2 / 3x3 Stokes block operators (interfaces/linearoperators.py:700-859).
+//
+// All are HBM-bound; the per-pixel operators move 56-80 B in + 8*pol B out per pixel.
+#include "cm2_pixindex.h"
+#include "cm2_blocks.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace cm2;
+
+// ------------------------------------------------------------------ a6 weights ---
+// One thread per pixel walks that pixel's samples in time order, so every sum is
+// formed in exactly the order of the reference's serial loop
+// (process_ces.py:480-487 / :505-514 / :527-539).  Products keep the reference's
+// association: w*c*c = (w*c)*c, w*s*c = (w*s)*c.
+template <int POL>
+__global__ __launch_bounds__(256) void k_weights(
+    int64_t npix, const int64_t *__restrict__ ptr, const uint32_t *__restrict__ sorted_t,
+    const double *__restrict__ w, const double *__restrict__ c, const double *__restrict__ s,
+    double *__restrict__ counts, double *__restrict__ cosine, double *__restrict__ sine,
+    double *__restrict__ cos2, double *__restrict__ sin2, double *__restrict__ sincos)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        const int64_t b = ptr[p], e = ptr[p + 1];
+        double n = 0.0, sc = 0.0, ss = 0.0, c2 = 0.0, s2 = 0.0, cs = 0.0;
+        for (int64_t k = b; k < e; ++k) {
+            const uint32_t t = sorted_t[k];
+            const double wt = w ? w[t] : 1.0;
+            if (POL == 1) {
+                n += wt;
+            } else {
+                const double ct = c[t], st = s[t];
+                if (POL == 3) {
+                    n += wt;
+                    sc += wt * ct;
+                    ss += wt * st;
+                }
+                c2 += wt * ct * ct;
+                s2 += wt * st * st;
+                cs += wt * st * ct;
+            }
+        }
+        if (POL != 2) counts[p] = n;
+        if (POL == 3) {
+            cosine[p] = sc;
+            sine[p] = ss;
+        }
+        if (POL >= 2) {
+            cos2[p] = c2;
+            sin2[p] = s2;
+            sincos[p] = cs;
+        }
+    }
+}
+
+extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const int32_t *d_pix,
+                                      const double *d_w, const double *d_cos,
+                                      const double *d_sin, double *d_counts, double *d_cosine,
+                                      double *d_sine, double *d_cos2, double *d_sin2,
+                                      double *d_sincos, void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_weights_accumulate: bad pol=%d", pol);
+    CM2_CHECK(pol == 1 || (d_cos && d_sin), "cm2_weights_accumulate: cos/sin required");
+    CM2_CHECK(pol == 2 || d_counts, "cm2_weights_accumulate: d_counts is NULL");
+    CM2_CHECK(pol == 1 || (d_cos2 && d_sin2 && d_sincos), "cm2_weights_accumulate: NULL output");
+    CM2_CHECK(pol != 3 || (d_cosine && d_sine), "cm2_weights_accumulate: NULL output");
+    hipStream_t stream = as_stream(stream_);
+    PixIndex ix;
+    if (int rc = build_pixindex(ix, d_pix, nt, npix, stream)) {
+        ix.release();
+        return rc;
+    }
+    const int g = grid_for(npix);
+#define CM2_W(POL)                                                                          \
+    k_weights<POL><<<g, kBlock, 0, stream>>>(npix, ix.d_ptr, ix.d_sorted_t, d_w, d_cos,     \
+                                             d_sin, d_counts, d_cosine, d_sine, d_cos2,     \
+                                             d_sin2, d_sincos)
+    if (pol == 1) CM2_W(1); else if (pol == 2) CM2_W(2); else CM2_W(3);
+#undef CM2_W
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
+    ix.release();
+    return 0;
+}
+
+// --------------------------------------------------------------- a6 pixel mask ---
+// process_ces.py:491 (pol=1) and :544-555 (pol>=2).  NaN condition numbers
+// (unobserved pixels: 0/0) compare false, exactly as np.where(cond_num<=thr) does.
+__global__ __launch_bounds__(256) void k_pixel_mask(int pol, int64_t npix,
+                                                     const double *__restrict__ counts,
+                                                     const double *__restrict__ cos2,
+                                                     const double *__restrict__ sin2,
+                                                     const double *__restrict__ sincos,
+                                                     double threshold, uint8_t *__restrict__ keep)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        bool k;
+        if (pol == 1) {
+            k = counts[p] > 0.0;
+        } else {
+            const double det = (cos2[p] * sin2[p]) - (sincos[p] * sincos[p]);
+            const double tr = cos2[p] + sin2[p];
+            const double sq = sqrt(tr * tr / 4. - det);
+            const double lmax = tr / 2. + sq;
+            const double lmin = tr / 2. - sq;
+            const double cond = fabs(lmax / lmin);
+            k = cond <= threshold;
+            if (pol == 3) k = k && (counts[p] > 2.0);
+        }
+        keep[p] = k ? 1 : 0;
+    }
+}
+
+extern "C" int cm2_pixel_mask(int pol, int64_t npix, const double *d_counts,
+                              const double *d_cos2, const double *d_sin2,
+                              const double *d_sincos, double threshold, uint8_t *d_keep,
+                              void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_pixel_mask: bad pol=%d", pol);
+    CM2_CHECK(d_keep != nullptr, "cm2_pixel_mask: d_keep is NULL");
+    k_pixel_mask<<<grid_for(npix), kBlock, 0, as_stream(stream_)>>>(pol, npix, d_counts, d_cos2,
+                                                                    d_sin2, d_sincos, threshold,
+                                                                    d_keep);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// -------------------------------------------------------------- a7 compaction ---
+__global__ __launch_bounds__(256) void k_keep_to_i32(int64_t n, const uint8_t *__restrict__ keep,
+                                                      int32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = keep[i] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_rank_to_old2new(int64_t n,
+                                                          const uint8_t *__restrict__ keep,
+                                                          int32_t *__restrict__ old2new)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!keep[i]) old2new[i] = -1;
+}
+
+extern "C" int cm2_pixel_compact(int64_t npix, const uint8_t *d_keep, int32_t *d_old2new,
+                                 int64_t *h_new_npix, void *stream_)
+{
+    CM2_CHECK(d_keep && d_old2new && h_new_npix, "cm2_pixel_compact: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    int32_t *flags = nullptr;
+    void *d_temp = nullptr;
+    size_t tb = 0;
+    CM2_HIP(hipMalloc(&flags, sizeof(int32_t) * (npix + 1)));
+    k_keep_to_i32<<<grid_for(npix), kBlock, 0, stream>>>(npix, d_keep, flags);
+    CM2_LAUNCH_OK();
+    // exclusive prefix sum of the keep flags = rank among kept pixels
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, d_old2new, npix, stream));
+    CM2_HIP(hipMalloc(&d_temp, tb + 16));
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb, flags, d_old2new, npix, stream));
+    int32_t last_rank = 0;
+    uint8_t last_keep = 0;
+    CM2_HIP(hipMemcpyAsync(&last_rank, d_old2new + (npix - 1), sizeof(int32_t),
+                           hipMemcpyDeviceToHost, stream));
+    CM2_HIP(hipMemcpyAsync(&last_keep, d_keep + (npix - 1), sizeof(uint8_t),
+                           hipMemcpyDeviceToHost, stream));
+    k_rank_to_old2new<<<grid_for(npix), kBlock, 0, stream>>>(npix, d_keep, d_old2new);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
+    *h_new_npix = (int64_t)last_rank + (last_keep ? 1 : 0);
+    (void)hipFree(flags);
+    (void)hipFree(d_temp);
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact(int64_t n, const int32_t *__restrict__ old2new,
+                                                  const T *__restrict__ in, T *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t j = old2new[i];
+        if (j >= 0) out[j] = in[i];
+    }
+}
+
+extern "C" int cm2_compact_f64(int64_t npix, const int32_t *d_old2new, const double *d_in,
+                               double *d_out, void *stream_)
+{
+    CM2_CHECK(d_old2new && d_in && d_out, "cm2_compact_f64: NULL argument");
+    k_compact<double><<<grid_for(npix), kBlock, 0, as_stream(stream_)>>>(npix, d_old2new, d_in,
+                                                                         d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_compact_i64(int64_t npix, const int32_t *d_old2new, const int64_t *d_in,
+                               int64_t *d_out, void *stream_)
+{
+    CM2_CHECK(d_old2new && d_in && d_out, "cm2_compact_i64: NULL argument");
+    k_compact<int64_t><<<grid_for(npix), kBlock, 0, as_stream(stream_)>>>(npix, d_old2new, d_in,
+                                                                          d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// process_ces.py:411-418
+__global__ __launch_bounds__(256) void k_flag(int64_t nt, int32_t *__restrict__ pix,
+                                               const int32_t *__restrict__ old2new)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const int32_t p = pix[i];
+        if (p == -1) continue;
+        pix[i] = old2new[p];
+    }
+}
+
+extern "C" int cm2_flag_samples(int64_t nt, int32_t *d_pix, const int32_t *d_old2new,
+                                void *stream_)
+{
+    CM2_CHECK(d_pix && d_old2new, "cm2_flag_samples: NULL argument");
+    if (nt == 0) return 0;
+    k_flag<<<grid_for(nt), kBlock, 0, as_stream(stream_)>>>(nt, d_pix, d_old2new);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------- a8 det / mask / M_BD ---
+// NumPy lines linearoperators.py:792-795 (pol 3) and :820-821 (pol 2), left to right.
+__global__ __launch_bounds__(256) void k_bd_det_mask(
+    int pol, int64_t npix, const double *__restrict__ counts, const double *__restrict__ c,
+    const double *__restrict__ s, const double *__restrict__ c2, const double *__restrict__ s2,
+    const double *__restrict__ cs, double *__restrict__ det, uint8_t *__restrict__ mask)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += stride) {
+        if (pol == 1) {
+            det[j] = counts[j];
+            mask[j] = counts[j] > 0.0 ? 1 : 0;
+        } else {
+            double d;
+            if (pol == 3) {
+                d = counts[j] * (c2[j] * s2[j] - cs[j] * cs[j]) - c[j] * c[j] * s2[j]
+                    - s[j] * s[j] * c2[j] + 2. * c[j] * s[j] * cs[j];
+            } else {
+                d = (c2[j] * s2[j]) - (cs[j] * cs[j]);
+            }
+            det[j] = d;
+            mask[j] = fabs(d) > 1e-5 ? 1 : 0;
+        }
+    }
+}
+
+extern "C" int cm2_bd_det_mask(int pol, int64_t npix, const double *d_counts,
+                               const double *d_cosine, const double *d_sine,
+                               const double *d_cos2, const double *d_sin2,
+                               const double *d_sincos, double *d_det, uint8_t *d_mask,
+                               void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_bd_det_mask: bad pol=%d", pol);
+    CM2_CHECK(d_det && d_mask, "cm2_bd_det_mask: NULL output");
+    k_bd_det_mask<<<grid_for(npix), kBlock, 0, as_stream(stream_)>>>(
+        pol, npix, d_counts, d_cosine, d_sine, d_cos2, d_sin2, d_sincos, d_det, d_mask);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+template <int POL>
+__global__ __launch_bounds__(256) void k_bdprecond(
+    int64_t npix, const double *__restrict__ hits, const double *__restrict__ c,
+    const double *__restrict__ s, const double *__restrict__ c2, const double *__restrict__ s2,
+    const double *__restrict__ cs, const double *__restrict__ det,
+    const uint8_t *__restrict__ mask, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += stride) {
+        double xin[3], yo[3];
+#pragma unroll
+        for (int k = 0; k < POL; ++k) xin[k] = x[POL * j + k];
+        const bool m = mask[j] != 0;
+        if (POL == 1)
+            bd_inverse_block<1>(hits[j], 0, 0, 0, 0, 0, 0, m, xin, yo);
+        else if (POL == 2)
+            bd_inverse_block<2>(0, 0, 0, c2[j], s2[j], cs[j], det[j], m, xin, yo);
+        else
+            bd_inverse_block<3>(hits[j], c[j], s[j], c2[j], s2[j], cs[j], det[j], m, xin, yo);
+#pragma unroll
+        for (int k = 0; k < POL; ++k) y[POL * j + k] = yo[k];
+    }
+}
+
+extern "C" int cm2_bdprecond_apply(int pol, int64_t npix, const double *d_counts,
+                                   const double *d_cosine, const double *d_sine,
+                                   const double *d_cos2, const double *d_sin2,
+                                   const double *d_sincos, const double *d_det,
+                                   const uint8_t *d_mask, const double *d_x, double *d_y,
+                                   void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_bdprecond_apply: bad pol=%d", pol);
+    CM2_CHECK(d_mask && d_x && d_y, "cm2_bdprecond_apply: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int g = grid_for(npix);
+#define CM2_BDP(POL)                                                                      \
+    k_bdprecond<POL><<<g, kBlock, 0, stream>>>(npix, d_counts, d_cosine, d_sine, d_cos2,  \
+                                               d_sin2, d_sincos, d_det, d_mask, d_x, d_y)
+    if (pol == 1) CM2_BDP(1); else if (pol == 2) CM2_BDP(2); else CM2_BDP(3);
+#undef CM2_BDP
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ----------------------------------------------------------- a9 forward block ---
+template <int POL>
+__global__ __launch_bounds__(256) void k_bd_apply(
+    int64_t npix, const double *__restrict__ hits, const double *__restrict__ c,
+    const double *__restrict__ s, const double *__restrict__ c2, const double *__restrict__ s2,
+    const double *__restrict__ cs, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        if (POL == 1) {
+            y[p] = x[p] * hits[p];                                       // :735
+        } else if (POL == 2) {
+            const double x0 = x[2 * p], x1 = x[2 * p + 1];               // :743-745
+            y[2 * p] = c2[p] * x0 + cs[p] * x1;
+            y[2 * p + 1] = cs[p] * x0 + s2[p] * x1;
+        } else {
+            const double x0 = x[3 * p], x1 = x[3 * p + 1], x2 = x[3 * p + 2];   // :737-741
+            y[3 * p] = hits[p] * x0 + c[p] * x1 + s[p] * x2;
+            y[3 * p + 1] = c[p] * x0 + c2[p] * x1 + cs[p] * x2;
+            y[3 * p + 2] = s[p] * x0 + cs[p] * x1 + s2[p] * x2;
+        }
+    }
+}
+
+extern "C" int cm2_bd_apply(int pol, int64_t npix, const double *d_counts,
+                            const double *d_cosine, const double *d_sine, const double *d_cos2,
+                            const double *d_sin2, const double *d_sincos, const double *d_x,
+                            double *d_y, void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_bd_apply: bad pol=%d", pol);
+    CM2_CHECK(d_x && d_y, "cm2_bd_apply: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int g = grid_for(npix);
+#define CM2_BD(POL)                                                                       \
+    k_bd_apply<POL><<<g, kBlock, 0, stream>>>(npix, d_counts, d_cosine, d_sine, d_cos2,   \
+                                              d_sin2, d_sincos, d_x, d_y)
+    if (pol == 1) CM2_BD(1); else if (pol == 2) CM2_BD(2); else CM2_BD(3);
+#undef CM2_BD
+    CM2_LAUNCH_OK();
+    return 0;
+}

@@ -1,0 +1,545 @@
+// cm2_vector.hip -- map-domain vector kernels: the BLAS-1 pieces of the PCG
+// recurrence, the tall-skinny deflation operators Z / Z^T, the coarse matrix
+// E = Z^T (A Z) on fp64 MFMA, and the fused tail of the two-level preconditioner.
+//
+// Reference code replaced:
+//   norm2/scalprod                utilities/linear_algebra_funcs.py:31-44
+//   cg recurrence                 scipy.sparse.linalg.cg (tests/test_2level_preconditioner.py:52)
+//   DeflationLO.mult / rmult      interfaces/linearoperators.py:1041-1056
+//   CoarseLO.__init__ dgemm       interfaces/linearoperators.py:1019
+//   M2 = Mbd*R + Zd*E*Zd.T        src/test_M2_precond_onto_real_data.py:109-112
+//
+// Everything here is HBM-bound (one pass over the vectors / over Z) except
+// cm2_gemm_tn, which is the one GEMM-shaped contraction on the path and runs on
+// v_mfma_f64_16x16x4_f64.  Reductions are two-stage with a fixed tree, so results
+// are bitwise reproducible from run to run.
+#include "cm2_blocks.h"
+
+using namespace cm2;
+
+namespace {
+constexpr int kRedBlocks = 1024;            // stage-1 workgroups of every reduction
+constexpr int kGemmBlocks = 128;            // workgroups of the Z^T Z contraction
+typedef double double4_t __attribute__((ext_vector_type(4)));
+}  // namespace
+
+extern "C" int64_t cm2_reduce_work_doubles(void) { return (int64_t)kRedBlocks * 256; }
+
+static inline int red_blocks(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kRedBlocks) g = kRedBlocks;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ dot --------
+__global__ __launch_bounds__(256) void k_dot_partial(int64_t n, const double *__restrict__ x,
+                                                      const double *__restrict__ y,
+                                                      double *__restrict__ partial)
+{
+    __shared__ double lds[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        acc += x[i] * y[i];
+    const double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// sums `count` partials (stride 1) into out[0]; one workgroup, fixed order
+__global__ __launch_bounds__(256) void k_reduce_final(int count, const double *__restrict__ partial,
+                                                       double *__restrict__ out)
+{
+    __shared__ double lds[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
+    const double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+extern "C" int cm2_dot(int64_t n, const double *d_x, const double *d_y, double *d_out,
+                       double *d_work, void *stream_)
+{
+    CM2_CHECK(d_out && d_work && (n == 0 || (d_x && d_y)), "cm2_dot: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int g = red_blocks(n);
+    k_dot_partial<<<g, kBlock, 0, stream>>>(n, d_x, d_y, d_work);
+    CM2_LAUNCH_OK();
+    k_reduce_final<<<1, kBlock, 0, stream>>>(g, d_work, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------- axpy / scal / xmy -----
+__global__ __launch_bounds__(256) void k_axpy(int64_t n, double a, const double *__restrict__ x,
+                                               double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = y[i] + a * x[i];
+}
+
+__global__ __launch_bounds__(256) void k_scal(int64_t n, double a, double *__restrict__ x)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(256) void k_xmy(int64_t n, const double *__restrict__ x,
+                                              const double *__restrict__ y,
+                                              double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = x[i] * y[i];
+}
+
+extern "C" int cm2_axpy(int64_t n, double alpha, const double *d_x, double *d_y, void *stream_)
+{
+    CM2_CHECK(n == 0 || (d_x && d_y), "cm2_axpy: NULL argument");
+    if (n == 0) return 0;
+    k_axpy<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, alpha, d_x, d_y);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_scal(int64_t n, double alpha, double *d_x, void *stream_)
+{
+    CM2_CHECK(n == 0 || d_x, "cm2_scal: NULL argument");
+    if (n == 0) return 0;
+    k_scal<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, alpha, d_x);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_xmy(int64_t n, const double *d_x, const double *d_y, double *d_out,
+                       void *stream_)
+{
+    CM2_CHECK(n == 0 || (d_x && d_y && d_out), "cm2_xmy: NULL argument");
+    if (n == 0) return 0;
+    k_xmy<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, d_x, d_y, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------ PCG fused updates -----
+// cg: beta = rho_cur / rho_prev ; p *= beta ; p += z
+__global__ __launch_bounds__(256) void k_pcg_update_p(int64_t n, const double *__restrict__ rho,
+                                                       const double *__restrict__ rho_prev,
+                                                       const double *__restrict__ z,
+                                                       double *__restrict__ p)
+{
+    const double beta = rho[0] / rho_prev[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        p[i] = p[i] * beta + z[i];
+}
+
+// cg: alpha = rho_cur / dot(p,q) ; x += alpha*p ; r -= alpha*q ; and ||r||^2 on the fly
+__global__ __launch_bounds__(256) void k_pcg_update_xr(
+    int64_t n, const double *__restrict__ rho, const double *__restrict__ pq,
+    const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
+    double *__restrict__ r, double *__restrict__ partial)
+{
+    __shared__ double lds[4];
+    const double alpha = rho[0] / pq[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] = x[i] + alpha * p[i];
+        const double rn = r[i] - alpha * q[i];
+        r[i] = rn;
+        acc += rn * rn;
+    }
+    const double s = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+extern "C" int cm2_pcg_update_p(int64_t n, const double *d_rho, const double *d_rho_prev,
+                                const double *d_z, double *d_p, void *stream_)
+{
+    CM2_CHECK(d_rho && d_rho_prev && d_z && d_p, "cm2_pcg_update_p: NULL argument");
+    k_pcg_update_p<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, d_rho, d_rho_prev, d_z, d_p);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d_pq,
+                                 const double *d_p, const double *d_q, double *d_x, double *d_r,
+                                 double *d_rr, double *d_work, void *stream_)
+{
+    CM2_CHECK(d_rho && d_pq && d_p && d_q && d_x && d_r && d_rr && d_work,
+              "cm2_pcg_update_xr: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int g = red_blocks(n);
+    k_pcg_update_xr<<<g, kBlock, 0, stream>>>(n, d_rho, d_pq, d_p, d_q, d_x, d_r, d_work);
+    CM2_LAUNCH_OK();
+    k_reduce_final<<<1, kBlock, 0, stream>>>(g, d_work, d_rr);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------------- Z^T x ----------
+// Z row-major [n][r].  Thread (row-lane, column): consecutive threads read
+// consecutive doubles of a row => full-line accesses; per-column partials are
+// combined in LDS in a fixed order, then across workgroups by k_Zt_final.
+__global__ __launch_bounds__(256) void k_Zt_partial(int64_t n, int r, int rp, int64_t rows_per_blk,
+                                                     const double *__restrict__ Z,
+                                                     const double *__restrict__ x,
+                                                     double *__restrict__ partial)
+{
+    __shared__ double lds[256];
+    const int col = threadIdx.x % rp;
+    const int rl = threadIdx.x / rp;
+    const int rstep = 256 / rp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    double acc = 0.0;
+    if (col < r)
+        for (int64_t i = r0 + rl; i < r1; i += rstep) acc += Z[i * r + col] * x[i];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < rp && col < r) {
+        double s = 0.0;
+        for (int q = 0; q < rstep; ++q) s += lds[q * rp + col];
+        partial[(int64_t)blockIdx.x * r + col] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_Zt_final(int nblk, int r, int rp,
+                                                   const double *__restrict__ partial,
+                                                   double *__restrict__ out)
+{
+    __shared__ double lds[256];
+    const int col = threadIdx.x % rp;
+    const int q = threadIdx.x / rp;
+    const int qn = 256 / rp;
+    double acc = 0.0;
+    if (col < r)
+        for (int b = q; b < nblk; b += qn) acc += partial[(int64_t)b * r + col];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < rp && col < r) {
+        double s = 0.0;
+        for (int k = 0; k < qn; ++k) s += lds[k * rp + col];
+        out[col] = s;
+    }
+}
+
+static inline int pow2_at_least(int r)
+{
+    int p = 1;
+    while (p < r) p <<= 1;
+    return p;
+}
+
+extern "C" int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d_x, double *d_out,
+                            double *d_work, void *stream_)
+{
+    CM2_CHECK(r >= 1 && r <= 256, "cm2_Zt_apply: deflation rank r=%d out of range [1,256]", r);
+    CM2_CHECK(d_Z && d_x && d_out && d_work, "cm2_Zt_apply: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int rp = pow2_at_least(r);
+    const int rstep = 256 / rp;
+    int nblk = red_blocks(n);
+    int64_t rows = (n + nblk - 1) / nblk;
+    rows = ((rows + rstep - 1) / rstep) * rstep;
+    if (rows < rstep) rows = rstep;
+    nblk = (int)((n + rows - 1) / rows);
+    if (nblk < 1) nblk = 1;
+    k_Zt_partial<<<nblk, kBlock, 0, stream>>>(n, r, rp, rows, d_Z, d_x, d_work);
+    CM2_LAUNCH_OK();
+    k_Zt_final<<<1, kBlock, 0, stream>>>(nblk, r, rp, d_work, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// --------------------------------------------------------------- Z y ----------
+// linearoperators.py:1047-1049: y = zeros; y += z_k * x_k for k = 0..r-1, so each
+// output is ((0 + Z_i0 y0) + Z_i1 y1) + ... in that order.
+__global__ __launch_bounds__(256) void k_Z_apply(int64_t n, int r, const double *__restrict__ Z,
+                                                  const double *__restrict__ y,
+                                                  double *__restrict__ out)
+{
+    __shared__ double ys[256];
+    if (threadIdx.x < r) ys[threadIdx.x] = y[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double *zr = Z + i * r;
+        double acc = 0.0;
+        for (int k = 0; k < r; ++k) acc += zr[k] * ys[k];
+        out[i] = acc;
+    }
+}
+
+extern "C" int cm2_Z_apply(int64_t n, int r, const double *d_Z, const double *d_y, double *d_out,
+                           void *stream_)
+{
+    CM2_CHECK(r >= 1 && r <= 256, "cm2_Z_apply: deflation rank r=%d out of range [1,256]", r);
+    CM2_CHECK(d_Z && d_y && d_out, "cm2_Z_apply: NULL argument");
+    k_Z_apply<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, r, d_Z, d_y, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------- E = Z1^T Z2 ----------
+extern "C" int64_t cm2_gemm_tn_work_doubles(int r1, int r2)
+{
+    return (int64_t)kGemmBlocks * 4 * r1 * r2;
+}
+
+// fp64 MFMA path, r1 and r2 multiples of 16, up to 64x64 (16 tiles).
+// v_mfma_f64_16x16x4_f64: lane l supplies A[m=l&15][k=l>>4] and B[k=l>>4][n=l&15];
+// result reg j of lane l is D[row=(l>>4)+4j][col=l&15].
+// Here K runs over map rows: A[m][k] = Z1[i0+k][16*mt+m], B[k][n] = Z2[i0+k][16*nt+n].
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_gemm_tn_mfma(int64_t n, const double *__restrict__ Z1,
+                                                       const double *__restrict__ Z2,
+                                                       double *__restrict__ work)
+{
+    constexpr int R1 = MT * 16, R2 = NT * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nwaves = (int)gridDim.x * 4;
+    const int m = lane & 15, k = lane >> 4;
+    double4_t acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // contiguous, 4-aligned row range per wave
+    int64_t chunk = (n + nwaves - 1) / nwaves;
+    chunk = (chunk + 3) & ~(int64_t)3;
+    const int64_t i_begin = (int64_t)wave * chunk;
+    int64_t i_end = i_begin + chunk;
+    if (i_end > n) i_end = n;
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 4) {
+        const int64_t i = i0 + k;
+        const bool ok = i < i_end;
+        double av[MT], bv[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) av[a] = ok ? Z1[i * R1 + a * 16 + m] : 0.0;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = ok ? Z2[i * R2 + b * 16 + m] : 0.0;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    double *w = work + (int64_t)wave * R1 * R2;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = a * 16 + (lane >> 4) + 4 * j;
+                const int col = b * 16 + (lane & 15);
+                w[row * R2 + col] = acc[a][b][j];
+            }
+}
+
+// scalar path for any r1, r2 (small deflation spaces, e.g. r = 5 in the tests)
+__global__ __launch_bounds__(256) void k_gemm_tn_scalar(int64_t n, int r1, int r2,
+                                                         const double *__restrict__ Z1,
+                                                         const double *__restrict__ Z2,
+                                                         double *__restrict__ work)
+{
+    const int nblk = gridDim.x;
+    int64_t chunk = (n + nblk - 1) / nblk;
+    const int64_t i_begin = (int64_t)blockIdx.x * chunk;
+    int64_t i_end = i_begin + chunk;
+    if (i_end > n) i_end = n;
+    double *w = work + (int64_t)blockIdx.x * r1 * r2;
+    for (int e = threadIdx.x; e < r1 * r2; e += blockDim.x) {
+        const int a = e / r2, b = e % r2;
+        double acc = 0.0;
+        for (int64_t i = i_begin; i < i_end; ++i) acc += Z1[i * r1 + a] * Z2[i * r2 + b];
+        w[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_final(int nparts, int rr,
+                                                        const double *__restrict__ work,
+                                                        double *__restrict__ E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rr) return;
+    double acc = 0.0;
+    for (int p = 0; p < nparts; ++p) acc += work[(int64_t)p * rr + e];
+    E[e] = acc;
+}
+
+extern "C" int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const double *d_Z2,
+                           double *d_E, double *d_work, void *stream_)
+{
+    CM2_CHECK(r1 >= 1 && r1 <= 256 && r2 >= 1 && r2 <= 256, "cm2_gemm_tn: r1=%d r2=%d out of range",
+              r1, r2);
+    CM2_CHECK(d_Z1 && d_Z2 && d_E && d_work, "cm2_gemm_tn: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int rr = r1 * r2;
+    int nparts;
+    const bool mfma = (r1 % 16 == 0) && (r2 % 16 == 0) && r1 <= 64 && r2 <= 64 && r1 == r2;
+    if (mfma) {
+        nparts = kGemmBlocks * 4;
+        if (r1 == 16) k_gemm_tn_mfma<1, 1><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+        else if (r1 == 32) k_gemm_tn_mfma<2, 2><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+        else if (r1 == 48) k_gemm_tn_mfma<3, 3><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+        else k_gemm_tn_mfma<4, 4><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+    } else {
+        nparts = kGemmBlocks * 4;
+        k_gemm_tn_scalar<<<nparts, kBlock, 0, stream>>>(n, r1, r2, d_Z1, d_Z2, d_work);
+    }
+    CM2_LAUNCH_OK();
+    k_gemm_tn_final<<<(rr + kBlock - 1) / kBlock, kBlock, 0, stream>>>(nparts, rr, d_work, d_E);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// --------------------------------------------------- out = M v  (r x r) -------
+__global__ __launch_bounds__(256) void k_small_matvec(int r, const double *__restrict__ M,
+                                                       const double *__restrict__ v,
+                                                       double *__restrict__ out)
+{
+    __shared__ double vs[256];
+    if (threadIdx.x < r) vs[threadIdx.x] = v[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < r) {
+        double acc = 0.0;
+        for (int l = 0; l < r; ++l) acc += M[threadIdx.x * r + l] * vs[l];
+        out[threadIdx.x] = acc;
+    }
+}
+
+extern "C" int cm2_small_matvec(int r, const double *d_M, const double *d_v, double *d_out,
+                                void *stream_)
+{
+    CM2_CHECK(r >= 1 && r <= 256, "cm2_small_matvec: r=%d out of range [1,256]", r);
+    CM2_CHECK(d_M && d_v && d_out, "cm2_small_matvec: NULL argument");
+    k_small_matvec<<<1, kBlock, 0, as_stream(stream_)>>>(r, d_M, d_v, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------ M2 r = M_BD (r - AZ y) + Z y  (tail) -----
+// One thread per pixel: reads its POL rows of Z and AZ once, forms
+// t = res - AZ y and zy = Z y (k = 0..r-1 in order, as DeflationLO.mult),
+// applies the closed-form M_BD block to t and adds zy.
+template <int POL>
+__global__ __launch_bounds__(256) void k_m2_finish(
+    int64_t npix, int r, const double *__restrict__ Z, const double *__restrict__ AZ,
+    const double *__restrict__ y, const double *__restrict__ res,
+    const double *__restrict__ hits, const double *__restrict__ c, const double *__restrict__ s,
+    const double *__restrict__ c2, const double *__restrict__ s2, const double *__restrict__ cs,
+    const double *__restrict__ det, const uint8_t *__restrict__ mask, double *__restrict__ out)
+{
+    __shared__ double ys[256];
+    if (threadIdx.x < r) ys[threadIdx.x] = y[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += stride) {
+        double t[3], zy[3], o[3];
+#pragma unroll
+        for (int a = 0; a < POL; ++a) {
+            const int64_t i = POL * j + a;
+            const double *zr = Z + i * r;
+            const double *ar = AZ + i * r;
+            double accz = 0.0, acca = 0.0;
+            for (int k = 0; k < r; ++k) {
+                accz += zr[k] * ys[k];
+                acca += ar[k] * ys[k];
+            }
+            zy[a] = accz;
+            t[a] = res[i] - acca;
+        }
+        const bool m = mask[j] != 0;
+        if (POL == 1)
+            bd_inverse_block<1>(hits[j], 0, 0, 0, 0, 0, 0, m, t, o);
+        else if (POL == 2)
+            bd_inverse_block<2>(0, 0, 0, c2[j], s2[j], cs[j], det[j], m, t, o);
+        else
+            bd_inverse_block<3>(hits[j], c[j], s[j], c2[j], s2[j], cs[j], det[j], m, t, o);
+#pragma unroll
+        for (int a = 0; a < POL; ++a) out[POL * j + a] = o[a] + zy[a];
+    }
+}
+
+extern "C" int cm2_m2_finish(int pol, int64_t npix, int r, const double *d_Z, const double *d_AZ,
+                             const double *d_y, const double *d_res, const double *d_counts,
+                             const double *d_cosine, const double *d_sine, const double *d_cos2,
+                             const double *d_sin2, const double *d_sincos, const double *d_det,
+                             const uint8_t *d_mask, double *d_out, void *stream_)
+{
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_m2_finish: bad pol=%d", pol);
+    CM2_CHECK(r >= 1 && r <= 256, "cm2_m2_finish: r=%d out of range [1,256]", r);
+    CM2_CHECK(d_Z && d_AZ && d_y && d_res && d_mask && d_out, "cm2_m2_finish: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    const int g = grid_for(npix);
+#define CM2_M2(POL)                                                                          \
+    k_m2_finish<POL><<<g, kBlock, 0, stream>>>(npix, r, d_Z, d_AZ, d_y, d_res, d_counts,     \
+                                               d_cosine, d_sine, d_cos2, d_sin2, d_sincos,   \
+                                               d_det, d_mask, d_out)
+    if (pol == 1) CM2_M2(1); else if (pol == 2) CM2_M2(2); else CM2_M2(3);
+#undef CM2_M2
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------ C[m x n] = A^T B^T  (general, API edge) ---
+// utilities/linear_algebra_funcs.py:16-29: gemm(a=A.T, b=B, trans_b=True).
+// A is k x m row-major, B is n x k row-major.  One thread per output element;
+// used for the small host-facing products (r x r, npix x r with tiny k), the large
+// contraction E = Z^T (A Z) goes through cm2_gemm_tn.
+__global__ __launch_bounds__(256) void k_gemm_atbt(int64_t m, int64_t n, int64_t k,
+                                                    const double *__restrict__ A,
+                                                    const double *__restrict__ B,
+                                                    double *__restrict__ C)
+{
+    const int64_t total = m * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / n, j = e % n;
+        double acc = 0.0;
+        for (int64_t l = 0; l < k; ++l) acc += A[l * m + i] * B[j * k + l];
+        C[e] = acc;
+    }
+}
+
+extern "C" int cm2_gemm_atbt(int64_t m, int64_t n, int64_t k, const double *d_A,
+                             const double *d_B, double *d_C, void *stream_)
+{
+    CM2_CHECK(m >= 1 && n >= 1 && k >= 1, "cm2_gemm_atbt: bad shape m=%lld n=%lld k=%lld",
+              (long long)m, (long long)n, (long long)k);
+    CM2_CHECK(d_A && d_B && d_C, "cm2_gemm_atbt: NULL argument");
+    k_gemm_atbt<<<grid_for(m * n), kBlock, 0, as_stream(stream_)>>>(m, n, k, d_A, d_B, d_C);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// cos(2 phi), sin(2 phi) of the HWP / polarisation angle (process_ces.py:493-494)
+__global__ __launch_bounds__(256) void k_trig2(int64_t n, const double *__restrict__ phi,
+                                                double *__restrict__ c, double *__restrict__ s)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double sv, cv;
+        sincos(2. * phi[i], &sv, &cv);
+        c[i] = cv;
+        s[i] = sv;
+    }
+}
+
+extern "C" int cm2_cos_sin_2phi(int64_t n, const double *d_phi, double *d_cos, double *d_sin,
+                                void *stream_)
+{
+    CM2_CHECK(n == 0 || (d_phi && d_cos && d_sin), "cm2_cos_sin_2phi: NULL argument");
+    if (n == 0) return 0;
+    k_trig2<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, d_phi, d_cos, d_sin);
+    CM2_LAUNCH_OK();
+    return 0;
+}

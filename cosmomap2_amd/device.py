@@ -1,0 +1,149 @@
+"""
+Device-memory plumbing: torch tensors are used ONLY as HBM allocations, streams
+and (in sharding.py) the torch.distributed transport.  All arithmetic on map- or
+TOD-sized data goes through the HIP kernels of libcosmomap2_hip.so.
+
+Vector kinds handled by the host classes:
+  * numpy.ndarray            -- API edge, like the reference (host round trip)
+  * torch cuda tensor (f64)  -- resident in HBM, no transfer
+  * torch cpu tensor         -- only met in the gloo multi-process tests
+"""
+import numpy as np
+
+try:
+    import torch
+except Exception:         # pragma: no cover
+    torch = None
+
+from . import _hip
+
+
+def gpu_available():
+    return torch is not None and torch.cuda.is_available()
+
+
+def require_gpu():
+    if not gpu_available():
+        raise _hip.HipError("cosmomap2_amd needs an AMD GPU visible to PyTorch-ROCm; "
+                            "there is no CPU fallback for the map-making kernels")
+    _hip.load()
+
+
+def dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    """hipStream_t of torch's current stream, as an integer for ctypes."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def is_dev(x):
+    return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def is_tensor(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def to_dev(a, dtype=None):
+    """Upload (or pass through) as a contiguous tensor on the current GPU."""
+    require_gpu()
+    if is_tensor(a):
+        t = a
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        if not t.is_cuda:
+            t = t.to(dev())
+        return t.contiguous()
+    arr = np.ascontiguousarray(a)
+    t = torch.from_numpy(arr)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(dev())
+
+
+def f64(a):
+    return to_dev(a, torch.float64)
+
+
+def i32(a):
+    return to_dev(a, torch.int32)
+
+
+def empty(n, dtype=None):
+    require_gpu()
+    return torch.empty(int(n), dtype=dtype or torch.float64, device=dev())
+
+
+def zeros(n, dtype=None):
+    require_gpu()
+    return torch.zeros(int(n), dtype=dtype or torch.float64, device=dev())
+
+
+def to_host(t):
+    if isinstance(t, np.ndarray):
+        return t
+    return t.detach().cpu().numpy()
+
+
+def like_input(result_dev, x):
+    """Return `result_dev` in the same kind as the caller's vector `x`."""
+    if isinstance(x, np.ndarray):
+        return to_host(result_dev)
+    if is_tensor(x) and not x.is_cuda:
+        return result_dev.cpu()
+    return result_dev
+
+
+# ----------------------------------------------------------------- algebra ------
+_work = {}
+
+
+def reduce_work():
+    """Scratch for the two-stage reductions (one per device)."""
+    d = torch.cuda.current_device()
+    if d not in _work:
+        _work[d] = torch.empty(int(_hip.load().cm2_reduce_work_doubles()), dtype=torch.float64,
+                               device=dev())
+    return _work[d]
+
+
+def add_scaled(y, alpha, x):
+    """New vector y + alpha*x (operator sums and differences)."""
+    if is_dev(y) or is_dev(x):
+        y, x = f64(y), f64(x)
+        out = y.clone()
+        _hip.call("cm2_axpy", out.numel(), float(alpha), ptr(x), ptr(out), stream())
+        return out
+    return y + alpha * x
+
+
+def scaled(alpha, x):
+    if is_dev(x):
+        out = x.clone()
+        _hip.call("cm2_scal", out.numel(), float(alpha), ptr(out), stream())
+        return out
+    return x * alpha
+
+
+def multiply(d, x):
+    if is_dev(x):
+        out = torch.empty_like(x)
+        _hip.call("cm2_xmy", x.numel(), ptr(d), ptr(x), ptr(out), stream())
+        return out
+    return d * x
+
+
+def dot(x, y):
+    """Device dot product -> python float (synchronises)."""
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    _hip.call("cm2_dot", x.numel(), ptr(x), ptr(y), ptr(out), ptr(reduce_work()), stream())
+    return float(out.item())

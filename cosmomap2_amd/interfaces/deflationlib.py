@@ -1,0 +1,201 @@
+"""
+Krylov helpers that build the deflation space (reference: interfaces/deflationlib.py).
+
+* :func:`arnoldi`, :func:`build_hess`, :func:`build_Z` follow the reference's own
+  Arnoldi (deflationlib.py:17-184) -- including its stop rule and its way of picking
+  Ritz vectors, see the notes in each function -- with the basis vectors kept in HBM
+  and the Gram-Schmidt dots/axpys done by the device BLAS-1 kernels.
+* :func:`run_krypy_arnoldi`, :func:`find_ritz_eigenvalues` wrap the third-party ``krypy``
+  package in the reference (deflationlib.py:187-219); krypy is not vendored and not
+  installed, so these restate its published algorithm (Arnoldi with an ``M`` inner
+  product, Ritz pairs of the Hessenberg matrix).  PARITY UNPINNED for these two.
+"""
+import math
+
+import numpy as np
+
+from .. import _hip
+from .. import device as D
+from .. import linop as lp
+from ..solvers import _apply
+from ..utilities.linear_algebra_funcs import dgemm
+
+__all__ = ["arnoldi", "build_hess", "build_Z", "run_krypy_arnoldi", "find_ritz_eigenvalues"]
+
+
+def _norm(v):
+    return math.sqrt(D.dot(v, v))
+
+
+def arnoldi(A, b, x0=None, tol=1e-5, maxiter=1000, inner_m=30):
+    """
+    Modified Gram-Schmidt Arnoldi on ``A.matvec`` started from ``r0 = b - A x0``
+    (deflationlib.py:17-113).  Returns ``(vs, hs, j)``: the list of orthonormal basis
+    vectors, the list of Hessenberg columns (column ``j`` has ``j+1`` entries) and the
+    number of steps.
+
+    Kept from the reference: ``ValueError`` for a non-finite ``b`` (:60-61); early
+    return ``(None, None, 0)`` when ``||r0|| < tol*||b||`` or ``< tol`` (:80-82); the
+    stop rule ``abs(v_new[j]*h[j+1,j]) <= tol`` on the j-th *component* of the new
+    vector (:101); ``RuntimeError`` when ``inner_m`` steps do not trigger it (:111-112).
+    ``vs`` holds NumPy arrays when ``b`` is NumPy, HBM tensors when ``b`` is a tensor.
+    """
+    D.require_gpu()
+    host_io = not D.is_tensor(b)
+    bd = D.f64(b).reshape(-1)
+    n = bd.numel()
+    if not bool(np.isfinite(D.dot(bd, bd))):
+        raise ValueError("RHS must contain only finite numbers")
+    if x0 is None:
+        x0 = np.zeros(n)
+    b_norm = _norm(bd)
+    if b_norm == 0:
+        b_norm = 1
+    r_outer = D.add_scaled(bd, -1.0, _apply(A, D.f64(x0).reshape(-1)))
+    r_norm = _norm(r_outer)
+    if r_norm < tol * b_norm or r_norm < tol:
+        print("Arnoldi exited at the first iteration\nr_norm < tol * b_norm or r_norm < tol")
+        return None, None, 0
+    vs = [D.scaled(1.0 / r_norm, r_outer)]
+    hs = []
+    out = (lambda seq: [D.to_host(v) for v in seq]) if host_io else (lambda seq: seq)
+    for j in range(1, 1 + inner_m):
+        v_new = _apply(A, vs[j - 1]).clone()
+        hcur = []
+        for v in vs:                                   # :94-97
+            alpha = D.dot(v, v_new)
+            hcur.append(alpha)
+            _hip.call("cm2_axpy", n, -alpha, D.ptr(v), D.ptr(v_new), D.stream())
+        hcur.append(_norm(v_new))
+        _hip.call("cm2_scal", n, 1.0 / hcur[-1], D.ptr(v_new), D.stream())
+        vj = float(v_new[j].item()) if j < n else 0.0
+        if abs(vj * hcur[-1]) <= tol:                  # :101
+            print("Computed  %d Ritz eigenvalues within the tolerance %.1g " % (j, tol))
+            hs.append(hcur)
+            return out(vs), hs, j
+        vs.append(v_new)
+        hs.append(hcur)
+        if j == inner_m:
+            raise RuntimeError("Convergence not achieved within the Arnoldi algorithm")
+
+
+def build_hess(h, m):
+    """m x m upper-Hessenberg matrix from the column list of :func:`arnoldi`
+    (deflationlib.py:115-137)."""
+    hess = np.zeros((m, m))
+    for q in range(m - 1):
+        hess[:(q + 2), q] = h[q]
+    hess[:m, m - 1] = h[-1][:m]
+    return hess
+
+
+def build_Z(z, y, w, eps, eigenvectors_in_columns=False):
+    """
+    Deflation matrix from the Ritz pairs whose ``|z_i| <= eps`` (deflationlib.py:140-184):
+    ``Z = W y_sel^T`` with ``W`` the (npix x m) matrix of basis vectors.  Raises
+    ``RuntimeError`` when no Ritz value is below the threshold (:176-177).
+
+    ``w`` may be the (npix x m) array the reference's ``w.T`` needs, or the list of basis
+    vectors :func:`arnoldi` returns (stacked as columns).  By default the selected
+    vectors are the ROWS ``y[i]`` of ``y`` exactly as the reference does (:172-174) even
+    though ``numpy.linalg.eigh`` returns eigenvectors in columns;
+    ``eigenvectors_in_columns=True`` selects ``y[:, i]`` instead.
+    """
+    m = len(z)
+    y = np.asarray(y)
+    sel = [(y[:, i] if eigenvectors_in_columns else y[i]) for i in range(m) if abs(z[i]) <= eps]
+    r = len(sel)
+    if r == 0:
+        raise RuntimeError("No Ritz eigenvalue are found smaller than fixed threshold %.1g " % eps)
+    print("Found  eigenvectors below the threshold %.1g!\nThe deflation subspace  has dim(Z)=%d "
+          % (eps, r))
+    if isinstance(w, (list, tuple)):
+        if D.is_tensor(w[0]):
+            W = D.torch.stack([D.f64(v) for v in w], dim=1)
+        else:
+            W = np.column_stack([np.asarray(v) for v in w])
+    else:
+        W = w
+    zsel = np.asarray(sel)                              # r x m
+    # dgemm(w.T, z) = (w.T).T z.T = W zsel^T            (:183)
+    Wt = W.t().contiguous() if D.is_tensor(W) else np.ascontiguousarray(np.asarray(W).T)
+    return dgemm(Wt, zsel), r
+
+
+def run_krypy_arnoldi(A, x0, M, tol, maxiter=None):
+    """
+    Arnoldi in the ``M`` inner product, the algorithm of ``krypy.utils.arnoldi(A, x0, M=M,
+    maxiter=...)`` that the reference calls (deflationlib.py:187-202): with ``P_1 = x0/||x0||_M``
+    and ``V_1 = M P_1``, each step orthogonalises ``A V_k`` against the ``P`` vectors using the
+    ``V`` vectors as duals, so that ``A V_k = P_{k+1} H_k`` and ``V^T P = I``.  Returns
+    ``(V, H, m)`` with ``V`` (n x (m+1)) NumPy and ``H`` ((m+1) x m).  ``tol`` is unused
+    there as well (the reference passes only ``maxiter``).  PARITY UNPINNED (krypy absent).
+    """
+    D.require_gpu()
+    x0d = D.f64(np.asarray(x0).reshape(-1) if not D.is_tensor(x0) else x0).reshape(-1)
+    n = x0d.numel()
+    nmax = n if maxiter is None else int(maxiter)
+    if M is None:
+        p0 = x0d.clone()
+        nrm = _norm(p0)
+        P = [D.scaled(1.0 / nrm, p0)]
+        V = [P[0]]
+    else:
+        Mv = _apply(M, x0d)
+        nrm = math.sqrt(abs(D.dot(x0d, Mv)))
+        P = [D.scaled(1.0 / nrm, x0d)]
+        V = [D.scaled(1.0 / nrm, Mv)]
+    H = np.zeros((nmax + 1, nmax))
+    k_done = 0
+    for k in range(nmax):
+        Av = _apply(A, V[k]).clone()
+        for j in range(k + 1):                          # MGS against P with duals V
+            alpha = D.dot(V[j], Av)
+            H[j, k] += alpha
+            _hip.call("cm2_axpy", n, -alpha, D.ptr(P[j]), D.ptr(Av), D.stream())
+        if M is None:
+            MAv = Av
+            nrm = _norm(Av)
+        else:
+            MAv = _apply(M, Av)
+            nrm = math.sqrt(abs(D.dot(Av, MAv)))
+        H[k + 1, k] = nrm
+        k_done = k + 1
+        if nrm <= 1e-14 * max(abs(H[:k + 1, k]).max(), 1.0):   # invariant subspace
+            break
+        P.append(D.scaled(1.0 / nrm, Av))
+        V.append(P[-1] if M is None else D.scaled(1.0 / nrm, MAv))
+    Vh = np.column_stack([D.to_host(v) for v in V])
+    Hh = H[:Vh.shape[1] if Vh.shape[1] > k_done else k_done + 1, :k_done]
+    m = Vh.shape[1]
+    print("Residual after  %d Arnoldi iterations, r^(k)= %g \nExiting Arnoldi ..."
+          % (m, float(np.linalg.norm(Vh[:, -1]))))
+    return Vh, Hh, m
+
+
+def find_ritz_eigenvalues(h, v, threshold=1.e-2, eigenvalues=False, filename=None):
+    """
+    Ritz pairs of the Hessenberg matrix (``krypy.utils.ritz(h, V=v, hermitian=True)``,
+    ordered by Ritz residual norm) and the selection of the reference
+    (deflationlib.py:204-219): ``r`` = number of Ritz values below ``threshold``; returns
+    ``(z[:, :r], r)`` or, with ``eigenvalues=True``, ``(z[:, sel], r, eig[sel])``.
+    ``filename`` (HDF5 dump of the Ritz vectors) is outside the scope of this package.
+    PARITY UNPINNED (krypy absent).
+    """
+    if filename is not None:
+        raise NotImplementedError("writing Ritz vectors to HDF5 is outside the hot path")
+    h = np.asarray(h)
+    n = h.shape[1]
+    Hn = h[:n, :n]
+    theta, U = np.linalg.eigh(0.5 * (Hn + Hn.T))
+    hlast = h[n, n - 1] if h.shape[0] > n else 0.0
+    resnorm = np.abs(hlast * U[-1, :])
+    order = np.argsort(resnorm)
+    theta, U = theta[order], U[:, order]
+    z = np.asarray(v)[:, :n].dot(U)
+    sel = theta < threshold
+    r = int(sel.sum())
+    print("Found   %d Ritz eigenvalues smaller than %.1g " % (r, threshold))
+    if eigenvalues:
+        return z[:, sel], r, theta[sel]
+    return z[:, :r], r

@@ -1,0 +1,640 @@
+"""
+The map-making operators of COSMOMAP2 with the reference's class names,
+constructor signatures and attributes (interfaces/linearoperators.py of the
+reference, cited per class), running on MI355X through libcosmomap2_hip.so.
+
+Every ``mult`` accepts a NumPy array (uploaded, result downloaded -- the
+reference's calling convention) or a float64 torch tensor already in HBM
+(returned as a tensor, nothing crosses PCIe).  There is no CPU code path: without
+the HIP library and a GPU the constructors raise.
+
+Ownership: the reference keeps *references* to the caller's arrays
+(linearoperators.py:531-534, 848-856).  Here the arrays are snapshotted into HBM
+at construction; later host-side mutation is not seen.
+"""
+import ctypes
+
+import numpy as np
+import scipy.linalg as sla
+
+from .. import _hip
+from .. import device as D
+from .. import linop as lp
+from . import blkop as blk
+
+torch = D.torch
+
+__all__ = ["SparseLO", "ToeplitzLO", "BlockLO", "BlockDiagonalLO",
+           "BlockDiagonalPreconditionerLO", "InverseLO", "CoarseLO", "DeflationLO",
+           "TwoLevelPreconditionerLO", "lp"]
+
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_DBLP = ctypes.POINTER(ctypes.c_double)
+
+
+def _as_i64(a):
+    arr = np.ascontiguousarray(a, dtype=np.int64)
+    return arr, arr.ctypes.data_as(_I64P)
+
+
+def _as_f64(a):
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    return arr, arr.ctypes.data_as(_DBLP)
+
+
+class _DeviceOp(lp.LinearOperator):
+    """Marker base: matvec understands device tensors (lets operator products stay
+    in HBM between factors)."""
+    _device_ok = True
+
+
+# ==================================================================== SparseLO ===
+class SparseLO(_DeviceOp):
+    """
+    Pointing matrix P (reference: interfaces/linearoperators.py:326-557).
+
+    ``SparseLO(n, m, pix_samples, pol=1, angle_processed=None)`` with ``n`` pixels,
+    ``m`` samples, ``pix_samples`` the pixel of each sample (-1 = flagged) and
+    ``angle_processed`` a :class:`ProcessTimeSamples` carrying ``cos``/``sin``.
+    ``P*x`` gathers (mult/mult_qu/mult_iqu, :356-497); ``P.T*v`` is the scatter-add
+    (rmult*, :385-526) computed as a fixed-order per-pixel reduction.
+    """
+
+    def __init__(self, n, m, pix_samples, pol=1, angle_processed=None):
+        self.ncols = int(n)
+        self.nrows = int(m)
+        self.pol = pol
+        self.pairs = pix_samples
+        if pol not in (1, 2, 3):
+            # same exception type and text class as linearoperators.py:549-550
+            raise RuntimeError("No valid polarization key set!\t=>\tpol=%r \n "
+                               "Possible values are pol=%d(I),%d(QU), %d(IQU)." % (pol, 1, 2, 3))
+        D.require_gpu()
+        self._d_pix = None
+        shared = getattr(angle_processed, "_d_pix", None)
+        if shared is not None and pix_samples is getattr(angle_processed, "pixs", None):
+            self._d_pix = shared                     # already flagged and resident
+        if self._d_pix is None:
+            self._d_pix = D.i32(pix_samples)
+        if self._d_pix.numel() != self.nrows:
+            raise lp.ShapeError("pix_samples has %d entries, expected m=%d"
+                                % (self._d_pix.numel(), self.nrows))
+        self._d_cos = self._d_sin = None
+        if pol > 1:
+            if angle_processed is None:
+                raise RuntimeError("pol=%d needs angle_processed (cos/sin of 2*phi)" % pol)
+            self._angles = angle_processed         # .cos / .sin are linked, not copied (:533-534)
+            dc = getattr(angle_processed, "_d_cos", None)
+            ds = getattr(angle_processed, "_d_sin", None)
+            self._d_cos = dc if dc is not None else D.f64(angle_processed.cos)
+            self._d_sin = ds if ds is not None else D.f64(angle_processed.sin)
+        handle = ctypes.c_void_p()
+        _hip.call("cm2_pointing_create", ctypes.byref(handle), D.ptr(self._d_pix),
+                  D.ptr(self._d_cos), D.ptr(self._d_sin), self.nrows, self.ncols, int(pol),
+                  D.stream())
+        self._plan = handle
+        self._weights_of = None          # BlockLO whose diagonal is attached for the fused matvec
+        self.__runcase = {1: "I", 2: "QU", 3: "IQU"}[pol]
+        mv = {1: self.mult, 2: self.mult_qu, 3: self.mult_iqu}[pol]
+        rmv = {1: self.rmult, 2: self.rmult_qu, 3: self.rmult_iqu}[pol]
+        super(SparseLO, self).__init__(nargin=self.pol * self.ncols, nargout=self.nrows,
+                                       matvec=mv, symmetric=False, rmatvec=rmv)
+
+    def __del__(self):
+        plan = getattr(self, "_plan", None)
+        if plan:
+            try:
+                _hip.load().cm2_pointing_destroy(plan)
+            except Exception:
+                pass
+            self._plan = None
+
+    @property
+    def maptype(self):
+        """'I', 'QU' or 'IQU' (linearoperators.py:552-557)."""
+        return self.__runcase
+
+    @property
+    def cos(self):
+        return self._angles.cos
+
+    @property
+    def sin(self):
+        return self._angles.sin
+
+    def plan_info(self):
+        info = (ctypes.c_int64 * 6)()
+        _hip.call("cm2_pointing_info", self._plan, info)
+        return dict(nt=info[0], npix=info[1], pol=info[2], nvalid=info[3],
+                    padded_len=info[4], nslices=info[5])
+
+    # -- P x -----------------------------------------------------------------------
+    def _gather(self, v):
+        x = D.f64(v)
+        if x.numel() != self.pol * self.ncols:
+            raise lp.ShapeError("map vector has %d entries, expected %d"
+                                % (x.numel(), self.pol * self.ncols))
+        out = D.empty(self.nrows)
+        _hip.call("cm2_P_apply", self._plan, D.ptr(x), D.ptr(out), D.stream())
+        return D.like_input(out, v)
+
+    # -- P^T v ---------------------------------------------------------------------
+    def _scatter(self, v):
+        x = D.f64(v)
+        if x.numel() != self.nrows:
+            raise lp.ShapeError("time-domain vector has %d entries, expected %d"
+                                % (x.numel(), self.nrows))
+        out = D.empty(self.pol * self.ncols)
+        _hip.call("cm2_Pt_apply", self._plan, D.ptr(x), D.ptr(out), D.stream())
+        return D.like_input(out, v)
+
+    # the reference's six method names, one gather/scatter pair per map type
+    mult = mult_qu = mult_iqu = _gather
+    rmult = rmult_qu = rmult_iqu = _scatter
+
+    # -- fused P^T diag(w) P ---------------------------------------------------------
+    def _attach_weights(self, noise):
+        """Make `noise` (a constant-diagonal BlockLO, or None for N = I) the weight
+        of the fused matvec."""
+        key = id(noise) if noise is not None else 0
+        if self._weights_of != key:
+            w = None if noise is None else noise._device_diag()
+            if w is not None and w.numel() != self.nrows:
+                raise lp.ShapeError("noise operator has %d samples, pointing has %d"
+                                    % (w.numel(), self.nrows))
+            _hip.call("cm2_pointing_set_weights", self._plan, D.ptr(w), D.stream())
+            self._weights_of = key
+            self._weights_keepalive = noise
+
+    def fused_normal_matvec(self, v, noise=None):
+        """(P.T * N * P) * v in one pass over the samples, N constant-diagonal."""
+        self._attach_weights(noise)
+        x = D.f64(v)
+        if x.numel() != self.pol * self.ncols:
+            raise lp.ShapeError("map vector has %d entries, expected %d"
+                                % (x.numel(), self.pol * self.ncols))
+        out = D.empty(self.pol * self.ncols)
+        _hip.call("cm2_PtNP_diag_apply", self._plan, D.ptr(x), D.ptr(out), D.stream())
+        return D.like_input(out, v)
+
+
+class _FusedNormalLO(_DeviceOp):
+    """P^T diag(w) P as one operator (produced by the product-chain fusion)."""
+
+    def __init__(self, P, noise):
+        self.P, self.noise = P, noise
+        n = P.pol * P.ncols
+        super(_FusedNormalLO, self).__init__(n, n, lambda v: P.fused_normal_matvec(v, noise),
+                                             symmetric=True)
+
+
+@lp.register_chain_fusion
+def _fuse_chain(chain):
+    """[..., P.T, N(diag), P, ...] -> [..., fused, ...]  and  [P.T, P] likewise.
+    The fused kernel performs the same operations in the same order as the three
+    stages, so results are identical; only the HBM traffic changes."""
+    out, i, changed = [], 0, False
+    n = len(chain)
+    while i < n:
+        a = chain[i]
+        P = getattr(a, "T", None) if getattr(a, "_is_transpose", False) else None
+        if isinstance(P, SparseLO):
+            if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], BlockLO) \
+                    and not chain[i + 1].isoffdiag:
+                out.append(_FusedNormalLO(P, chain[i + 1]))
+                i += 3
+                changed = True
+                continue
+            if i + 1 < n and chain[i + 1] is P:
+                out.append(_FusedNormalLO(P, None))
+                i += 2
+                changed = True
+                continue
+        out.append(a)
+        i += 1
+    return out if changed else None
+
+
+# ================================================================== noise N^-1 ===
+class _NoiseHandle(object):
+    """Owns a cm2_noise object."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                _hip.load().cm2_noise_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+
+def _make_toeplitz(bands, sizes, method=0):
+    bands = np.ascontiguousarray(bands, dtype=np.float64)
+    nb, lam = bands.shape
+    _, pb = _as_f64(bands.ravel())
+    sz, ps = _as_i64(sizes)
+    h = ctypes.c_void_p()
+    _hip.call("cm2_noise_create_toeplitz", ctypes.byref(h), pb, int(lam), ps, int(nb),
+              int(method), D.stream())
+    return _NoiseHandle(h)
+
+
+def _noise_apply(handle, nt, v):
+    x = D.f64(v)
+    if x.numel() != nt:
+        raise lp.ShapeError("Multiplying with vector of wrong shape: %d samples expected, got %d"
+                            % (nt, x.numel()))
+    out = D.empty(nt)
+    _hip.call("cm2_noise_apply", handle.h, D.ptr(x), D.ptr(out), D.stream())
+    return D.like_input(out, v)
+
+
+class ToeplitzLO(_DeviceOp):
+    """
+    Symmetric banded Toeplitz block (reference: linearoperators.py:560-602):
+    ``ToeplitzLO(a, size)`` with ``a`` the first ``len(a)`` entries of the first row.
+    ``mult`` reproduces the zero-boundary product of :582-595.  ``method`` selects
+    the direct kernel (reference summation order) or rocFFT overlap-save.
+    """
+
+    def __init__(self, a, size, method=0):
+        D.require_gpu()
+        self.array = a
+        self._size = int(size)
+        band = np.atleast_1d(np.asarray(a, dtype=np.float64))
+        self._noise = _make_toeplitz(band.reshape(1, -1), [self._size], method)
+        super(ToeplitzLO, self).__init__(nargin=size, nargout=size, matvec=self.mult,
+                                         symmetric=True)
+
+    def mult(self, v):
+        return _noise_apply(self._noise, self._size, v)
+
+
+class BlockLO(blk.BlockDiagonalLinearOperator):
+    """
+    Inverse noise N^-1, block diagonal over stationary intervals (reference:
+    linearoperators.py:627-697).  ``BlockLO(blocksize, t, offdiag=False)``:
+
+    * ``offdiag=False``: ``t[b]`` is the constant diagonal of block ``b``;
+      ``.diag`` is the per-sample weight array (:677-683);
+    * ``offdiag=True``: ``t[b]`` is the band of a :class:`ToeplitzLO` block; ``.diag``
+      is only ``t[0]``, as in the reference (:673, :683).
+
+    ``blocksize`` may be an int (equal blocks) or a list of per-block sizes (the
+    docstring's promise at :638-639, which the reference itself does not honour).
+    All blocks are applied by one device call (blkop.py:195-206 loops in Python).
+    """
+    _device_ok = True
+
+    def __init__(self, blocksize, t, offdiag=False, method=0):
+        D.require_gpu()
+        self.__isoffdiag = bool(offdiag)
+        self.blocksize = blocksize
+        self.covnoise = t
+        nb = len(t)
+        if np.ndim(blocksize) == 0:
+            self._sizes = [int(blocksize)] * nb
+        else:
+            self._sizes = [int(b) for b in blocksize]
+            if len(self._sizes) != nb:
+                raise lp.ShapeError("blocksize lists %d blocks, t has %d" % (len(self._sizes), nb))
+        self._nt = int(sum(self._sizes))
+        self._method = method
+        self._diag_host = None
+        self._diag_dev = None
+        self.build_blocks()
+        super(BlockLO, self).__init__(None, _lazy=(self._make_blocklist, self._sizes),
+                                      matvec=self._apply_all)
+
+    def build_blocks(self):
+        """Create the device-side operator (the reference builds one Python
+        operator per block here, :655-683; those are made lazily by ``blocklist``)."""
+        if self.isoffdiag:
+            bands = [np.atleast_1d(np.asarray(b, dtype=np.float64)) for b in self.covnoise]
+            lam = len(bands[0])
+            if any(len(b) != lam for b in bands):
+                raise lp.ShapeError("all Toeplitz bands must have the same length")
+            self._noise = _make_toeplitz(np.vstack(bands), self._sizes, self._method)
+        else:
+            vals, pv = _as_f64([float(v) for v in self.covnoise])
+            sz, ps = _as_i64(self._sizes)
+            h = ctypes.c_void_p()
+            _hip.call("cm2_noise_create_diag", ctypes.byref(h), pv, ps, len(self._sizes))
+            self._noise = _NoiseHandle(h)
+
+    def _make_blocklist(self):
+        if self.isoffdiag:
+            return [ToeplitzLO(b, s, self._method) for b, s in zip(self.covnoise, self._sizes)]
+        return [lp.DiagonalOperator(np.full(s, float(v))) for v, s in zip(self.covnoise, self._sizes)]
+
+    @property
+    def blocklist(self):
+        return self.blocks
+
+    @property
+    def isoffdiag(self):
+        """Whether the operator has off-diagonal terms (:691-697)."""
+        return self.__isoffdiag
+
+    @property
+    def diag(self):
+        """diag(N^-1) as a NumPy array (built on first use)."""
+        if self._diag_host is None:
+            if self.isoffdiag:
+                self._diag_host = np.asarray(self.covnoise[0], dtype=np.float64)
+            else:
+                self._diag_host = D.to_host(self._device_diag())
+        return self._diag_host
+
+    def _device_diag(self):
+        if self.isoffdiag:
+            raise RuntimeError("per-sample diagonal is only defined for offdiag=False")
+        if self._diag_dev is None:
+            self._diag_dev = D.empty(self._nt)
+            _hip.call("cm2_noise_expand_diag", self._noise.h, D.ptr(self._diag_dev), D.stream())
+        return self._diag_dev
+
+    def noise_info(self):
+        info = (ctypes.c_int64 * 5)()
+        _hip.call("cm2_noise_info", self._noise.h, info)
+        return dict(nt=info[0], nblocks=info[1], lam=info[2], method=info[3], fft_len=info[4])
+
+    def _apply_all(self, v):
+        return _noise_apply(self._noise, self._nt, v)
+
+
+# ====================================================== per-pixel Stokes blocks ===
+class _PixelWeights(object):
+    """Device copies of the per-pixel sums held by a ProcessTimeSamples."""
+
+    FIELDS = ("counts", "cosine", "sine", "cos2", "sin2", "sincos")
+
+    def __init__(self, CES, n, pol):
+        D.require_gpu()
+        self.npix, self.pol = int(n), int(pol)
+        need = {1: ("counts",), 2: ("cos2", "sin2", "sincos"), 3: self.FIELDS}[pol]
+        dev_side = getattr(CES, "_dev_weights", None) or {}
+        self.d = {}
+        for k in self.FIELDS:
+            if k in need:
+                t = dev_side.get(k)
+                self.d[k] = t if t is not None else D.f64(getattr(CES, k))
+                if self.d[k].numel() != self.npix:
+                    raise lp.ShapeError("CES.%s has %d pixels, expected n=%d"
+                                        % (k, self.d[k].numel(), self.npix))
+            else:
+                self.d[k] = None
+
+    def ptrs(self):
+        return [D.ptr(self.d[k]) for k in self.FIELDS]
+
+
+class BlockDiagonalLO(_DeviceOp):
+    """
+    Explicit per-pixel apply of ``P^T diag(N^-1) P`` (reference:
+    linearoperators.py:700-746): pol=1 ``x*counts``; pol=2 / pol=3 the 2x2 / 3x3
+    blocks ``[[hits,c,s],[c,c2,cs],[s,cs,s2]]``.
+    """
+
+    def __init__(self, CES, n, pol=1):
+        self.size = pol * n
+        self.pol = pol
+        self.pixels = np.arange(n)
+        self._w = _PixelWeights(CES, n, pol)
+        if pol == 1:
+            self.counts = CES.counts
+        elif pol > 1:
+            self.sin2, self.sincos, self.cos2 = CES.sin2, CES.sincos, CES.cos2
+            if pol == 3:
+                self.counts, self.cos, self.sin = CES.counts, CES.cosine, CES.sine
+        super(BlockDiagonalLO, self).__init__(nargin=self.size, nargout=self.size,
+                                              matvec=self.mult, symmetric=True)
+
+    def mult(self, x):
+        xd = D.f64(x)
+        out = D.empty(self.size)
+        _hip.call("cm2_bd_apply", int(self.pol), self._w.npix, *(self._w.ptrs() + [
+            D.ptr(xd), D.ptr(out), D.stream()]))
+        return D.like_input(out, x)
+
+
+class BlockDiagonalPreconditionerLO(_DeviceOp):
+    """
+    ``M_BD = (P^T diag(N^-1) P)^-1`` per pixel (reference: linearoperators.py:749-859):
+    closed-form 1x1 / 2x2 / 3x3 inverse; pixels with ``|det| <= 1e-5`` (pol>1) or
+    ``counts <= 0`` (pol=1) give 0 (:780, :789, :795, :821).  The determinant and
+    mask are computed once at construction (the reference recomputes them per call).
+    """
+
+    def __init__(self, CES, n, pol=1):
+        self.size = pol * n
+        self.pixels = np.arange(n)
+        self.pol = pol
+        self._w = _PixelWeights(CES, n, pol)
+        if pol == 1:
+            self.counts = CES.counts
+        elif pol > 1:
+            self.sin2, self.cos2, self.sincos = CES.sin2, CES.cos2, CES.sincos
+            if pol == 3:
+                self.counts, self.cos, self.sin = CES.counts, CES.cosine, CES.sine
+        self._d_det = D.empty(n)
+        self._d_mask = D.empty(n, torch.uint8)
+        _hip.call("cm2_bd_det_mask", int(pol), int(n), *(self._w.ptrs() + [
+            D.ptr(self._d_det), D.ptr(self._d_mask), D.stream()]))
+        super(BlockDiagonalPreconditionerLO, self).__init__(nargin=self.size, nargout=self.size,
+                                                            matvec=self.mult, symmetric=True)
+
+    def mult(self, x):
+        xd = D.f64(x)
+        out = D.empty(self.size)
+        _hip.call("cm2_bdprecond_apply", int(self.pol), self._w.npix, *(self._w.ptrs() + [
+            D.ptr(self._d_det), D.ptr(self._d_mask), D.ptr(xd), D.ptr(out), D.stream()]))
+        return D.like_input(out, x)
+
+
+# =================================================================== InverseLO ===
+class InverseLO(lp.LinearOperator):
+    """
+    ``A^-1`` as an operator: ``mult(x)`` runs ``method(A, x, M=preconditioner)`` and
+    returns the solution (reference: linearoperators.py:861-941).  ``method`` is any
+    solver with the ``scipy.sparse.linalg.cg`` calling convention, e.g.
+    :func:`cosmomap2_amd.cg` (device PCG).
+    """
+
+    def __init__(self, A, method=None, preconditioner=None):
+        super(InverseLO, self).__init__(nargin=A.shape[0], nargout=A.shape[1], matvec=self.mult,
+                                        symmetric=True)
+        self.A = A
+        self.__method = method
+        self.__preconditioner = preconditioner
+        self.__converged = None
+
+    def mult(self, x):
+        y, info = self.method(self.A, x, M=self.preconditioner)
+        self.isconverged(info)
+        return y
+
+    def isconverged(self, info):
+        self.__converged = info
+        return info == 0
+
+    method = property(lambda self: self.__method)
+    converged = property(lambda self: self.__converged)
+    preconditioner = property(lambda self: self.__preconditioner)
+
+
+# ============================================================ deflation / coarse ===
+def _dev_matrix(z):
+    """n x r matrix as a row-major float64 tensor in HBM."""
+    if D.is_tensor(z):
+        t = D.f64(z)
+    else:
+        t = D.f64(np.ascontiguousarray(np.asarray(z, dtype=np.float64)))
+    if t.dim() != 2:
+        raise lp.ShapeError("deflation matrix must be 2-d (n x r)")
+    return t
+
+
+class DeflationLO(_DeviceOp):
+    """
+    Deflation operator Z (reference: linearoperators.py:1029-1065): ``Z*y`` is the
+    combination of the r columns (:1041-1050), ``Z.T*x`` the r scalar products
+    (:1051-1056).  Z lives row-major in HBM, read once per application.
+    """
+
+    def __init__(self, z):
+        D.require_gpu()
+        self._d_Z = _dev_matrix(z)
+        self.nrows, self.ncols = int(self._d_Z.shape[0]), int(self._d_Z.shape[1])
+        self._z_host = None if D.is_tensor(z) else np.asarray(z)
+        super(DeflationLO, self).__init__(nargin=self.ncols, nargout=self.nrows,
+                                          matvec=self.mult, symmetric=False, rmatvec=self.rmult)
+
+    @property
+    def z(self):
+        """The columns of Z as a list of arrays (:1059-1062)."""
+        if self._z_host is None:
+            self._z_host = D.to_host(self._d_Z)
+        return [self._z_host[:, j] for j in range(self.ncols)]
+
+    def mult(self, x):
+        y = D.f64(x)
+        if y.numel() != self.ncols:
+            raise lp.ShapeError("coefficient vector has %d entries, expected r=%d"
+                                % (y.numel(), self.ncols))
+        out = D.empty(self.nrows)
+        _hip.call("cm2_Z_apply", self.nrows, self.ncols, D.ptr(self._d_Z), D.ptr(y), D.ptr(out),
+                  D.stream())
+        return D.like_input(out, x)
+
+    def rmult(self, x):
+        xd = D.f64(x)
+        if xd.numel() != self.nrows:
+            raise lp.ShapeError("map vector has %d entries, expected %d" % (xd.numel(), self.nrows))
+        out = D.empty(self.ncols)
+        _hip.call("cm2_Zt_apply", self.nrows, self.ncols, D.ptr(self._d_Z), D.ptr(xd), D.ptr(out),
+                  D.ptr(D.reduce_work()), D.stream())
+        return D.like_input(out, x)
+
+
+class CoarseLO(_DeviceOp):
+    """
+    Coarse operator, always applied as ``E^-1`` (reference: linearoperators.py:946-1027).
+    ``E = Z^T (A Z)`` is contracted on the GPU (fp64 MFMA panels when r is a multiple of
+    16), brought to the host (r x r) and factorised there exactly like the reference:
+    ``apply='LU'`` -> ``lu(E, permute_l=True)`` and two solves (:975-976, :1025);
+    ``apply='eig'`` -> ``eigh``, eigenvalues with ``|lambda/lambda_max| < 1e-6`` dropped
+    (:994-1015).  Vectors already in HBM are multiplied by the explicit r x r inverse.
+    """
+
+    def __init__(self, Z, Az, r, apply='LU'):
+        D.require_gpu()
+        dZ, dAZ = _dev_matrix(Z), _dev_matrix(Az)
+        n, rz = int(dZ.shape[0]), int(dZ.shape[1])
+        if tuple(dAZ.shape) != (n, rz):
+            raise lp.ShapeError("Z is %r, Az is %r" % (tuple(dZ.shape), tuple(dAZ.shape)))
+        dE = D.empty(rz * rz)
+        work = D.empty(int(_hip.load().cm2_gemm_tn_work_doubles(rz, rz)))
+        _hip.call("cm2_gemm_tn", n, rz, rz, D.ptr(dZ), D.ptr(dAZ), D.ptr(dE), D.ptr(work),
+                  D.stream())
+        M = D.to_host(dE).reshape(rz, rz)                      # :1019  dgemm(Z, Az.T)
+        self.E = M.copy()
+        self.r = rz
+        self._apply_kind = apply
+        if apply == 'eig':
+            self.setting_inverse_w_eigenvalues(M)
+            inv = self.invE
+            mv = self.mult_eig
+        elif apply == 'LU':
+            self.L, self.U = sla.lu(M, permute_l=True, check_finite=False)
+            inv = sla.solve(self.U, sla.solve(self.L, np.eye(rz)))
+            mv = self.mult
+        else:
+            raise ValueError("apply must be 'LU' or 'eig', got %r" % (apply,))
+        self._d_inv = D.f64(np.ascontiguousarray(inv))
+        super(CoarseLO, self).__init__(nargin=r, nargout=r, matvec=mv, symmetric=True)
+
+    def _device_mult(self, v):
+        out = D.empty(self.r)
+        _hip.call("cm2_small_matvec", self.r, D.ptr(self._d_inv), D.ptr(D.f64(v)), D.ptr(out),
+                  D.stream())
+        return D.like_input(out, v)
+
+    def mult(self, v):
+        """x = E^-1 v through L and U (:969-977)."""
+        if D.is_tensor(v):
+            return self._device_mult(v)
+        y = sla.solve(self.L, v)
+        return sla.solve(self.U, y)
+
+    def mult_eig(self, v):
+        """x = E^+ v with the eigen-decomposed pseudo-inverse (:979-984)."""
+        if D.is_tensor(v):
+            return self._device_mult(v)
+        return self.invE.dot(v)
+
+    def setting_inverse_w_eigenvalues(self, E):
+        """Pseudo-inverse of E keeping eigenvalues with |lambda/lambda_max| > 1e-6
+        (:986-1015)."""
+        eigenvals, W = sla.eigh(E)
+        lambda_max = max(eigenvals)
+        diags = eigenvals * 0.
+        keep = np.where(abs(eigenvals / lambda_max) > 1.e-6)[0]
+        self.n_discarded = len(eigenvals) - len(keep)
+        diags[keep] = 1. / eigenvals[keep]
+        self.invE = (W * diags).dot(W.T)
+
+
+class TwoLevelPreconditionerLO(_DeviceOp):
+    """
+    ``M2 = Mbd (I - AZ E^-1 Z^T) + Z E^-1 Z^T`` as one operator (the composition of
+    src/test_M2_precond_onto_real_data.py:98-112 and
+    tests/test_2level_preconditioner.py:45-48), with ``y = E^-1 Z^T r`` evaluated
+    once: Z^T r (one pass over Z), the r x r solve, then one fused pass over Z and AZ
+    that also applies the per-pixel M_BD block.
+    """
+
+    def __init__(self, Mbd, Zd, AZd, E):
+        if not isinstance(Mbd, BlockDiagonalPreconditionerLO):
+            raise TypeError("Mbd must be a BlockDiagonalPreconditionerLO")
+        self.Mbd, self.Zd, self.AZd, self.E = Mbd, Zd, AZd, E
+        n = Mbd.size
+        if Zd.nrows != n or AZd.nrows != n or Zd.ncols != AZd.ncols:
+            raise lp.ShapeError("Z / AZ shapes do not match the map size %d" % n)
+        super(TwoLevelPreconditionerLO, self).__init__(nargin=n, nargout=n, matvec=self.mult,
+                                                       symmetric=True)
+
+    def mult(self, x):
+        res = D.f64(x)
+        y0 = self.Zd.rmult(res)
+        y = self.E._device_mult(y0)
+        out = D.empty(self.Mbd.size)
+        w = self.Mbd._w
+        _hip.call("cm2_m2_finish", int(self.Mbd.pol), w.npix, self.Zd.ncols,
+                  D.ptr(self.Zd._d_Z), D.ptr(self.AZd._d_Z), D.ptr(y), D.ptr(res),
+                  *(w.ptrs() + [D.ptr(self.Mbd._d_det), D.ptr(self.Mbd._d_mask), D.ptr(out),
+                                D.stream()]))
+        return D.like_input(out, x)

@@ -1,0 +1,127 @@
+"""
+Preconditioned conjugate gradient with map vectors resident in HBM.
+
+The reference has no solver of its own: it calls ``scipy.sparse.linalg.cg``
+(tests/test_2level_preconditioner.py:52, tests/test_arnoldi_algorithm.py:46,91,
+src/test_BD_precond_onto_real_data.py:47, src/test_M2_precond_onto_real_data.py:117,
+and InverseLO.mult interfaces/linearoperators.py:882).  :func:`cg` keeps that calling
+convention and reproduces scipy's recurrence step for step (scipy 1.15
+``_isolve/iterative.py::cg``):
+
+    atol = max(atol, rtol*||b||);  r = b - A x0 (b if x0 == 0)
+    loop:  if ||r|| < atol: return x, 0
+           z = M r; rho = r.z; p = z (first) | p = beta p + z, beta = rho/rho_prev
+           q = A p; alpha = rho / (p.q); x += alpha p; r -= alpha q; callback(x)
+    return x, maxiter
+
+"Iterations" = number of callback invocations, as the reference counts them
+(src/test_BD_precond_onto_real_data.py:41-47).  The scalars alpha and beta never
+visit the host: the fused update kernels read rho, rho_prev and p.q from device
+memory; the only per-iteration synchronisation is the 8-byte read of ||r||^2 for
+the convergence test.
+"""
+import math
+
+import numpy as np
+
+from . import _hip
+from . import device as D
+from . import linop as lp
+
+torch = D.torch
+
+__all__ = ["cg"]
+
+
+def _apply(op, x):
+    """Apply an operator / callable / matrix to a device vector, staying in HBM when
+    the operator can."""
+    if op is None:
+        return x
+    if isinstance(op, lp.BaseLinearOperator):
+        if lp.supports_device(op):
+            return D.f64(op.matvec(x))
+        return D.f64(np.asarray(op.matvec(D.to_host(x))))
+    if callable(op) and not hasattr(op, "matvec"):
+        return D.f64(op(x))
+    if hasattr(op, "matvec"):                      # scipy LinearOperator and the like
+        return D.f64(np.asarray(op.matvec(D.to_host(x))))
+    return D.f64(np.asarray(op).dot(D.to_host(x)))
+
+
+def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rtol=1e-5,
+       sync=None):
+    """
+    Solve ``A x = b`` by PCG on the GPU.  Arguments and return value ``(x, info)`` follow
+    ``scipy.sparse.linalg.cg``; ``tol`` is accepted as the old name of ``rtol`` (the
+    reference still passes ``tol=``).  ``b`` / ``x0`` may be NumPy arrays (result is NumPy)
+    or float64 tensors in HBM (result is a tensor, ``callback`` receives a tensor).
+
+    ``sync``: optional callable mapping the host value of ||r||^2 to the value every
+    rank must use (sharding.py passes an all-reduce so that all ranks take the same
+    branch).
+    """
+    D.require_gpu()
+    if tol is not None:
+        rtol = tol
+    host_io = not D.is_tensor(b)
+    bd = D.f64(b).reshape(-1)
+    n = bd.numel()
+    lib = _hip.load()
+    work = D.reduce_work()
+    st = D.stream
+
+    def dot_into(out, u, v):
+        _hip.check(lib.cm2_dot(n, D.ptr(u), D.ptr(v), D.ptr(out), D.ptr(work), st()))
+
+    scal = D.zeros(5)                   # rho_a, rho_b, pq, rr, tmp  (device scalars)
+    rho = [scal[0:1], scal[1:2]]
+    pq, rr, tmp = scal[2:3], scal[3:4], scal[4:5]
+
+    dot_into(tmp, bd, bd)
+    bnrm2 = math.sqrt(float(tmp.item()))
+    atol = max(float(atol), float(rtol) * bnrm2)
+    if bnrm2 == 0:
+        return (D.to_host(bd) if host_io else bd.clone()), 0
+    if maxiter is None:
+        maxiter = n * 10
+
+    if x0 is None:
+        x = D.zeros(n)
+        r = bd.clone()
+    else:
+        x = D.f64(x0).reshape(-1).clone()
+        dot_into(tmp, x, x)
+        xx = float(tmp.item())
+        if xx != 0.0 or xx != xx:
+            r = D.add_scaled(bd, -1.0, _apply(A, x))          # r = b - A x0
+        else:
+            r = bd.clone()
+    dot_into(rr, r, r)
+    rr_host = float(rr.item())
+    if sync is not None:
+        rr_host = sync(rr_host)
+
+    p = None
+    cur = 0
+    for iteration in range(int(maxiter)):
+        if math.sqrt(rr_host) < atol:
+            return (D.to_host(x) if host_io else x), 0
+        z = _apply(M, r) if M is not None else r
+        dot_into(rho[cur], r, z)
+        if iteration > 0:
+            _hip.check(lib.cm2_pcg_update_p(n, D.ptr(rho[cur]), D.ptr(rho[1 - cur]), D.ptr(z),
+                                            D.ptr(p), st()))
+        else:
+            p = z.clone()
+        q = _apply(A, p)
+        dot_into(pq, p, q)
+        _hip.check(lib.cm2_pcg_update_xr(n, D.ptr(rho[cur]), D.ptr(pq), D.ptr(p), D.ptr(q),
+                                         D.ptr(x), D.ptr(r), D.ptr(rr), D.ptr(work), st()))
+        cur = 1 - cur
+        rr_host = float(rr.item())
+        if sync is not None:
+            rr_host = sync(rr_host)
+        if callback is not None:
+            callback(D.to_host(x) if host_io else x)
+    return (D.to_host(x) if host_io else x), int(maxiter)

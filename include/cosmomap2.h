@@ -1,0 +1,217 @@
+/*
+ * cosmomap2.h -- C ABI of libcosmomap2_hip.so, the MI355X (gfx950) implementation
+ * of the COSMOMAP2 PCG map-making hot path.
+ *
+ * The reference (giuspugl/COSMOMAP2) has no FFI of its own: its native code is a
+ * set of C++ loop bodies held as Python strings and JIT-compiled by weave.inline
+ * (e.g. interfaces/linearoperators.py:368-382).  Each entry point below replaces
+ * one of those loops (or the NumPy/BLAS lines that play the same role) and cites
+ * it.  The Python binding a maintainer would add in place of each
+ * `inline(code, ...)` call is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     cm2_last_error() returns a static, thread-local message for the last failure;
+ *   - pointers named d_* are DEVICE pointers, h_* are HOST pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is enqueued on it and the call returns without synchronising unless stated;
+ *   - maps are pixel-interleaved doubles [I0,Q0,U0,I1,...] (linearoperators.py:487);
+ *     pixel ids are int32, -1 marks a flagged sample (linearoperators.py:372);
+ *     all arithmetic is IEEE double, no FMA contraction, reference operand order;
+ *   - one context per process per GPU; not thread-safe (the reference is
+ *     single-threaded).
+ */
+#ifndef COSMOMAP2_H
+#define COSMOMAP2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM2_ABI_VERSION 1
+
+const char *cm2_last_error(void);
+int cm2_abi_version(void);
+/* device properties used by the bench harness (name buffer >= 256 bytes) */
+int cm2_device_info(int device, char *h_name, int *h_num_cu, double *h_hbm_gib);
+
+/* ------------------------------------------------------------------------- *
+ * a1-a3  Pointing matrix  (SparseLO, interfaces/linearoperators.py:326-557)
+ * ------------------------------------------------------------------------- */
+typedef struct cm2_pointing cm2_pointing;
+
+/* Builds the device-side pointing plan from time-ordered arrays that are
+ * already resident in HBM.  The plan KEEPS the three pointers (caller keeps the
+ * buffers alive) and adds a pixel-major copy: samples grouped by pixel in time
+ * order, 64 pixels per slice, slices sorted by hit count (sliced-ELL), which is
+ * what makes P^T a race-free, fixed-order reduction.  d_cos/d_sin may be NULL
+ * for pol == 1.  Replaces SparseLO.__init__ (linearoperators.py:527-550);
+ * pol not in {1,2,3} fails like the RuntimeError at :549.  Synchronises. */
+int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix, const double *d_cos,
+                        const double *d_sin, int64_t nt, int64_t npix, int pol,
+                        void *stream);
+int cm2_pointing_destroy(cm2_pointing *p);
+/* h_info[0..5] = nt, npix, pol, valid samples, padded pixel-major length, slices */
+int cm2_pointing_info(const cm2_pointing *p, int64_t *h_info);
+
+/* P x: gather, time order.  d_out[t] = I_p + Q_p cos2phi_t + U_p sin2phi_t, 0 for
+ * flagged samples.  Replaces the weave loops at linearoperators.py:368-375
+ * (mult), :424-430 (mult_qu), :483-489 (mult_iqu). */
+int cm2_P_apply(const cm2_pointing *p, const double *d_x, double *d_out, void *stream);
+
+/* P^T v: scatter-add in sample order per pixel, written as a per-pixel
+ * fixed-order reduction.  Replaces linearoperators.py:394-400 (rmult),
+ * :447-454 (rmult_qu), :509-516 (rmult_iqu).  Overwrites d_out (pol*npix). */
+int cm2_Pt_apply(const cm2_pointing *p, const double *d_v, double *d_out, void *stream);
+
+/* Attach per-sample diagonal noise weights w_t = (N^-1)_tt (time order, nt
+ * doubles; NULL = all ones) for the fused matvec below.  Replaces the role of
+ * BlockLO.diag (linearoperators.py:677-683). */
+int cm2_pointing_set_weights(cm2_pointing *p, const double *d_w, void *stream);
+
+/* Fused P^T diag(w) P x in ONE pass over the pixel-major samples; no TOD vector
+ * is materialised.  Same arithmetic, in the same order, as the reference's
+ * three-stage chain (P.T*N*P)*x  (tests/test_toeplitz_vector_multiplication.py:24-28,
+ * call stack SURVEY 3.2). */
+int cm2_PtNP_diag_apply(const cm2_pointing *p, const double *d_x, double *d_out,
+                        void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * a4-a5  Noise operator N^-1  (ToeplitzLO linearoperators.py:560-602,
+ *        BlockLO :627-697, blk_matvec interfaces/blkop.py:178-208)
+ * ------------------------------------------------------------------------- */
+typedef struct cm2_noise cm2_noise;
+
+#define CM2_TOEPLITZ_AUTO   0   /* direct for short bands, FFT otherwise */
+#define CM2_TOEPLITZ_DIRECT 1   /* O(n*lambda), reference summation order  */
+#define CM2_TOEPLITZ_FFT    2   /* overlap-save, rocFFT R2C/C2R fp64       */
+
+/* Block-diagonal with constant diagonal blocks: block b = h_t[b] * I of
+ * h_sizes[b] samples (BlockLO offdiag=False, :676-683). */
+int cm2_noise_create_diag(cm2_noise **out, const double *h_t, const int64_t *h_sizes,
+                          int64_t nblocks);
+/* Block-diagonal of symmetric banded Toeplitz blocks: block b has first row
+ * h_bands[b*lambda .. b*lambda+lambda-1] (ToeplitzLO.mult :582-595), zero
+ * boundary at each block edge -- never circulant, never across blocks. */
+int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands, int64_t lambda,
+                              const int64_t *h_sizes, int64_t nblocks, int method,
+                              void *stream);
+int cm2_noise_destroy(cm2_noise *n);
+/* y = N^-1 v over all blocks (blk_matvec, blkop.py:195-206).  d_out != d_v. */
+int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, void *stream);
+/* per-sample diagonal of a constant-diagonal noise operator (BlockLO.diag). */
+int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
+/* h_info[0..4] = nt, nblocks, lambda (0 for diag), method used, FFT length */
+int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
+
+/* ------------------------------------------------------------------------- *
+ * a6-a7  ProcessTimeSamples  (utilities/process_ces.py:58-555)
+ * ------------------------------------------------------------------------- */
+/* Per-pixel sums of w, w c, w s, w c c, w s s, w s c over the samples of each
+ * pixel IN TIME ORDER (fixed-order, race-free).  pol=1 fills d_counts only,
+ * pol=2 the last three, pol=3 all six (unused outputs may be NULL).  d_w NULL =
+ * ones (process_ces.py:65-66).  Replaces :480-487, :505-514, :527-539 and
+ * compute_arrays :125-186.  Synchronises (builds a temporary pixel index). */
+int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const int32_t *d_pix,
+                           const double *d_w, const double *d_cos, const double *d_sin,
+                           double *d_counts, double *d_cosine, double *d_sine,
+                           double *d_cos2, double *d_sin2, double *d_sincos, void *stream);
+/* cos(2 phi_t), sin(2 phi_t) for angles already resident in HBM
+ * (process_ces.py:493-494; host arrays use NumPy so that they match the reference
+ * bit for bit). */
+int cm2_cos_sin_2phi(int64_t nt, const double *d_phi, double *d_cos, double *d_sin,
+                     void *stream);
+/* keep[p] = 1 for well-conditioned observed pixels: pol=1 counts>0 (:491);
+ * pol>=2 |lambda_max/lambda_min| <= threshold of the QU block (:544-550);
+ * pol=3 additionally counts>2 (:554-555). */
+int cm2_pixel_mask(int pol, int64_t npix, const double *d_counts, const double *d_cos2,
+                   const double *d_sin2, const double *d_sincos, double threshold,
+                   uint8_t *d_keep, void *stream);
+/* old2new[p] = rank of p among kept pixels or -1; *h_new_npix = kept count.
+ * Same output as the O(Nold*Nm) search at :205-228, by prefix sum.  Synchronises. */
+int cm2_pixel_compact(int64_t npix, const uint8_t *d_keep, int32_t *d_old2new,
+                      int64_t *h_new_npix, void *stream);
+/* d_out[old2new[p]] = d_in[p] for kept pixels (:218-219, :248-251, :280-286). */
+int cm2_compact_f64(int64_t npix, const int32_t *d_old2new, const double *d_in,
+                    double *d_out, void *stream);
+int cm2_compact_i64(int64_t npix, const int32_t *d_old2new, const int64_t *d_in,
+                    int64_t *d_out, void *stream);
+/* pix[t] = old2new[pix[t]] in place, -1 stays -1 (flagging_samples :411-418). */
+int cm2_flag_samples(int64_t nt, int32_t *d_pix, const int32_t *d_old2new, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * a8-a9  Per-pixel Stokes blocks
+ * ------------------------------------------------------------------------- */
+/* det and |det|>1e-5 mask of the per-pixel blocks, as the NumPy lines
+ * linearoperators.py:792-795 (pol=3) / :820-821 (pol=2) / :789 (pol=1, counts>0). */
+int cm2_bd_det_mask(int pol, int64_t npix, const double *d_counts, const double *d_cosine,
+                    const double *d_sine, const double *d_cos2, const double *d_sin2,
+                    const double *d_sincos, double *d_det, uint8_t *d_mask, void *stream);
+/* y = M_BD x: closed-form adjugate/det per masked pixel, 0 elsewhere
+ * (BlockDiagonalPreconditionerLO.mult, linearoperators.py:775-841). */
+int cm2_bdprecond_apply(int pol, int64_t npix, const double *d_counts,
+                        const double *d_cosine, const double *d_sine, const double *d_cos2,
+                        const double *d_sin2, const double *d_sincos, const double *d_det,
+                        const uint8_t *d_mask, const double *d_x, double *d_y, void *stream);
+/* y = (P^T diag(N^-1) P) x per pixel (BlockDiagonalLO.mult, :728-746). */
+int cm2_bd_apply(int pol, int64_t npix, const double *d_counts, const double *d_cosine,
+                 const double *d_sine, const double *d_cos2, const double *d_sin2,
+                 const double *d_sincos, const double *d_x, double *d_y, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * a15-a16  BLAS-1 and the PCG recurrence
+ *   (utilities/linear_algebra_funcs.py:31-44; scipy.sparse.linalg.cg as called at
+ *    tests/test_2level_preconditioner.py:52, src/test_BD_precond_onto_real_data.py:47)
+ * ------------------------------------------------------------------------- */
+/* *d_out = sum_i x_i y_i, fixed two-stage tree (bitwise reproducible run to run).
+ * d_work: >= cm2_reduce_work_doubles() doubles of scratch. */
+int64_t cm2_reduce_work_doubles(void);
+int cm2_dot(int64_t n, const double *d_x, const double *d_y, double *d_out, double *d_work,
+            void *stream);
+int cm2_axpy(int64_t n, double alpha, const double *d_x, double *d_y, void *stream); /* y += alpha x */
+int cm2_scal(int64_t n, double alpha, double *d_x, void *stream);
+int cm2_xmy(int64_t n, const double *d_x, const double *d_y, double *d_out, void *stream); /* out = x*y */
+/* p = z + (rho/rho_prev) p   with rho, rho_prev read from device memory
+ * (cg: beta = rho_cur/rho_prev; p *= beta; p += z). */
+int cm2_pcg_update_p(int64_t n, const double *d_rho, const double *d_rho_prev,
+                     const double *d_z, double *d_p, void *stream);
+/* alpha = rho/pq (device scalars); x += alpha p; r -= alpha q; *d_rr = r.r */
+int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d_pq, const double *d_p,
+                      const double *d_q, double *d_x, double *d_r, double *d_rr,
+                      double *d_work, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * a10-a12  Deflation space and coarse operator
+ *   (DeflationLO linearoperators.py:1029-1065, CoarseLO :946-1027,
+ *    M2 src/test_M2_precond_onto_real_data.py:98-112)
+ *   Z is n x r, ROW-major in HBM (the r entries of one map element contiguous).
+ * ------------------------------------------------------------------------- */
+int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d_x, double *d_out,
+                 double *d_work, void *stream);                 /* out[r] = Z^T x  (:1051-1056) */
+int cm2_Z_apply(int64_t n, int r, const double *d_Z, const double *d_y, double *d_out,
+                void *stream);                                  /* out[n] = Z y    (:1041-1050) */
+/* E[r1 x r2] (row-major) = Z1^T Z2, fp64 MFMA panels when r1,r2 are multiples of
+ * 16 (CoarseLO.__init__: dgemm(Z, Az.T), :1019).  d_work >= cm2_gemm_tn_work_doubles(r1,r2). */
+int64_t cm2_gemm_tn_work_doubles(int r1, int r2);
+int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const double *d_Z2, double *d_E,
+                double *d_work, void *stream);
+/* C[m x n] (row-major) = A^T B^T with A k x m and B n x k, both row-major: the
+ * reference's dgemm(A,B) helper (utilities/linear_algebra_funcs.py:16-29). */
+int cm2_gemm_atbt(int64_t m, int64_t n, int64_t k, const double *d_A, const double *d_B,
+                  double *d_C, void *stream);
+/* out[r] = M[r x r] (row-major) v  -- E^-1 held as an explicit small matrix */
+int cm2_small_matvec(int r, const double *d_M, const double *d_v, double *d_out, void *stream);
+/* fused second half of M2 r = M_BD (r - AZ y) + Z y  given y = E^-1 Z^T r:
+ * one pass over Z and AZ, then the per-pixel M_BD block. */
+int cm2_m2_finish(int pol, int64_t npix, int r, const double *d_Z, const double *d_AZ,
+                  const double *d_y, const double *d_res, const double *d_counts,
+                  const double *d_cosine, const double *d_sine, const double *d_cos2,
+                  const double *d_sin2, const double *d_sincos, const double *d_det,
+                  const uint8_t *d_mask, double *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSMOMAP2_H */

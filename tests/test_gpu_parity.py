@@ -1,0 +1,515 @@
+"""
+GPU parity tests: the HIP path (through the C ABI, via the drop-in Python classes)
+against the CPU oracle on the same seeded inputs, and against the golden vectors made
+from the reference's own code.  Integer/index results and every deterministic
+fixed-order kernel are compared BIT FOR BIT; reductions whose summation tree differs
+from the BLAS/NumPy one are compared at 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cm():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import cosmomap2_amd.interfaces as I
+    import cosmomap2_amd.utilities as U
+    import cosmomap2_amd
+    from types import SimpleNamespace
+    return SimpleNamespace(I=I, U=U, cg=cosmomap2_amd.cg, torch=torch)
+
+
+def make_problem(oracle, seed, nt, npix, nb, pol, flag_frac=0.0, bandsize=2):
+    rng = np.random.default_rng(seed)
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb, bandsize)
+    if flag_frac:
+        pairs[rng.random(nt) < flag_frac] = -1
+    return d, pairs, phi, t, diag
+
+
+# ------------------------------------------------------------------ a6 / a7 ------
+@pytest.mark.parametrize("pol", [1, 2, 3])
+@pytest.mark.parametrize("nt,npix", [(80, 50), (10000, 100), (20000, 600)])
+def test_process_time_samples_bitexact(cm, oracle, pol, nt, npix):
+    d, pairs, phi, t, diag = make_problem(oracle, 11 + pol, nt, npix, 4, pol, flag_frac=0.05)
+    w = np.random.default_rng(3).random(nt)
+    p_o = pairs.copy()
+    ro = oracle.process_time_samples(p_o, npix, pol=pol, phi=phi, w=w)
+    p_g = pairs.astype(np.int64)                 # callers pass int64 (np.random.randint)
+    rg = cm.U.ProcessTimeSamples(p_g, npix, pol=pol, phi=phi, w=w)
+    assert rg.get_new_pixel[0] == ro.new_npix
+    np.testing.assert_array_equal(rg.old2new, ro.old2new)
+    np.testing.assert_array_equal(rg.mask, ro.mask)
+    np.testing.assert_array_equal(p_g, p_o)      # flagged IN PLACE
+    np.testing.assert_array_equal(rg.get_new_pixel[1], ro.obspix)
+    keys = {1: ("counts",), 2: ("cos2", "sin2", "sincos"),
+            3: ("counts", "cosine", "sine", "cos2", "sin2", "sincos")}[pol]
+    for k in keys:
+        np.testing.assert_array_equal(getattr(rg, k), getattr(ro, k), err_msg=k)
+    if pol > 1:
+        np.testing.assert_array_equal(rg.cos, ro.cos)
+        np.testing.assert_array_equal(rg.sin, ro.sin)
+
+
+def test_process_time_samples_removes_bad_pixels(cm, oracle):
+    # pixel 0 never observed, pixel 1 observed twice (pol=3 needs counts>2), pixel 2 observed at
+    # a single angle (singular QU block): all three must go, ids compact in order.
+    nt, npix = 400, 12
+    rng = np.random.default_rng(0)
+    pairs = rng.integers(3, npix, size=nt).astype(np.int32)
+    phi = oracle.angles_gen(0.1, nt)
+    pairs[[5, 9]] = 1
+    pairs[[20, 40, 60, 80]] = 2
+    phi[[20, 40, 60, 80]] = 0.7
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=3, phi=phi)
+    pg = pairs.copy()
+    rg = cm.U.ProcessTimeSamples(pg, npix, pol=3, phi=phi)
+    assert ro.new_npix == npix - 3 and rg.get_new_pixel[0] == npix - 3
+    assert list(rg.old2new[:4]) == [-1, -1, -1, 0]
+    np.testing.assert_array_equal(pg, po)
+    assert (pg[[5, 9, 20, 40]] == -1).all()
+
+
+# ------------------------------------------------------------------ a2 / a3 ------
+@pytest.mark.parametrize("pol", [1, 2, 3])
+@pytest.mark.parametrize("nt,npix", [(1000, 17), (65536, 300), (200000, 4097)])
+def test_pointing_bitexact(cm, oracle, pol, nt, npix):
+    d, pairs, phi, t, diag = make_problem(oracle, 100 + pol, nt, npix, 5, pol, flag_frac=0.1)
+    rng = np.random.default_rng(7)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    from types import SimpleNamespace
+    ces = SimpleNamespace(cos=c, sin=s)
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=ces)
+    assert P.shape == (nt, pol * npix) and P.maptype == {1: "I", 2: "QU", 3: "IQU"}[pol]
+    x = rng.standard_normal(pol * npix)
+    v = rng.standard_normal(nt)
+    np.testing.assert_array_equal(P * x, oracle.sparse_mult(pol, pairs, c, s, x))
+    np.testing.assert_array_equal(P.T * v, oracle.sparse_rmult(pol, npix, pairs, c, s, v))
+    # fused P^T diag(w) P == the three stages, bit for bit
+    w = rng.random(nt)
+    ref = oracle.ptnp_diag(pol, npix, pairs, c, s, w, x)
+    P._attach_weights(SimpleNamespace(_device_diag=lambda: cm.torch.from_numpy(w).cuda()))
+    np.testing.assert_array_equal(P.fused_normal_matvec(x, P._weights_keepalive), ref)
+    info = P.plan_info()
+    assert info["nvalid"] == int((pairs >= 0).sum()) and info["nslices"] == (npix + 63) // 64
+
+
+def test_pointing_errors(cm):
+    with pytest.raises(RuntimeError):
+        cm.I.SparseLO(10, 20, np.zeros(20, dtype=np.int32), pol=4)      # linearoperators.py:549
+    with pytest.raises(RuntimeError):
+        cm.I.SparseLO(10, 20, np.full(20, 10, dtype=np.int32))          # pixel id out of range
+    P = cm.I.SparseLO(10, 20, np.zeros(20, dtype=np.int32))
+    with pytest.raises(cm.I.lp.ShapeError):
+        P * np.ones(11)
+    # all samples flagged, empty pixels
+    P = cm.I.SparseLO(70, 20, np.full(20, -1, dtype=np.int32))
+    assert not (P * np.ones(70)).any() and not (P.T * np.ones(20)).any()
+
+
+def test_device_resident_vectors(cm, oracle):
+    """torch tensors in HBM go in and come out without a host round trip."""
+    nt, npix, pol = 5000, 64, 3
+    d, pairs, phi, t, diag = make_problem(oracle, 5, nt, npix, 1, pol)
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    P = cm.I.SparseLO(ces.get_new_pixel[0], nt, pairs, pol=pol, angle_processed=ces)
+    x = cm.torch.ones(P.shape[1], dtype=cm.torch.float64, device="cuda")
+    y = P.T * (P * x)
+    assert y.is_cuda and y.dtype == cm.torch.float64
+    np.testing.assert_array_equal(y.cpu().numpy(), P.T * (P * np.ones(P.shape[1])))
+
+
+# ------------------------------------------------------------------ a8 / a9 ------
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_block_operators_bitexact(cm, oracle, golden, pol):
+    d, pairs, phi, t, diag = make_problem(oracle, 21, 20000, 100, 4, pol)
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, 100, pol=pol, phi=phi)
+    pg = pairs.copy()
+    rg = cm.U.ProcessTimeSamples(pg, 100, pol=pol, phi=phi)
+    n = rg.get_new_pixel[0]
+    x = np.random.default_rng(1).standard_normal(pol * n)
+    M = cm.I.BlockDiagonalPreconditionerLO(rg, n, pol=pol)
+    B = cm.I.BlockDiagonalLO(rg, n, pol=pol)
+    np.testing.assert_array_equal(M * x, oracle.bd_precond_mult(pol, ro, x))
+    np.testing.assert_array_equal(B * x, oracle.bd_mult(pol, ro, x))
+    # golden vectors from the reference's own BlockDiagonalLO.mult
+    from types import SimpleNamespace
+    W = SimpleNamespace(counts=golden["bd_counts"], cosine=golden["bd_cos"], sine=golden["bd_sin"],
+                        cos2=golden["bd_cos2"], sin2=golden["bd_sin2"], sincos=golden["bd_sincos"])
+    Bg = cm.I.BlockDiagonalLO(W, 23, pol=pol)
+    np.testing.assert_array_equal(Bg * golden["bd_x%d" % pol], golden["bd_y%d" % pol])
+
+
+def test_bd_preconditioner_masks_singular_pixels(cm, oracle, golden):
+    from types import SimpleNamespace
+    W = SimpleNamespace(counts=golden["bdp1_counts"])
+    M = cm.I.BlockDiagonalPreconditionerLO(W, 23, pol=1)
+    np.testing.assert_array_equal(M * golden["bdp1_x"], golden["bdp1_y"])
+    z = np.zeros(4)
+    W3 = SimpleNamespace(counts=z + 5, cosine=z, sine=z, cos2=z + 1e-3, sin2=z + 1e-3, sincos=z)
+    M3 = cm.I.BlockDiagonalPreconditionerLO(W3, 4, pol=3)     # |det| = 5e-6 <= 1e-5 -> zero
+    assert not (M3 * np.ones(12)).any()
+
+
+# ------------------------------------------------------------------ a4 / a5 ------
+@pytest.mark.parametrize("lam", [1, 2, 33])
+def test_toeplitz_direct_bitexact_vs_reference(cm, golden, lam):
+    a, v = golden["toep_a%d" % lam], golden["toep_v"]
+    T = cm.I.ToeplitzLO(a, len(v), method=1)
+    np.testing.assert_array_equal(T * v, golden["toep_y%d" % lam])
+    assert T.symmetric and T.T is T
+
+
+def test_toeplitz_band_longer_than_block(cm, golden):
+    T = cm.I.ToeplitzLO(golden["toep_a9"], 5, method=1)
+    np.testing.assert_array_equal(T * golden["toep_vshort"], golden["toep_yshort"])
+
+
+@pytest.mark.parametrize("lam,sizes", [(2, [500, 400, 124]), (33, [1000, 50, 3000]),
+                                       (257, [5000, 7000]), (2048, [30000, 20000])])
+def test_toeplitz_fft_matches_direct(cm, oracle, lam, sizes):
+    rng = np.random.default_rng(lam)
+    nb = len(sizes)
+    k = np.arange(lam)
+    bands = [(1.0 + 0.3 * rng.random()) * np.exp(-k / (0.2 * lam + 1.0)) *
+             np.cos(0.5 * k / (lam + 1.0)) for _ in range(nb)]
+    v = rng.standard_normal(sum(sizes))
+    ref = oracle.blocklo_mult(sizes, bands, True, v)
+    Nd = cm.I.BlockLO(sizes, bands, offdiag=True, method=1)
+    Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=2)
+    np.testing.assert_array_equal(Nd * v, ref)
+    assert rel_l2(Nf * v, ref) < 1e-12
+    assert Nf.noise_info()["method"] == 2 and Nf.noise_info()["fft_len"] > 2 * (lam - 1)
+    # zero boundary: an impulse at a block edge must not leak into the neighbour block
+    e = np.zeros(sum(sizes))
+    e[sizes[0] - 1] = 1.0
+    out = Nf * e
+    assert np.abs(out[sizes[0]:]).max() < 1e-13
+
+
+def test_blocklo_diag_and_errors(cm, oracle):
+    sizes = 2 * [500, 400, 124]
+    t = list(np.random.default_rng(2).random(6))
+    N = cm.I.BlockLO(sizes, t)
+    assert not N.isoffdiag and N.shape == (sum(sizes), sum(sizes))
+    np.testing.assert_array_equal(N.diag, oracle.blocklo_diag(sizes, t))
+    v = np.random.default_rng(3).standard_normal(sum(sizes))
+    np.testing.assert_array_equal(N * v, oracle.blocklo_mult(sizes, t, False, v))
+    N2 = cm.I.BlockLO(100, t[:3])
+    np.testing.assert_array_equal(N2.diag, oracle.blocklo_diag(100, t[:3]))
+    assert len(N2.blocklist) == 3 and N2.blocklist[0].shape == (100, 100)
+    with pytest.raises(cm.I.lp.ShapeError):
+        N2 * np.ones(299)
+
+
+# ----------------------------------------------------- reference test invariants ---
+def test_PtP_ones_equals_counts(cm):
+    # tests/test_matrix_vector_product.py:9-23
+    np.random.seed(0)
+    nt, npix = 80, 50
+    pairs = cm.U.pairs_gen(nt, npix)
+    processd = cm.U.ProcessTimeSamples(pairs, npix)
+    npix = processd.get_new_pixel[0]
+    P = cm.I.SparseLO(npix, nt, pairs)
+    y = P.T * P * np.ones(npix)
+    assert np.allclose(y, processd.counts)
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_explicit_blockdiagonal_preconditioner(cm, pol):
+    # tests/test_matrix_vector_product.py:26-63 and :65-94
+    from scipy.linalg import inv
+    np.random.seed(1)
+    nt = 10000
+    phi = cm.U.angles_gen(2., nt)
+    for npix in [10, 50, 100, 300, 600]:
+        pairs = cm.U.pairs_gen(nt, npix)
+        processd = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+        npix = processd.get_new_pixel[0]
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=processd)
+        x = np.ones(npix * pol)
+        v = P.T * P * x
+        v2 = v * 0.
+        Mbd = cm.I.BlockDiagonalPreconditionerLO(processd, npix, pol=pol)
+        if pol == 1:
+            v2 = v / processd.counts
+        elif pol == 3:
+            for j in range(npix):
+                matr = np.array([[Mbd.counts[j], Mbd.cos[j], Mbd.sin[j]],
+                                 [Mbd.cos[j], Mbd.cos2[j], Mbd.sincos[j]],
+                                 [Mbd.sin[j], Mbd.sincos[j], Mbd.sin2[j]]])
+                v2[3 * j:3 * j + 3] = inv(matr).dot(v[3 * j:3 * j + 3])
+        else:
+            for j in range(npix):
+                matr = np.array([[Mbd.cos2[j], Mbd.sincos[j]], [Mbd.sincos[j], Mbd.sin2[j]]])
+                v2[2 * j:2 * j + 2] = inv(matr).dot(v[2 * j:2 * j + 2])
+        assert np.allclose(v2, Mbd * v)
+        xt = {1: np.ones(npix), 3: np.tile([0, 0, 1.], npix), 2: np.tile([0, 1.], npix)}[pol]
+        assert np.allclose(Mbd * P.T * P * xt, xt)
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_block_diagonal_operator_and_spd(cm, pol):
+    # tests/test_block_diagonal_operator.py:8-64
+    np.random.seed(2)
+    nt, npix = 2 ** 14, 128
+    d, pairs, phi, t, diag = cm.U.system_setup(nt, npix, 1)
+    processd = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    npix = processd.get_new_pixel[0]
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=processd)
+    x = np.ones(pol * npix)
+    Mbd = cm.I.BlockDiagonalPreconditionerLO(processd, npix, pol=pol)
+    invMbd = cm.I.BlockDiagonalLO(processd, npix, pol=pol)
+    assert np.allclose(invMbd * x, P.T * P * x)
+    assert np.allclose(Mbd * invMbd * x, x)
+    nb, blocksize = 6, 2 * [500, 400, 124]
+    nt = sum(blocksize)
+    d, pairs, phi, t, diag = cm.U.system_setup(nt, 64, nb)
+    N = cm.I.BlockLO(blocksize, diag, offdiag=False)
+    processd = cm.U.ProcessTimeSamples(pairs, 64, pol=pol, phi=phi, w=N.diag)
+    npix = processd.get_new_pixel[0]
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=processd)
+    r = np.random.rand(pol * npix)
+    A = P.T * N * P
+    assert np.allclose(A * r, A.T * r) and cm.U.scalprod(r, A * r) > 0.
+    Mbd = cm.I.BlockDiagonalPreconditionerLO(processd, npix, pol)
+    assert np.allclose(Mbd * r, Mbd.T * r) and cm.U.scalprod(r, Mbd * r) > 0.
+    # tests/test_toeplitz_vector_multiplication.py:58-76: BlockDiagonalLO == P^T N P, w = N.diag
+    PtNP = cm.I.BlockDiagonalLO(processd, npix, pol=pol)
+    assert np.allclose(PtNP * np.ones(pol * npix), P.T * N * P * np.ones(pol * npix))
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+@pytest.mark.parametrize("offdiag", [False, True])
+def test_composed_equals_stepwise(cm, oracle, pol, offdiag):
+    # tests/test_toeplitz_vector_multiplication.py:6-55; the composed product takes the
+    # fused kernel for diagonal N -- it must give the same bits as the three stages.
+    np.random.seed(3)
+    nb, blocksize = 6, 2 * [500, 400, 124]
+    nt = sum(blocksize)
+    d, pairs, phi, t, diag = cm.U.system_setup(nt, 64, nb)
+    N = cm.I.BlockLO(blocksize, t if offdiag else diag, offdiag=offdiag)
+    processd = cm.U.ProcessTimeSamples(pairs, 64, pol=pol, phi=phi,
+                                       w=None if offdiag else N.diag)
+    npix = processd.get_new_pixel[0]
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=processd)
+    x = np.random.rand(pol * npix)
+    z = P.T * (N * (P * x))
+    z2 = P.T * N * P * x
+    np.testing.assert_array_equal(z2, z)
+    c = processd.cos if pol > 1 else None
+    s = processd.sin if pol > 1 else None
+    zo = oracle.sparse_rmult(pol, npix, pairs, c, s, oracle.blocklo_mult(
+        blocksize, t if offdiag else diag, offdiag, oracle.sparse_mult(pol, pairs, c, s, x)))
+    np.testing.assert_array_equal(z, zo)
+
+
+# ------------------------------------------------------------- a15 BLAS helpers ---
+def test_blas_helpers(cm, golden):
+    G = golden
+    np.testing.assert_allclose(cm.U.dgemm(G["la_A"], G["la_B"]), G["la_dgemm"], rtol=1e-13)
+    assert cm.U.norm2(G["la_q"]) == pytest.approx(float(G["la_norm2"]), rel=1e-14)
+    assert cm.U.scalprod(G["la_q"], G["la_q2"]) == pytest.approx(float(G["la_scalprod"]), rel=1e-13,
+                                                                 abs=1e-14)
+    x = np.random.default_rng(0).standard_normal(1_000_003)
+    assert cm.U.norm2(x) == pytest.approx(np.linalg.norm(x), rel=1e-13)
+    assert cm.U.scalprod(x, x[::-1].copy()) == pytest.approx(float(x.dot(x[::-1])), rel=1e-10,
+                                                             abs=1e-9)
+
+
+def test_generators_match_reference_streams(cm, golden):
+    import random
+    G = golden
+    np.testing.assert_array_equal(cm.U.angles_gen(0.3, 50), G["gen_angles"])
+    np.random.seed(int(G["gen_seed"]))
+    random.seed(int(G["gen_seed"]))
+    d, pairs, phi, t, diag = cm.U.system_setup(120, 17, 3)
+    np.testing.assert_array_equal(d, G["gen_d"])
+    np.testing.assert_array_equal(pairs, G["gen_pairs"])
+    np.testing.assert_array_equal(phi, G["gen_phi"])
+    np.testing.assert_array_equal(np.asarray(t), G["gen_t"])
+    np.testing.assert_array_equal(np.asarray(diag), G["gen_diag"])
+
+
+# -------------------------------------------------------- a10 / a11 deflation ---
+def test_deflation_and_coarse_vs_reference(cm, golden, oracle):
+    G = golden
+    Z, A, v = G["defl_Z"], G["coarse_A"], G["coarse_v"]
+    Zd = cm.I.DeflationLO(Z)
+    np.testing.assert_array_equal(Zd * G["defl_y"], G["defl_Zy"])       # same term order
+    np.testing.assert_allclose(Zd.T * G["defl_x"], G["defl_Ztx"], rtol=1e-13)
+    np.testing.assert_allclose(Zd.H * G["defl_x"], G["defl_Ztx"], rtol=1e-13)
+    assert len(Zd.z) == 4 and np.array_equal(Zd.z[2], Z[:, 2])
+    Az = A @ Z
+    lu = cm.I.CoarseLO(Z, Az, 4, apply='LU')
+    np.testing.assert_allclose(lu.E, G["coarse_E"], rtol=1e-13)
+    np.testing.assert_allclose(lu * v, G["coarse_lu_x"], rtol=1e-11)
+    eig = cm.I.CoarseLO(Z, Az, 4, apply='eig')
+    np.testing.assert_allclose(eig.invE, G["coarse_invE"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(eig * v, G["coarse_eig_x"], rtol=1e-9)
+    vd = cm.torch.from_numpy(v).cuda()
+    np.testing.assert_allclose((lu * vd).cpu().numpy(), G["coarse_lu_x"], rtol=1e-10)
+    Zdup = Z.copy()
+    Zdup[:, 3] = Zdup[:, 0]
+    deg = cm.I.CoarseLO(Zdup, A @ Zdup, 4, apply='eig')
+    assert deg.n_discarded == 1
+    np.testing.assert_allclose(deg.invE, G["coarse_deg_invE"], rtol=1e-7, atol=1e-11)
+
+
+@pytest.mark.parametrize("r", [5, 16, 32, 64])
+def test_coarse_matrix_mfma_and_tall_skinny(cm, r):
+    rng = np.random.default_rng(r)
+    n = 3 * 40000 + 7
+    Z = rng.standard_normal((n, r))
+    AZ = rng.standard_normal((n, r))
+    E = cm.I.CoarseLO(Z, AZ, r, apply='eig').E
+    ref = Z.T @ AZ
+    assert rel_l2(E, ref) < 1e-13
+    Zd = cm.I.DeflationLO(Z)
+    x = rng.standard_normal(n)
+    y = rng.standard_normal(r)
+    assert rel_l2(Zd.T * x, Z.T @ x) < 1e-12
+    assert rel_l2(Zd * y, Z @ y) < 1e-13
+
+
+# ------------------------------------------------------------- a13 arnoldi -----
+def test_arnoldi_vs_reference(cm, golden):
+    G = golden
+    A, b = G["arn_A"], G["arn_b"]
+    Aop = cm.I.lp.LinearOperator(30, 30, lambda x: A @ x, symmetric=True)
+    vs, hs, j = cm.I.arnoldi(Aop, b, x0=np.zeros(30), tol=1e-8, inner_m=30)
+    assert j == int(G["arn_j"])
+    np.testing.assert_allclose(np.asarray(vs), G["arn_V"], rtol=0, atol=1e-9)
+    H = cm.I.build_hess(hs, j)
+    np.testing.assert_allclose(H, G["arn_H"], rtol=0, atol=1e-9)
+    Z, r = cm.I.build_Z(G["arn_ritz"], np.linalg.eigh(G["arn_H"])[1], G["arn_V"].T.copy(), 1e-2)
+    assert r == int(G["arn_r"])
+    np.testing.assert_allclose(Z, G["arn_Z"], rtol=1e-11, atol=1e-13)
+    Z2, _ = cm.I.build_Z(G["arn_ritz"], np.linalg.eigh(G["arn_H"])[1], list(G["arn_V"]), 1e-2)
+    np.testing.assert_allclose(Z2, G["arn_Z"], rtol=1e-11, atol=1e-13)
+    with pytest.raises(RuntimeError):
+        cm.I.arnoldi(Aop, b, x0=np.zeros(30), tol=1e-8, inner_m=3)
+    with pytest.raises(ValueError):
+        cm.I.arnoldi(Aop, b * np.nan, x0=np.zeros(30))
+    assert cm.I.arnoldi(Aop, A @ np.ones(30), x0=np.ones(30), tol=1e-5)[2] == 0
+    with pytest.raises(RuntimeError):
+        cm.I.build_Z(G["arn_ritz"], np.eye(j), G["arn_V"].T.copy(), 1e-9)
+
+
+# ---------------------------------------------------------------- a16 PCG -------
+def _mapmaking_system(cm, oracle, seed, nt, npix, nb, pol, offdiag):
+    np.random.seed(seed)
+    import random
+    random.seed(seed)
+    d, pairs, phi, t, diag = cm.U.system_setup(nt, npix, nb)
+    if offdiag:        # SPD banded inverse noise
+        t = [np.array([1.0 + 0.5 * ti[0], 0.3 * ti[1]]) for ti in t]
+    pairs = pairs.astype(np.int32)
+    po = pairs.copy()
+    N = cm.I.BlockLO(nt // nb, t if offdiag else diag, offdiag=offdiag)
+    w = None if offdiag else N.diag
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi, w=w)
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi, w=w)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    A = P.T * N * P
+    b = P.T * N * d
+    c, s = (ro.cos, ro.sin)
+    tt = t if offdiag else diag
+
+    def A_o(x):
+        return oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(
+            nt // nb, tt, offdiag, oracle.sparse_mult(pol, po, c, s, x)))
+    b_o = oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(nt // nb, tt, offdiag, d))
+    M_o = lambda x: oracle.bd_precond_mult(pol, ro, x)
+    return A, b, M, A_o, b_o, M_o, n
+
+
+@pytest.mark.parametrize("pol,offdiag", [(1, False), (3, False), (3, True), (2, True)])
+def test_pcg_matches_oracle_iterations_and_solution(cm, oracle, pol, offdiag):
+    A, b, M, A_o, b_o, M_o, n = _mapmaking_system(cm, oracle, 10 + pol, 40000, 300, 4, pol, offdiag)
+    np.testing.assert_array_equal(b, b_o)
+    its_g, its_o = [], []
+    xg, info_g = cm.cg(A, b, M=M, rtol=1e-6, callback=lambda x: its_g.append(1))
+    xo, info_o = oracle.cg(A_o, b_o, M=M_o, rtol=1e-6, callback=lambda x: its_o.append(1))
+    assert info_g == 0 and info_o == 0
+    assert len(its_g) == len(its_o)                   # identical PCG iteration counts
+    assert rel_l2(xg, xo) < 1e-6                      # north_star tolerance
+    import scipy.sparse.linalg as spla
+    its_s = []
+    xs, info_s = spla.cg(A, b, M=M, rtol=1e-6, callback=lambda x: its_s.append(1))
+    assert info_s == 0 and len(its_s) == len(its_g) and rel_l2(xs, xg) < 1e-8
+    # maxiter exhaustion and device-resident call
+    x1, info1 = cm.cg(A, b, M=M, rtol=1e-14, maxiter=2)
+    assert info1 == 2
+    bd = cm.torch.from_numpy(b).cuda()
+    xd, info_d = cm.cg(A, bd, M=M, tol=1e-6)
+    assert info_d == 0 and xd.is_cuda
+    np.testing.assert_array_equal(xd.cpu().numpy(), xg)
+    inv = cm.I.InverseLO(A, method=cm.cg, preconditioner=M)
+    assert rel_l2(inv * b, xo) < 1e-4 and inv.converged == 0
+
+
+# ------------------------------------------------------- a12 two-level precond ---
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_two_level_preconditioner_invariants(cm, pol):
+    # tests/test_2level_preconditioner.py:8-53 and tests/test_coarse_operator.py:6-43
+    import scipy.sparse.linalg as spla
+    import scipy.linalg as la
+    import random
+    np.random.seed(40 + pol)
+    random.seed(40 + pol)
+    nt, npix, nb = 500, 40, 1
+    d, pairs, phi, t, diag = cm.U.system_setup(nt, npix, nb)
+    t = [np.array([1.0 + 0.5 * ti[0], 0.3 * ti[1]]) for ti in t]
+    N = cm.I.BlockLO(nt // nb, t, offdiag=True)
+    processd = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    npix = processd.get_new_pixel[0]
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=processd)
+    M = cm.I.BlockDiagonalPreconditionerLO(processd, npix, pol=pol)
+    B = cm.I.BlockDiagonalLO(processd, npix, pol=pol)
+    x0 = np.ones(pol * npix)
+    tol = 1.e-4
+    A = P.T * N * P
+    eigv, Z = spla.eigsh(A, M=B, Minv=M, k=5, v0=x0, which='SM', ncv=15, tol=tol)
+    r = Z.shape[1]
+    Az = Z * 0.
+    for i in range(r):
+        Az[:, i] = A * Z[:, i]
+    E = cm.I.CoarseLO(Z, Az, r)
+    Zd = cm.I.DeflationLO(Z)
+    I = cm.I.lp.IdentityOperator(pol * npix)
+    R = I - A * Zd * E * Zd.T
+    M2 = M * R + Zd * E * Zd.T
+    AZd = cm.I.DeflationLO(Az)
+    M2f = cm.I.TwoLevelPreconditionerLO(M, Zd, AZd, E)
+    Eeig = cm.I.CoarseLO(Z, Az, r, apply='eig')
+    Emat = cm.U.dgemm(Z, Az.T)
+    v = np.ones(r)
+    assert np.allclose(np.dot(Emat, Eeig * v), v) and np.allclose(la.solve(Emat, v), Eeig * v)
+    assert abs(np.linalg.cond(Eeig.to_array())) < 1e3 * np.linalg.cond(Emat) + 1
+    for i in range(r):
+        assert np.allclose(M2 * A * Z[:, i], Z[:, i])
+        assert np.allclose(M2f * (A * Z[:, i]), Z[:, i])
+        assert cm.U.norm2(R * A * Z[:, i]) <= 1.e-10
+        its = []
+        x, info = spla.cg(M2 * A, Z[:, i], rtol=tol, maxiter=2, callback=lambda xk: its.append(1))
+        assert info == 0
+        assert len(its) == 1                          # tests/test_arnoldi_algorithm.py:91-93
+    rr = np.random.rand(pol * npix)
+    assert rel_l2(M2f * rr, M2 * rr) < 1e-10
+    # the deflated preconditioner must not need more PCG steps than M_BD alone
+    b = P.T * N * d
+    n1, n2 = [], []
+    x1, i1 = cm.cg(A, b, M=M, tol=1e-8, callback=lambda xk: n1.append(1))
+    x2, i2 = cm.cg(A, b, M=M2f, tol=1e-8, callback=lambda xk: n2.append(1))
+    assert i1 == 0 and i2 == 0 and len(n2) <= len(n1)
+    assert rel_l2(x2, x1) < 1e-6
