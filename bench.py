@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
     ap.add_argument("--fft-len", type=int, default=0)
+    ap.add_argument("--toeplitz", default="fused", choices=["fused", "rocfft"],
+                    help="overlap-save implementation for the Toeplitz configs")
     args = ap.parse_args()
     if args.fft_len:
         os.environ["CM2_FFT_LEN"] = str(args.fft_len)
@@ -109,7 +111,8 @@ def main():
     d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
     if lam:
         bands = [toeplitz_band(lam, rng) for _ in range(nb)]
-        N = BlockLO(bsize, bands, offdiag=True, method=2)
+        N = BlockLO(bsize, bands, offdiag=True, method=(3 if args.toeplitz == "fused" else 2))
+        nlabel = "N^-1 (k_overlap_save, LDS FFT)" if args.toeplitz == "fused" else "N^-1 (overlap-save rocFFT)"
         w = None
     else:
         N = BlockLO(bsize, list(rng.random(nb) + 0.5), offdiag=False)
@@ -169,11 +172,40 @@ def main():
     stages = {}
     map_bytes = 48.0 * npix_c
     if lam:
+        from cosmomap2_amd.interfaces import linearoperators as L
         tod = P * x
         tod2 = N * tod
-        stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2)
-        stages["N^-1 (overlap-save rocFFT)"] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
-        stages["P^T (k_Pt_sell)"] = (ev_time(lambda: P.T * tod2, reps), 28.0 * nt + map_bytes / 2)
+        if L._use_tiles(P):
+            T = L._sparse_tiles(P)
+            st = D.stream
+            d_tb = D.empty(T.nvalid)
+            out = D.empty(n)
+            call = _hip.call
+            stages["P tiles (k_P_tiles)"] = (ev_time(lambda: call(
+                "cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()), reps),
+                28.0 * nt + map_bytes / 2)
+            if args.toeplitz == "fused":
+                v_tb = D.empty(T.nvalid)
+                stages["N^-1 on tile order (k_overlap_save, LDS FFT)"] = (ev_time(lambda: call(
+                    "cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st()),
+                    reps), 16.0 * nt)
+                del v_tb
+            else:
+                stages["tiles->time (k_tiles_to_time)"] = (ev_time(lambda: call(
+                    "cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st()), reps), 16.0 * nt)
+                stages[nlabel] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
+                stages["time->tiles (k_time_to_tiles)"] = (ev_time(lambda: call(
+                    "cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st()), reps),
+                    16.0 * nt)
+            stages["P^T tiles (k_Pt_tiles)"] = (ev_time(lambda: call(
+                "cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st()), reps),
+                28.0 * nt + map_bytes / 2)
+            del d_tb, out
+        else:
+            stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2)
+            stages[nlabel] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
+            stages["P^T (k_Pt_sell)"] = (ev_time(lambda: P.T * tod2, reps),
+                                         28.0 * nt + map_bytes / 2)
         step_bytes = 72.0 * nt + map_bytes
         del tod, tod2
     else:

@@ -28,11 +28,19 @@ PROTOTYPES = {
     "cm2_Pt_apply": [_vp, _vp, _vp, _vp],
     "cm2_pointing_set_weights": [_vp, _vp, _vp],
     "cm2_PtNP_diag_apply": [_vp, _vp, _vp, _vp],
+    "cm2_tiles_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _vp],
+    "cm2_tiles_destroy": [_vp],
+    "cm2_tiles_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
+    "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],
+    "cm2_tod_time_to_tiles": [_vp, _vp, _vp, _vp],
+    "cm2_tod_tiles_to_time": [_vp, _vp, _vp, _vp],
     "cm2_noise_create_diag": [ctypes.POINTER(_vp), ctypes.POINTER(_dbl), ctypes.POINTER(_i64), _i64],
     "cm2_noise_create_toeplitz": [ctypes.POINTER(_vp), ctypes.POINTER(_dbl), _i64,
                                   ctypes.POINTER(_i64), _i64, _int, _vp],
     "cm2_noise_destroy": [_vp],
     "cm2_noise_apply": [_vp, _vp, _vp, _vp],
+    "cm2_noise_apply_tiles": [_vp, _vp, _vp, _vp, _vp],
     "cm2_noise_expand_diag": [_vp, _vp, _vp],
     "cm2_noise_info": [_vp, ctypes.POINTER(_i64)],
     "cm2_weights_accumulate": [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,23 @@
+// cm2_fft.h -- fused overlap-save Toeplitz application (LDS-resident fp64 FFT), see cm2_fft.hip
+#pragma once
+#include "cm2_common.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace cm2 {
+
+struct FusedOS;
+
+bool fused_os_supported(int64_t lambda);
+// d_bands: [nblocks][lambda] on the device; off: nblocks+1 block offsets (host)
+int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
+                    const std::vector<int64_t> &off, hipStream_t stream);
+int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream);
+// same, with input and output TODs addressed through d_idx[t] (tile-bucketed order)
+int fused_os_apply_indexed(const FusedOS *f, const uint32_t *d_idx, const double *d_v,
+                           double *d_out, hipStream_t stream);
+int64_t fused_os_length(const FusedOS *f);
+void fused_os_destroy(FusedOS *f);
+
+}  // namespace cm2

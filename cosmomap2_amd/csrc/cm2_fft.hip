@@ -1,0 +1,430 @@
+// cm2_fft.hip -- banded-Toeplitz N^-1 by overlap-save with a hand-written fp64 FFT that
+// lives entirely in LDS: one kernel reads the TOD once and writes the filtered TOD once.
+//
+// Reference semantics: ToeplitzLO.mult, interfaces/linearoperators.py:582-595 (symmetric
+// band, ZERO boundary at both ends of every block), dispatched per block as
+// interfaces/blkop.py:195-206.
+//
+// Algorithm per workgroup (512 threads, one CU):
+//   * two overlap-save segments A, B of the same noise block (each: hop = N - 2*halo new
+//     samples + halo = lambda-1 samples on both sides, zero outside the block) are packed
+//     as ONE complex signal z = A + iB of length N;
+//   * forward complex FFT of length N = R1*R2*R3 (decimation in frequency, three in-place
+//     radix passes through LDS, output in digit-reversed order);
+//   * pointwise product with the band's spectrum H.  H is real and even (the band is
+//     symmetric), so  ifft(H fft(A + iB)) = h*A + i h*B : no untangling is needed, and H is
+//     stored pre-permuted in the digit-reversed order and with 1/N folded in;
+//   * inverse FFT (the same three passes backwards, conjugate twiddles);
+//   * the hop samples of A (real part) and B (imaginary part) are written out.
+//
+// LDS: 2 * (N + N/32) doubles (re / im planes, one pad double every 32 to keep the
+// stride-R3 accesses of the last pass conflict-free) = 135 KB for N = 8192.
+// HBM traffic per output sample: N/hop * 8 B read + 8 B write (2 + 1 doubles at
+// lambda = 2048, N = 8192) against the 16 B algorithmic figure; the rocFFT route
+// (pack, 2 x [FFT + real pre/post kernel], spectrum multiply, unpack) moves ~7x that.
+// This translation unit is compiled with FMA contraction ON (results are compared with
+// the direct sum at 1e-12, not bit for bit).
+#include "cm2_fft.h"
+
+using namespace cm2;
+
+namespace {
+
+constexpr double kCos32[32] = {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828, 0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304};
+constexpr double kSin32[32] = {0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304, 1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828};
+
+constexpr int kThreads = 512;
+
+__host__ __device__ constexpr int ilog2(int r) { return r <= 1 ? 0 : 1 + ilog2(r >> 1); }
+
+template <int R>
+__host__ __device__ constexpr int brev(int m)
+{
+    int out = 0;
+    for (int b = 0; b < ilog2(R); ++b) out |= ((m >> b) & 1) << (ilog2(R) - 1 - b);
+    return out;
+}
+
+__device__ __forceinline__ int padi(int a) { return a + (a >> 5); }
+
+// In-register forward DFT of size R (radix-2 decimation in frequency):
+//   X[m] = sum_l x[l] exp(-2 pi i l m / R)  ends up at position brev<R>(m).
+template <int R>
+__device__ __forceinline__ void dft_regs(double (&re)[R], double (&im)[R])
+{
+#pragma unroll
+    for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const int a = blk + i, b = a + h;
+                const int tw = i * (32 / (2 * h));          // exponent in units of 2 pi / 32
+                const double ar = re[a], ai = im[a], br = re[b], bi = im[b];
+                re[a] = ar + br;
+                im[a] = ai + bi;
+                const double dr = ar - br, di = ai - bi;
+                if (tw == 0) {
+                    re[b] = dr;
+                    im[b] = di;
+                } else if (tw == 8) {                        // times -i
+                    re[b] = di;
+                    im[b] = -dr;
+                } else {                                     // times (c - i s)
+                    const double c = kCos32[tw], s = kSin32[tw];
+                    re[b] = dr * c + di * s;
+                    im[b] = di * c - dr * s;
+                }
+            }
+        }
+    }
+}
+
+// One in-place radix-R pass over the N-point signal held in LDS.
+//   forward: butterfly, then twiddle w_n^{j m};  inverse: conj twiddle (and optional real
+//   scale h[a]), then inverse butterfly.   n = current sub-transform length, s = n / R.
+template <int R, int N, bool INVERSE, bool TWIDDLE, bool SCALE>
+__device__ __forceinline__ void radix_pass(double *__restrict__ pre, double *__restrict__ pim,
+                                           int n, const double2 *__restrict__ W,
+                                           const double *__restrict__ hperm)
+{
+    const int s = n / R;
+    for (int beta = threadIdx.x; beta < N / R; beta += kThreads) {
+        const int g = beta / s, j = beta - g * s;
+        const int base = g * n + j;
+        double xr[R], xi[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int a = base + m * s;
+            xr[m] = pre[padi(a)];
+            xi[m] = pim[padi(a)];
+            if (SCALE) {
+                const double h = hperm[a];
+                xr[m] *= h;
+                xi[m] *= h;
+            }
+        }
+        // twiddles w^m, w = exp(-2 pi i (N/n) j / N): one table load, powers by
+        // squaring / one multiplication (depth <= 2 log2 R, error a few ulp)
+        double wr[R], wi[R];
+        if (TWIDDLE) {
+            const double2 w1 = W[((N / n) * j) & (N - 1)];
+            wr[1] = w1.x;
+            wi[1] = w1.y;
+#pragma unroll
+            for (int m = 2; m < R; ++m) {
+                if ((m & 1) == 0) {
+                    const double a = wr[m / 2], b = wi[m / 2];
+                    wr[m] = a * a - b * b;
+                    wi[m] = 2.0 * a * b;
+                } else {
+                    wr[m] = wr[m - 1] * w1.x - wi[m - 1] * w1.y;
+                    wi[m] = wr[m - 1] * w1.y + wi[m - 1] * w1.x;
+                }
+            }
+        }
+        if (!INVERSE) {
+            dft_regs<R>(xr, xi);
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                double yr = xr[brev<R>(m)], yi = xi[brev<R>(m)];
+                if (TWIDDLE && m > 0) {
+                    const double tr = yr * wr[m] - yi * wi[m];
+                    yi = yr * wi[m] + yi * wr[m];
+                    yr = tr;
+                }
+                const int a = base + m * s;
+                pre[padi(a)] = yr;
+                pim[padi(a)] = yi;
+            }
+        } else {
+            if (TWIDDLE) {
+#pragma unroll
+                for (int m = 1; m < R; ++m) {
+                    const double tr = xr[m] * wr[m] + xi[m] * wi[m];      // times conj(w^m)
+                    xi[m] = xi[m] * wr[m] - xr[m] * wi[m];
+                    xr[m] = tr;
+                }
+            }
+            // inverse DFT = swap(DFT(swap(x))): run the forward network on (im, re)
+            dft_regs<R>(xi, xr);
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int a = base + m * s;
+                pre[padi(a)] = xr[brev<R>(m)];
+                pim[padi(a)] = xi[brev<R>(m)];
+            }
+        }
+    }
+}
+
+// The innermost pass (sub-transforms of length R, contiguous in LDS) of the forward FFT,
+// the spectrum product and the first pass of the inverse FFT, all in registers: one LDS
+// round trip instead of two.  hperm is in the digit-reversed (address) order.
+template <int R, int N>
+__device__ __forceinline__ void middle_pass(double *__restrict__ pre, double *__restrict__ pim,
+                                            const double *__restrict__ hperm)
+{
+    for (int beta = threadIdx.x; beta < N / R; beta += kThreads) {
+        const int base = beta * R;
+        double xr[R], xi[R], yr[R], yi[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            xr[m] = pre[padi(base + m)];
+            xi[m] = pim[padi(base + m)];
+        }
+        dft_regs<R>(xr, xi);                       // X[k] sits at position brev(k)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double h = hperm[base + k];
+            yr[k] = xr[brev<R>(k)] * h;
+            yi[k] = xi[brev<R>(k)] * h;
+        }
+        dft_regs<R>(yi, yr);                       // inverse = swap . forward . swap
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            pre[padi(base + m)] = yr[brev<R>(m)];
+            pim[padi(base + m)] = yi[brev<R>(m)];
+        }
+    }
+}
+
+struct PairDesc {          // one workgroup's work: two segments of one noise block
+    int64_t a_start, a_len, b_start, b_len, lo, hi;
+    int32_t blk, pad;
+};
+
+// INDIRECT: input and output TODs are in the tile-bucketed order of cm2_tiles.hip and are
+// reached through idx[t] (position of time sample t, 0xFFFFFFFF = flagged -> reads 0, not
+// written).  Because that order is a stable partition, a segment's samples form one short
+// sequential run per pixel tile; consecutive segments are mapped to the SAME XCD (blockIdx
+// is dealt round-robin over the 8 XCDs) so that the cache lines shared by neighbouring
+// segments -- run ends and the 2*halo overlap -- are served / merged by one L2.
+template <int R1, int R2, int R3, bool INDIRECT>
+__global__ __launch_bounds__(kThreads) void k_overlap_save(
+    const PairDesc *__restrict__ pairs, int npairs, int halo, const double2 *__restrict__ W,
+    const double *__restrict__ Hperm, const uint32_t *__restrict__ idx,
+    const double *__restrict__ v, double *__restrict__ out)
+{
+    constexpr int N = R1 * R2 * R3;
+    extern __shared__ double lds[];
+    double *pre = lds;
+    double *pim = lds + (N + N / 32);
+    const int per_xcd = (npairs + 7) / 8;
+    const int pair_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pair_id >= npairs) return;
+    const PairDesc pd = pairs[pair_id];
+    const double *hperm = Hperm + (int64_t)pd.blk * N;
+
+    // all of this thread's loads are issued before the first LDS write (one HBM round trip)
+    constexpr int PER = N / kThreads;
+    double va[PER], vb[PER];
+    if (INDIRECT) {
+        uint32_t ka[PER], kb[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * kThreads;
+            const int64_t ta = pd.a_start - halo + j;
+            const int64_t tb = pd.b_start - halo + j;
+            ka[u] = (ta >= pd.lo && ta < pd.hi) ? idx[ta] : kInvalidSample;
+            kb[u] = (pd.b_len > 0 && tb >= pd.lo && tb < pd.hi) ? idx[tb] : kInvalidSample;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            va[u] = (ka[u] != kInvalidSample) ? v[ka[u]] : 0.0;
+            vb[u] = (kb[u] != kInvalidSample) ? v[kb[u]] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * kThreads;
+            const int64_t ta = pd.a_start - halo + j;
+            const int64_t tb = pd.b_start - halo + j;
+            va[u] = (ta >= pd.lo && ta < pd.hi) ? v[ta] : 0.0;
+            vb[u] = (pd.b_len > 0 && tb >= pd.lo && tb < pd.hi) ? v[tb] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int j = threadIdx.x + u * kThreads;
+        pre[padi(j)] = va[u];
+        pim[padi(j)] = vb[u];
+    }
+    __syncthreads();
+    radix_pass<R1, N, false, true, false>(pre, pim, N, W, nullptr);
+    __syncthreads();
+    radix_pass<R2, N, false, true, false>(pre, pim, N / R1, W, nullptr);
+    __syncthreads();
+    middle_pass<R3, N>(pre, pim, hperm);
+    __syncthreads();
+    radix_pass<R2, N, true, true, false>(pre, pim, N / R1, W, nullptr);
+    __syncthreads();
+    radix_pass<R1, N, true, true, false>(pre, pim, N, W, nullptr);
+    __syncthreads();
+    if (INDIRECT) {
+        for (int j = threadIdx.x; j < pd.a_len; j += kThreads) {
+            const uint32_t k = idx[pd.a_start + j];
+            if (k != kInvalidSample) out[k] = pre[padi(halo + j)];
+        }
+        for (int j = threadIdx.x; j < pd.b_len; j += kThreads) {
+            const uint32_t k = idx[pd.b_start + j];
+            if (k != kInvalidSample) out[k] = pim[padi(halo + j)];
+        }
+    } else {
+        for (int j = threadIdx.x; j < pd.a_len; j += kThreads)
+            out[pd.a_start + j] = pre[padi(halo + j)];
+        for (int j = threadIdx.x; j < pd.b_len; j += kThreads)
+            out[pd.b_start + j] = pim[padi(halo + j)];
+    }
+}
+
+// W[t] = exp(-2 pi i t / N)
+__global__ void k_twiddles(int N, double2 *__restrict__ W)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N) W[t] = make_double2(cospi(2.0 * t / N), -sinpi(2.0 * t / N));
+}
+
+// Hperm[b][a] = H_b(k(a)) / N with a = d1*(R2*R3) + d2*R3 + d3  <->  k = d1 + R1*d2 + R1*R2*d3
+// and H_b(k) = a0 + 2 sum_{j>=1} a_j cos(2 pi j k / N)   (real, even: symmetric band)
+__global__ __launch_bounds__(256) void k_spectrum_perm(int nb, int64_t lambda, int N, int R1,
+                                                        int R2, int R3,
+                                                        const double *__restrict__ bands,
+                                                        double *__restrict__ Hperm)
+{
+    const int64_t total = (int64_t)nb * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N;
+        const int a = (int)(e - b * N);
+        const int d1 = a / (R2 * R3), d2 = (a / R3) % R2, d3 = a % R3;
+        const int64_t k = d1 + (int64_t)R1 * d2 + (int64_t)R1 * R2 * d3;
+        const double *band = bands + b * lambda;
+        double acc = 0.0;
+        for (int64_t j = lambda - 1; j >= 1; --j) {
+            const int64_t m = (j * k) % N;
+            acc += band[j] * cospi(2.0 * (double)m / (double)N);
+        }
+        Hperm[e] = (band[0] + 2.0 * acc) / (double)N;
+    }
+}
+
+}  // namespace
+
+namespace cm2 {
+
+struct FusedOS {
+    int N = 0, R1 = 0, R2 = 0, R3 = 0, halo = 0;
+    int64_t hop = 0, npairs = 0;
+    PairDesc *d_pairs = nullptr;
+    double2 *d_W = nullptr;
+    double *d_Hperm = nullptr;
+    size_t lds_bytes = 0;
+};
+
+void fused_os_destroy(FusedOS *f)
+{
+    if (!f) return;
+    if (f->d_pairs) (void)hipFree(f->d_pairs);
+    if (f->d_W) (void)hipFree(f->d_W);
+    if (f->d_Hperm) (void)hipFree(f->d_Hperm);
+    delete f;
+}
+
+bool fused_os_supported(int64_t lambda) { return lambda >= 1 && lambda - 1 <= 2048; }
+
+int64_t fused_os_length(const FusedOS *f) { return f ? f->N : 0; }
+
+template <int R1, int R2, int R3, bool INDIRECT>
+static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
+                  hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save<R1, R2, R3, INDIRECT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)f->lds_bytes));
+        attr_set = true;
+    }
+    const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
+    k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
+        f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx, d_v, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+template <bool INDIRECT>
+static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
+                    hipStream_t stream)
+{
+    if (f->npairs == 0) return 0;
+    if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
+    if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
+    return launch<16, 16, 2, INDIRECT>(f, d_idx, d_v, d_out, stream);
+}
+
+int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
+{
+    return dispatch<false>(f, nullptr, d_v, d_out, stream);
+}
+
+int fused_os_apply_indexed(const FusedOS *f, const uint32_t *d_idx, const double *d_v,
+                           double *d_out, hipStream_t stream)
+{
+    return dispatch<true>(f, d_idx, d_v, d_out, stream);
+}
+
+int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
+                    const std::vector<int64_t> &off, hipStream_t stream)
+{
+    *out = nullptr;
+    CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
+              (long long)lambda);
+    FusedOS *f = new FusedOS();
+    f->halo = (int)(lambda - 1);
+    int64_t forced = 0;
+    if (const char *e = getenv("CM2_FUSED_FFT_LEN")) forced = atoll(e);
+    if (forced == 512 || forced == 2048 || forced == 8192) {
+        CM2_CHECK(forced > 2 * f->halo, "CM2_FUSED_FFT_LEN=%lld too short for lambda=%lld",
+                  (long long)forced, (long long)lambda);
+        f->N = (int)forced;
+    } else {
+        f->N = f->halo <= 128 ? 512 : (f->halo <= 512 ? 2048 : 8192);
+    }
+    f->R1 = 16; f->R2 = 16; f->R3 = f->N / 256;
+    f->hop = f->N - 2 * (int64_t)f->halo;
+    f->lds_bytes = sizeof(double) * 2 * (size_t)(f->N + f->N / 32);
+    const int64_t nb = (int64_t)off.size() - 1;
+    std::vector<PairDesc> pairs;
+    for (int64_t b = 0; b < nb; ++b) {
+        for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += 2 * f->hop) {
+            PairDesc pd;
+            pd.lo = off[b]; pd.hi = off[b + 1]; pd.blk = (int32_t)b; pd.pad = 0;
+            pd.a_start = s0;
+            pd.a_len = (off[b + 1] - s0 < f->hop) ? off[b + 1] - s0 : f->hop;
+            pd.b_start = s0 + f->hop;
+            pd.b_len = pd.b_start < off[b + 1]
+                           ? ((off[b + 1] - pd.b_start < f->hop) ? off[b + 1] - pd.b_start : f->hop)
+                           : 0;
+            if (pd.b_len == 0) pd.b_start = s0;
+            pairs.push_back(pd);
+        }
+    }
+    f->npairs = (int64_t)pairs.size();
+    CM2_HIP(hipMalloc(&f->d_pairs, sizeof(PairDesc) * (pairs.size() ? pairs.size() : 1)));
+    if (!pairs.empty())
+        CM2_HIP(hipMemcpy(f->d_pairs, pairs.data(), sizeof(PairDesc) * pairs.size(),
+                          hipMemcpyHostToDevice));
+    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * f->N));
+    CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * nb * f->N));
+    k_twiddles<<<(f->N + 255) / 256, 256, 0, stream>>>(f->N, f->d_W);
+    CM2_LAUNCH_OK();
+    k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, f->R1,
+                                                               f->R2, f->R3, d_bands, f->d_Hperm);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
+    *out = f;
+    return 0;
+}
+
+}  // namespace cm2

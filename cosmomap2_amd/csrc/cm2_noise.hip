@@ -19,7 +19,7 @@
 //             and is evaluated in closed form H_k = (a0 + 2 sum_j a_j cos(2 pi j k/L))/L.
 // Algorithmic traffic 16 B/sample (read v, write y); the rocFFT route moves
 // ~7x that through HBM (pack, 2 FFTs, spectrum multiply, unpack) -- see DESIGN.md.
-#include "cm2_common.h"
+#include "cm2_fft.h"
 
 #include <rocfft/rocfft.h>
 
@@ -46,6 +46,7 @@ struct cm2_noise {
     rocfft_execution_info info = nullptr;
     void *d_fftwork = nullptr;
     size_t fftwork_bytes = 0;
+    cm2::FusedOS *fused = nullptr;   // method CM2_TOEPLITZ_FUSED
 };
 
 #define CM2_FFT(call)                                                                  \
@@ -197,6 +198,7 @@ static int noise_common(cm2_noise *n, const int64_t *h_sizes, int64_t nb,
 extern "C" int cm2_noise_destroy(cm2_noise *n)
 {
     if (!n) return 0;
+    if (n->fused) cm2::fused_os_destroy(n->fused);
     if (n->fwd) rocfft_plan_destroy(n->fwd);
     if (n->inv) rocfft_plan_destroy(n->inv);
     if (n->info) rocfft_execution_info_destroy(n->info);
@@ -244,14 +246,17 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
 {
     CM2_CHECK(out && h_bands && h_sizes, "cm2_noise_create_toeplitz: NULL argument");
     CM2_CHECK(lambda >= 1, "cm2_noise_create_toeplitz: band length lambda=%lld < 1", (long long)lambda);
-    CM2_CHECK(method >= 0 && method <= 2, "cm2_noise_create_toeplitz: bad method %d", method);
+    CM2_CHECK(method >= 0 && method <= 3, "cm2_noise_create_toeplitz: bad method %d", method);
     *out = nullptr;
     hipStream_t stream = as_stream(stream_);
     cm2_noise *n = new cm2_noise();
     std::vector<int64_t> off;
     if (int rc = noise_common(n, h_sizes, nblocks, off)) { cm2_noise_destroy(n); return rc; }
     n->lambda = lambda;
-    if (method == CM2_TOEPLITZ_AUTO) method = (lambda <= 32) ? CM2_TOEPLITZ_DIRECT : CM2_TOEPLITZ_FFT;
+    if (method == CM2_TOEPLITZ_AUTO)
+        method = (lambda <= 32) ? CM2_TOEPLITZ_DIRECT
+                                : (cm2::fused_os_supported(lambda) ? CM2_TOEPLITZ_FUSED
+                                                                   : CM2_TOEPLITZ_FFT);
     n->method = method;
     CM2_HIP(hipMalloc(&n->d_t, sizeof(double) * nblocks * lambda));
     CM2_HIP(hipMemcpy(n->d_t, h_bands, sizeof(double) * nblocks * lambda, hipMemcpyHostToDevice));
@@ -259,7 +264,18 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
         *out = n;
         return 0;
     }
-    // ---- overlap-save plan ----
+    if (method == CM2_TOEPLITZ_FUSED) {
+        if (int rc = cm2::fused_os_create(&n->fused, n->d_t, lambda, off, stream)) {
+            cm2_noise_destroy(n);
+            return rc;
+        }
+        n->L = cm2::fused_os_length(n->fused);
+        n->halo = lambda - 1;
+        n->hop = n->L - 2 * n->halo;
+        *out = n;
+        return 0;
+    }
+    // ---- overlap-save plan (rocFFT) ----
     int64_t max_block = 0;
     for (int64_t b = 0; b < nblocks; ++b) max_block = h_sizes[b] > max_block ? h_sizes[b] : max_block;
     n->halo = lambda - 1;
@@ -353,6 +369,7 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
         CM2_LAUNCH_OK();
         return 0;
     }
+    if (n->method == CM2_TOEPLITZ_FUSED) return cm2::fused_os_apply(n->fused, d_v, d_out, stream);
     // overlap-save: pack -> R2C -> spectrum multiply -> C2R -> unpack
     const int gx_L = (int)((n->L + kBlock * 4 - 1) / (kBlock * 4));
     const int64_t per_launch = 65535;             // gridDim.y limit
@@ -382,4 +399,24 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
         CM2_LAUNCH_OK();
     }
     return 0;
+}
+
+// N^-1 applied to a TOD held in the tile-bucketed order of cm2_tiles (input and output):
+// the overlap-save kernel gathers its segment through the tile index and scatters the
+// result back the same way, so no time-ordered copy of the TOD is ever written.
+struct cm2_tiles;
+extern "C" const uint32_t *cm2_tiles_index(const cm2_tiles *t);
+extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t);
+
+extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
+                                     double *d_out_tb, void *stream_)
+{
+    CM2_CHECK(n && tiles && d_in_tb && d_out_tb, "cm2_noise_apply_tiles: NULL argument");
+    CM2_CHECK(d_in_tb != d_out_tb, "cm2_noise_apply_tiles: in-place application is not supported");
+    CM2_CHECK(n->method == CM2_TOEPLITZ_FUSED && n->fused,
+              "cm2_noise_apply_tiles needs a Toeplitz operator built with CM2_TOEPLITZ_FUSED");
+    CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
+              (long long)n->nt, (long long)cm2_tiles_nt(tiles));
+    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), d_in_tb, d_out_tb,
+                                       as_stream(stream_));
 }

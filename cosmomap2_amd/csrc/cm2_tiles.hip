@@ -1,0 +1,384 @@
+// cm2_tiles.hip -- tile-bucketed ("TB") TOD order and the LDS-staged pointing kernels
+// that work on it.  This is the throughput path of the P^T N^-1 P chain when N has
+// off-diagonal terms (so that a time-ordered TOD must exist between P and P^T).
+//
+// Why: with uniformly random pointing a time-ordered gather P x touches a random 24-B
+// map record per sample and a pixel-major P^T touches a random 8-B TOD entry per sample;
+// both pay a whole cache line for a few useful bytes (measured 2.0 ms each at 1e8
+// samples / nside 256, i.e. 1.4 TB/s algorithmic).  Bucketing the samples by pixel TILE
+// (TP pixels, tile map slice = TP*pol*8 B staged in LDS) makes every HBM access of the
+// two pointing kernels a coalesced stream:
+//
+//   TB order   = stable partition of the valid samples by tile (time order inside a tile)
+//   pl_tb u16  = pixel index inside the tile,  cos_tb / sin_tb f64     (static, built once)
+//   tb_dst u32 = position of time sample t in TB order (0xFFFFFFFF for flagged samples)
+//
+//   P    : stage the tile of x in LDS, stream the bucket, write d_tb      26 B read + 8 B write
+//   P^T  : stream the bucket, ds_add_f64 into the LDS tile, flush tile    26+8 B read
+//   time<->TB permutation: time-order-driven; because the partition is stable every tile
+//          is a sequential stream, so the scattered 8-B accesses combine in L2
+//          (each workgroup owns one contiguous time range).                20 B / sample
+//
+// P on TB order is bit-identical to the reference loop (same per-sample expression).
+// P^T sums with LDS atomics: the set of terms per pixel is the reference's, their order is
+// not fixed, so it agrees with the serial loop to rounding (~1e-16 relative) and is not
+// bitwise reproducible; cm2_Pt_apply (pixel-major, cm2_pointing.hip) is the exact form.
+//
+// Reference loops replaced: interfaces/linearoperators.py:483-489 (mult_iqu) and :509-516
+// (rmult_iqu) and their I / QU variants.
+#include "cm2_pixindex.h"
+
+#include <hipcub/hipcub.hpp>
+#include <vector>
+
+using namespace cm2;
+
+struct cm2_tiles {
+    int64_t nt = 0, npix = 0, nvalid = 0;
+    int pol = 0;
+    int tp = 0;                  // pixels per tile
+    int64_t ntiles = 0, nitems = 0;
+    uint32_t *d_tb_dst = nullptr;   // [nt]
+    uint16_t *d_pl = nullptr;       // [nvalid]
+    double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]
+    int32_t *d_item_tile = nullptr; // [nitems]
+    int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
+    int64_t *d_item_k1 = nullptr;
+};
+
+// ------------------------------------------------------------------ build -------
+__global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ pix, int64_t nt,
+                                                    int tp, uint32_t ntiles,
+                                                    uint32_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const int32_t p = pix[i];
+        keys[i] = p < 0 ? ntiles : (uint32_t)(p / tp);
+        vals[i] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict__ keys, int64_t nt,
+                                                      int64_t ntiles, int64_t *__restrict__ off)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > ntiles) return;
+    int64_t lo = 0, hi = nt;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)b) lo = mid + 1; else hi = mid;
+    }
+    off[b] = lo;
+}
+
+template <int POL>
+__global__ __launch_bounds__(256) void k_tile_fill(
+    int64_t nt, int64_t nvalid, int tp, const uint32_t *__restrict__ tb_src,
+    const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
+    uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb,
+    double *__restrict__ stb)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nt; k += stride) {
+        const uint32_t t = tb_src[k];
+        if (k < nvalid) {
+            tb_dst[t] = (uint32_t)k;
+            pl[k] = (uint16_t)(pix[t] % tp);
+            if (POL > 1) {
+                ctb[k] = c[t];
+                stb[k] = s[t];
+            }
+        } else {
+            tb_dst[t] = kInvalidSample;      // flagged samples sort behind every tile
+        }
+    }
+}
+
+// ------------------------------------------------------------------ P (TB) ------
+// one workgroup per work item = (tile, contiguous slice of its bucket)
+template <int POL>
+__global__ __launch_bounds__(256) void k_P_tiles(
+    int tp, int64_t npix, const int32_t *__restrict__ item_tile,
+    const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
+    const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
+    const double *__restrict__ x, double *__restrict__ d_tb)
+{
+    extern __shared__ double tile[];                    // tp*POL doubles
+    const int b = item_tile[blockIdx.x];
+    const int64_t p0 = (int64_t)b * tp;
+    int64_t np = npix - p0;
+    if (np > tp) np = tp;
+    const int64_t nvals = np * POL;
+    const double *xs = x + p0 * POL;
+    for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = xs[i];
+    __syncthreads();
+    const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        const int q = pl[k];
+        double r = 0.0;
+        if (POL == 1) {
+            r += tile[q];
+        } else if (POL == 2) {
+            r += tile[2 * q] * c[k] + tile[2 * q + 1] * s[k];
+        } else {
+            r += tile[3 * q] + tile[3 * q + 1] * c[k] + tile[3 * q + 2] * s[k];
+        }
+        d_tb[k] = r;
+    }
+}
+
+// ---------------------------------------------------------------- P^T (TB) ------
+template <int POL>
+__global__ __launch_bounds__(256) void k_Pt_tiles(
+    int tp, int64_t npix, const int32_t *__restrict__ item_tile,
+    const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
+    const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
+    const double *__restrict__ v_tb, double *__restrict__ out)
+{
+    extern __shared__ double tile[];                    // tp*POL accumulators
+    const int b = item_tile[blockIdx.x];
+    const int64_t p0 = (int64_t)b * tp;
+    int64_t np = npix - p0;
+    if (np > tp) np = tp;
+    const int64_t nvals = np * POL;
+    for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = 0.0;
+    __syncthreads();
+    const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        const int q = pl[k];
+        const double v = v_tb[k];
+        if (POL == 1) {
+            atomicAdd(&tile[q], v);
+        } else if (POL == 2) {
+            atomicAdd(&tile[2 * q], v * c[k]);
+            atomicAdd(&tile[2 * q + 1], v * s[k]);
+        } else {
+            atomicAdd(&tile[3 * q], v);
+            atomicAdd(&tile[3 * q + 1], v * c[k]);
+            atomicAdd(&tile[3 * q + 2], v * s[k]);
+        }
+    }
+    __syncthreads();
+    double *o = out + p0 * POL;
+    for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) atomicAdd(&o[i], tile[i]);
+}
+
+// ------------------------------------------------------- time <-> TB order ------
+// each workgroup owns ONE contiguous time range, so that the K sequential tile streams
+// it touches stay in its XCD's L2 until their lines are complete
+__global__ __launch_bounds__(1024) void k_time_to_tiles(int64_t nt, int64_t chunk,
+                                                         const uint32_t *__restrict__ tb_dst,
+                                                         const double *__restrict__ in,
+                                                         double *__restrict__ out_tb)
+{
+    const int64_t t0 = (int64_t)blockIdx.x * chunk;
+    int64_t t1 = t0 + chunk;
+    if (t1 > nt) t1 = nt;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const uint32_t k = tb_dst[t];
+        if (k != kInvalidSample) out_tb[k] = in[t];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tiles_to_time(int64_t nt, int64_t chunk,
+                                                         const uint32_t *__restrict__ tb_dst,
+                                                         const double *__restrict__ in_tb,
+                                                         double *__restrict__ out)
+{
+    const int64_t t0 = (int64_t)blockIdx.x * chunk;
+    int64_t t1 = t0 + chunk;
+    if (t1 > nt) t1 = nt;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const uint32_t k = tb_dst[t];
+        out[t] = (k != kInvalidSample) ? in_tb[k] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ C ABI -------
+extern "C" int cm2_tiles_destroy(cm2_tiles *t)
+{
+    if (!t) return 0;
+    void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_item_tile, t->d_item_k0,
+                    t->d_item_k1};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete t;
+    return 0;
+}
+
+extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
+                                const double *d_sin, int64_t nt, int64_t npix, int pol,
+                                int tile_pixels, int64_t slice_samples, void *stream_)
+{
+    CM2_CHECK(out != nullptr, "cm2_tiles_create: out is NULL");
+    *out = nullptr;
+    CM2_CHECK(pol == 1 || pol == 2 || pol == 3, "cm2_tiles_create: bad pol=%d", pol);
+    CM2_CHECK(pol == 1 || (d_cos && d_sin), "cm2_tiles_create: cos/sin required for pol=%d", pol);
+    CM2_CHECK(nt > 0 && nt < (int64_t)0xFFFFFFFF, "cm2_tiles_create: nt=%lld out of range",
+              (long long)nt);
+    CM2_CHECK(tile_pixels >= 64 && tile_pixels <= 65536 && tile_pixels * pol * 8 <= 160 * 1024 - 1024,
+              "cm2_tiles_create: tile of %d pixels does not fit LDS / uint16", tile_pixels);
+    CM2_CHECK(slice_samples >= 256, "cm2_tiles_create: slice too short");
+    hipStream_t stream = as_stream(stream_);
+    cm2_tiles *t = new cm2_tiles();
+    t->nt = nt; t->npix = npix; t->pol = pol; t->tp = tile_pixels;
+    t->ntiles = (npix + tile_pixels - 1) / tile_pixels;
+
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *tb_src = nullptr;
+    int64_t *d_off = nullptr;
+    void *d_temp = nullptr;
+    CM2_HIP(hipMalloc(&keys_in, sizeof(uint32_t) * nt));
+    CM2_HIP(hipMalloc(&keys_out, sizeof(uint32_t) * nt));
+    CM2_HIP(hipMalloc(&vals_in, sizeof(uint32_t) * nt));
+    CM2_HIP(hipMalloc(&tb_src, sizeof(uint32_t) * nt));
+    CM2_HIP(hipMalloc(&d_off, sizeof(int64_t) * (t->ntiles + 1)));
+    k_tile_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, tile_pixels, (uint32_t)t->ntiles,
+                                                     keys_in, vals_in);
+    CM2_LAUNCH_OK();
+    int end_bit = 1;
+    while (((int64_t)1 << end_bit) <= t->ntiles) ++end_bit;
+    size_t tb = 0;
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, tb_src, nt,
+                                               0, end_bit, stream));
+    CM2_HIP(hipMalloc(&d_temp, tb + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, keys_in, keys_out, vals_in, tb_src, nt,
+                                               0, end_bit, stream));
+    k_tile_bounds<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+        keys_out, nt, t->ntiles, d_off);
+    CM2_LAUNCH_OK();
+    std::vector<int64_t> off(t->ntiles + 1);
+    CM2_HIP(hipMemcpyAsync(off.data(), d_off, sizeof(int64_t) * (t->ntiles + 1),
+                           hipMemcpyDeviceToHost, stream));
+    CM2_HIP(hipStreamSynchronize(stream));
+    t->nvalid = off[t->ntiles];
+
+    const int64_t nv = t->nvalid > 0 ? t->nvalid : 1;
+    CM2_HIP(hipMalloc(&t->d_tb_dst, sizeof(uint32_t) * nt));
+    CM2_HIP(hipMalloc(&t->d_pl, sizeof(uint16_t) * nv));
+    if (pol > 1) {
+        CM2_HIP(hipMalloc(&t->d_cos, sizeof(double) * nv));
+        CM2_HIP(hipMalloc(&t->d_sin, sizeof(double) * nv));
+    }
+#define CM2_TF(POL)                                                                            \
+    k_tile_fill<POL><<<grid_for(nt), kBlock, 0, stream>>>(nt, t->nvalid, tile_pixels, tb_src,  \
+                                                          d_pix, d_cos, d_sin, t->d_tb_dst,    \
+                                                          t->d_pl, t->d_cos, t->d_sin)
+    if (pol == 1) CM2_TF(1); else if (pol == 2) CM2_TF(2); else CM2_TF(3);
+#undef CM2_TF
+    CM2_LAUNCH_OK();
+
+    // work items: every tile bucket cut into slices of <= slice_samples
+    std::vector<int32_t> it_tile;
+    std::vector<int64_t> it_k0, it_k1;
+    for (int64_t b = 0; b < t->ntiles; ++b)
+        for (int64_t k = off[b]; k < off[b + 1]; k += slice_samples) {
+            it_tile.push_back((int32_t)b);
+            it_k0.push_back(k);
+            it_k1.push_back(k + slice_samples < off[b + 1] ? k + slice_samples : off[b + 1]);
+        }
+    t->nitems = (int64_t)it_tile.size();
+    const int64_t ni = t->nitems > 0 ? t->nitems : 1;
+    CM2_HIP(hipMalloc(&t->d_item_tile, sizeof(int32_t) * ni));
+    CM2_HIP(hipMalloc(&t->d_item_k0, sizeof(int64_t) * ni));
+    CM2_HIP(hipMalloc(&t->d_item_k1, sizeof(int64_t) * ni));
+    if (t->nitems) {
+        CM2_HIP(hipMemcpy(t->d_item_tile, it_tile.data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
+        CM2_HIP(hipMemcpy(t->d_item_k0, it_k0.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
+        CM2_HIP(hipMemcpy(t->d_item_k1, it_k1.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
+    }
+    CM2_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(keys_in);
+    (void)hipFree(keys_out);
+    (void)hipFree(vals_in);
+    (void)hipFree(tb_src);
+    (void)hipFree(d_off);
+    (void)hipFree(d_temp);
+    *out = t;
+    return 0;
+}
+
+extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
+{
+    CM2_CHECK(t && h_info, "cm2_tiles_info: NULL argument");
+    h_info[0] = t->nt; h_info[1] = t->nvalid; h_info[2] = t->tp;
+    h_info[3] = t->ntiles; h_info[4] = t->nitems;
+    return 0;
+}
+
+extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb,
+                                 void *stream_)
+{
+    CM2_CHECK(t && d_x && (d_tod_tb || t->nvalid == 0), "cm2_P_tiles_apply: NULL argument");
+    if (t->nitems == 0) return 0;
+    hipStream_t stream = as_stream(stream_);
+    const size_t lds = sizeof(double) * t->tp * t->pol;
+#define CM2_PT(POL)                                                                            \
+    k_P_tiles<POL><<<(int)t->nitems, kBlock, lds, stream>>>(t->tp, t->npix, t->d_item_tile,    \
+                                                            t->d_item_k0, t->d_item_k1,        \
+                                                            t->d_pl, t->d_cos, t->d_sin, d_x,  \
+                                                            d_tod_tb)
+    if (t->pol == 1) CM2_PT(1); else if (t->pol == 2) CM2_PT(2); else CM2_PT(3);
+#undef CM2_PT
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, double *d_out,
+                                  void *stream_)
+{
+    CM2_CHECK(t && d_out && (d_tod_tb || t->nvalid == 0), "cm2_Pt_tiles_apply: NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    CM2_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * t->npix * t->pol, stream));
+    if (t->nitems == 0) return 0;
+    const size_t lds = sizeof(double) * t->tp * t->pol;
+#define CM2_PTT(POL)                                                                           \
+    k_Pt_tiles<POL><<<(int)t->nitems, kBlock, lds, stream>>>(t->tp, t->npix, t->d_item_tile,   \
+                                                             t->d_item_k0, t->d_item_k1,       \
+                                                             t->d_pl, t->d_cos, t->d_sin,      \
+                                                             d_tod_tb, d_out)
+    if (t->pol == 1) CM2_PTT(1); else if (t->pol == 2) CM2_PTT(2); else CM2_PTT(3);
+#undef CM2_PTT
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+static inline void perm_geometry(int64_t nt, int &blocks, int64_t &chunk)
+{
+    // one 1024-thread workgroup per CU-slot, each with a contiguous time range
+    blocks = kNumCU * 2;
+    chunk = (nt + blocks - 1) / blocks;
+    chunk = ((chunk + 1023) / 1024) * 1024;
+    blocks = (int)((nt + chunk - 1) / chunk);
+    if (blocks < 1) blocks = 1;
+}
+
+extern "C" int cm2_tod_time_to_tiles(const cm2_tiles *t, const double *d_time, double *d_tb,
+                                     void *stream_)
+{
+    CM2_CHECK(t && d_time && d_tb, "cm2_tod_time_to_tiles: NULL argument");
+    int blocks;
+    int64_t chunk;
+    perm_geometry(t->nt, blocks, chunk);
+    k_time_to_tiles<<<blocks, 1024, 0, as_stream(stream_)>>>(t->nt, chunk, t->d_tb_dst, d_time, d_tb);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_tod_tiles_to_time(const cm2_tiles *t, const double *d_tb, double *d_time,
+                                     void *stream_)
+{
+    CM2_CHECK(t && d_time && d_tb, "cm2_tod_tiles_to_time: NULL argument");
+    int blocks;
+    int64_t chunk;
+    perm_geometry(t->nt, blocks, chunk);
+    k_tiles_to_time<<<blocks, 1024, 0, as_stream(stream_)>>>(t->nt, chunk, t->d_tb_dst, d_tb, d_time);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// device address of the time -> tile-order index (nt entries), for kernels that fuse the
+// permutation into their own loads and stores (cm2_noise_apply_tiles)
+extern "C" const uint32_t *cm2_tiles_index(const cm2_tiles *t) { return t ? t->d_tb_dst : nullptr; }
+extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t) { return t ? t->nt : 0; }

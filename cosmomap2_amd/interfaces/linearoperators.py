@@ -26,7 +26,7 @@ torch = D.torch
 
 __all__ = ["SparseLO", "ToeplitzLO", "BlockLO", "BlockDiagonalLO",
            "BlockDiagonalPreconditionerLO", "InverseLO", "CoarseLO", "DeflationLO",
-           "TwoLevelPreconditionerLO", "lp"]
+           "TwoLevelPreconditionerLO", "set_pointing_mode", "lp"]
 
 _I64P = ctypes.POINTER(ctypes.c_int64)
 _DBLP = ctypes.POINTER(ctypes.c_double)
@@ -178,6 +178,101 @@ class SparseLO(_DeviceOp):
         return D.like_input(out, v)
 
 
+class _TileHandle(object):
+    """Owns a cm2_tiles object (tile-bucketed copy of the pointing)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        info = (ctypes.c_int64 * 5)()
+        _hip.call("cm2_tiles_info", handle, info)
+        self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                _hip.load().cm2_tiles_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+
+def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
+    """Tile-bucketed plan of a SparseLO, built on first use (sort by pixel tile)."""
+    if getattr(P, "_tiles", None) is None:
+        if tile_pixels is None:
+            tile_pixels = {1: 8192, 2: 4096, 3: 2048}[P.pol]       # <= 64 KB of LDS per tile
+            while tile_pixels > 64 and tile_pixels // 2 >= P.ncols:
+                tile_pixels //= 2
+        if slice_samples is None:
+            slice_samples = max(4096, min(65536, P.nrows // 4096))
+        h = ctypes.c_void_p()
+        _hip.call("cm2_tiles_create", ctypes.byref(h), D.ptr(P._d_pix), D.ptr(P._d_cos),
+                  D.ptr(P._d_sin), P.nrows, P.ncols, int(P.pol), int(tile_pixels),
+                  int(slice_samples), D.stream())
+        P._tiles = _TileHandle(h)
+    return P._tiles
+
+
+class _TiledNormalLO(_DeviceOp):
+    """
+    ``P^T N^-1 P`` for a noise operator with off-diagonal terms, on the tile-bucketed TOD
+    order: LDS-staged gather -> time order -> N^-1 -> tile order -> LDS-staged scatter-add.
+    Every HBM access is a coalesced stream.  Equal to the three separate stages up to
+    the summation order inside P^T (LDS atomics), i.e. to rounding.
+    """
+
+    def __init__(self, P, noise):
+        self.P, self.noise = P, noise
+        self._fused_noise = None
+        n = P.pol * P.ncols
+        super(_TiledNormalLO, self).__init__(n, n, self._mult, symmetric=True)
+
+    def _mult(self, v):
+        P = self.P
+        T = _sparse_tiles(P)
+        x = D.f64(v)
+        if x.numel() != P.pol * P.ncols:
+            raise lp.ShapeError("map vector has %d entries, expected %d"
+                                % (x.numel(), P.pol * P.ncols))
+        st = D.stream()
+        d_tb = D.empty(max(T.nvalid, 1))
+        _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)
+        if self._fused_noise is None:
+            self._fused_noise = self.noise.noise_info()["method"] == 3
+        if self._fused_noise:
+            # overlap-save kernel reads and writes the tile order directly
+            v_tb = D.empty(max(T.nvalid, 1))
+            _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
+                      D.ptr(v_tb), st)
+            out = D.empty(P.pol * P.ncols)
+            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+            return D.like_input(out, v)
+        tod = D.empty(P.nrows)
+        _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
+        tod2 = self.noise._apply_all(tod)
+        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st)
+        out = D.empty(P.pol * P.ncols)
+        _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st)
+        return D.like_input(out, v)
+
+
+#: "exact": P^T is always the fixed-order pixel-major reduction (bit-reproducible, equal to
+#: the reference's serial loop).  "tiled": products P.T*N*P with a Toeplitz N run on the
+#: tile-bucketed order (faster, P^T equal to rounding).  "auto": tiled from 2^20 samples up.
+POINTING_MODE = "auto"
+
+
+def set_pointing_mode(mode):
+    global POINTING_MODE
+    if mode not in ("exact", "tiled", "auto"):
+        raise ValueError("pointing mode must be 'exact', 'tiled' or 'auto'")
+    POINTING_MODE = mode
+
+
+def _use_tiles(P):
+    return POINTING_MODE == "tiled" or (POINTING_MODE == "auto" and P.nrows >= (1 << 20))
+
+
 class _FusedNormalLO(_DeviceOp):
     """P^T diag(w) P as one operator (produced by the product-chain fusion)."""
 
@@ -202,6 +297,12 @@ def _fuse_chain(chain):
             if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], BlockLO) \
                     and not chain[i + 1].isoffdiag:
                 out.append(_FusedNormalLO(P, chain[i + 1]))
+                i += 3
+                changed = True
+                continue
+            if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], BlockLO) \
+                    and chain[i + 1].isoffdiag and _use_tiles(P):
+                out.append(_TiledNormalLO(P, chain[i + 1]))
                 i += 3
                 changed = True
                 continue

@@ -79,14 +79,37 @@ int cm2_PtNP_diag_apply(const cm2_pointing *p, const double *d_x, double *d_out,
                         void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * a2-a3 (throughput form)  Tile-bucketed TOD order
+ *   Samples grouped by pixel tile (stable, so time order inside a tile); the tile's
+ *   slice of the map is staged in LDS, so P and P^T stream HBM with no random access.
+ *   Same loops as above (linearoperators.py:483-489, :509-516); P^T adds with LDS
+ *   atomics (term order not fixed: equal to the serial loop to rounding only).
+ * ------------------------------------------------------------------------- */
+typedef struct cm2_tiles cm2_tiles;
+int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
+                     const double *d_sin, int64_t nt, int64_t npix, int pol, int tile_pixels,
+                     int64_t slice_samples, void *stream);
+int cm2_tiles_destroy(cm2_tiles *t);
+/* h_info[0..4] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items */
+int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
+/* d_tod_tb[k] = (P x) for the k-th sample in TB order */
+int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
+/* d_out = P^T v for a TB-ordered v (d_out is overwritten) */
+int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, double *d_out, void *stream);
+/* permutations between time order (nt, flagged samples read as / written with 0) and TB order */
+int cm2_tod_time_to_tiles(const cm2_tiles *t, const double *d_time, double *d_tb, void *stream);
+int cm2_tod_tiles_to_time(const cm2_tiles *t, const double *d_tb, double *d_time, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * a4-a5  Noise operator N^-1  (ToeplitzLO linearoperators.py:560-602,
  *        BlockLO :627-697, blk_matvec interfaces/blkop.py:178-208)
  * ------------------------------------------------------------------------- */
 typedef struct cm2_noise cm2_noise;
 
-#define CM2_TOEPLITZ_AUTO   0   /* direct for short bands, FFT otherwise */
+#define CM2_TOEPLITZ_AUTO   0   /* direct for short bands, fused FFT, rocFFT beyond its range */
 #define CM2_TOEPLITZ_DIRECT 1   /* O(n*lambda), reference summation order  */
 #define CM2_TOEPLITZ_FFT    2   /* overlap-save, rocFFT R2C/C2R fp64       */
+#define CM2_TOEPLITZ_FUSED  3   /* overlap-save, one kernel, fp64 FFT in LDS (lambda <= 2049) */
 
 /* Block-diagonal with constant diagonal blocks: block b = h_t[b] * I of
  * h_sizes[b] samples (BlockLO offdiag=False, :676-683). */
@@ -101,6 +124,11 @@ int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands, int64_t la
 int cm2_noise_destroy(cm2_noise *n);
 /* y = N^-1 v over all blocks (blk_matvec, blkop.py:195-206).  d_out != d_v. */
 int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, void *stream);
+/* y = N^-1 v with v and y both in the tile-bucketed order of `tiles` (CM2_TOEPLITZ_FUSED
+ * operators only): the permutation to and from time order is folded into the overlap-save
+ * kernel's own loads and stores.  d_out_tb != d_in_tb. */
+int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
+                          double *d_out_tb, void *stream);
 /* per-sample diagonal of a constant-diagonal noise operator (BlockLO.diag). */
 int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
 /* h_info[0..4] = nt, nblocks, lambda (0 for diag), method used, FFT length */
