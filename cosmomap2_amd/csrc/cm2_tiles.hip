@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(
 // ------------------------------------------------------------------ P (TB) ------
 // one workgroup per work item = (tile, contiguous slice of its bucket)
 template <int POL>
-__global__ __launch_bounds__(256) void k_P_tiles(
+__global__ __launch_bounds__(1024) void k_P_tiles(
     int tp, int64_t npix, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_P_tiles(
 
 // ---------------------------------------------------------------- P^T (TB) ------
 template <int POL>
-__global__ __launch_bounds__(256) void k_Pt_tiles(
+__global__ __launch_bounds__(1024) void k_Pt_tiles(
     int tp, int64_t npix, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
@@ -146,7 +146,36 @@ __global__ __launch_bounds__(256) void k_Pt_tiles(
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = 0.0;
     __syncthreads();
     const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+    constexpr int U = 4;                     // independent loads in flight per thread
+    int64_t k = k0 + threadIdx.x;
+    for (; k + (U - 1) * (int64_t)blockDim.x < k1; k += U * (int64_t)blockDim.x) {
+        int q[U];
+        double v[U], cc[U], ss[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = k + u * (int64_t)blockDim.x;
+            q[u] = pl[kk];
+            v[u] = v_tb[kk];
+            if (POL > 1) {
+                cc[u] = c[kk];
+                ss[u] = s[kk];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (POL == 1) {
+                atomicAdd(&tile[q[u]], v[u]);
+            } else if (POL == 2) {
+                atomicAdd(&tile[2 * q[u]], v[u] * cc[u]);
+                atomicAdd(&tile[2 * q[u] + 1], v[u] * ss[u]);
+            } else {
+                atomicAdd(&tile[3 * q[u]], v[u]);
+                atomicAdd(&tile[3 * q[u] + 1], v[u] * cc[u]);
+                atomicAdd(&tile[3 * q[u] + 2], v[u] * ss[u]);
+            }
+        }
+    }
+    for (; k < k1; k += blockDim.x) {
         const int q = pl[k];
         const double v = v_tb[k];
         if (POL == 1) {
@@ -194,6 +223,20 @@ __global__ __launch_bounds__(1024) void k_tiles_to_time(int64_t nt, int64_t chun
         const uint32_t k = tb_dst[t];
         out[t] = (k != kInvalidSample) ? in_tb[k] : 0.0;
     }
+}
+
+// workgroup size of the two tile kernels (CM2_TILE_BLOCK = 256 / 512 / 1024 to experiment)
+static int tile_block()
+{
+    static int b = 0;
+    if (b == 0) {
+        b = 512;
+        if (const char *e = getenv("CM2_TILE_BLOCK")) {
+            const int v = atoi(e);
+            if (v == 256 || v == 512 || v == 1024) b = v;
+        }
+    }
+    return b;
 }
 
 // ------------------------------------------------------------------ C ABI -------
@@ -315,7 +358,7 @@ extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *
     hipStream_t stream = as_stream(stream_);
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PT(POL)                                                                            \
-    k_P_tiles<POL><<<(int)t->nitems, kBlock, lds, stream>>>(t->tp, t->npix, t->d_item_tile,    \
+    k_P_tiles<POL><<<(int)t->nitems, tile_block(), lds, stream>>>(t->tp, t->npix, t->d_item_tile,    \
                                                             t->d_item_k0, t->d_item_k1,        \
                                                             t->d_pl, t->d_cos, t->d_sin, d_x,  \
                                                             d_tod_tb)
@@ -334,7 +377,7 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
     if (t->nitems == 0) return 0;
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PTT(POL)                                                                           \
-    k_Pt_tiles<POL><<<(int)t->nitems, kBlock, lds, stream>>>(t->tp, t->npix, t->d_item_tile,   \
+    k_Pt_tiles<POL><<<(int)t->nitems, tile_block(), lds, stream>>>(t->tp, t->npix, t->d_item_tile,   \
                                                              t->d_item_k0, t->d_item_k1,       \
                                                              t->d_pl, t->d_cos, t->d_sin,      \
                                                              d_tod_tb, d_out)

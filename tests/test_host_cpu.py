@@ -1,0 +1,152 @@
+"""
+CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute calls), the operator algebra that stands in for `linop`, the seeded
+generators against the reference's streams, and the "no CPU fallback" contract.
+"""
+import os
+import random
+import re
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cosmomap2.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cm2_[a-zA-Z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cosmomap2_amd import _hip
+    lib = _hip.load()                     # dlopen only; no GPU call
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), "libcosmomap2_hip.so lacks %s" % s
+    # the ctypes table binds exactly the declared interface
+    assert sorted(_hip.PROTOTYPES) == syms
+    assert lib.cm2_abi_version() == 1
+    assert lib.cm2_last_error() is not None
+    assert lib.cm2_reduce_work_doubles() > 0 and lib.cm2_gemm_tn_work_doubles(32, 32) > 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cosmomap2_amd import _hip, cg
+    from cosmomap2_amd.interfaces import SparseLO, BlockLO, ToeplitzLO, DeflationLO
+    from cosmomap2_amd.utilities import ProcessTimeSamples, norm2
+    for make in (lambda: SparseLO(10, 20, np.zeros(20, dtype=np.int32)),
+                 lambda: BlockLO(10, [1.0, 2.0]),
+                 lambda: ToeplitzLO(np.ones(2), 10),
+                 lambda: DeflationLO(np.ones((10, 2))),
+                 lambda: ProcessTimeSamples(np.zeros(20, dtype=np.int32), 10),
+                 lambda: norm2(np.ones(4)),
+                 lambda: cg(np.eye(3), np.ones(3))):
+        with pytest.raises(_hip.HipError):
+            make()
+    with pytest.raises(RuntimeError):                       # bad pol is checked first (:549)
+        SparseLO(10, 20, np.zeros(20, dtype=np.int32), pol=7)
+
+
+def test_linop_algebra():
+    from cosmomap2_amd import linop as lp
+    rng = np.random.default_rng(0)
+    Am, Bm = rng.standard_normal((5, 4)), rng.standard_normal((4, 6))
+    A = lp.LinearOperator(4, 5, lambda x: Am @ x, rmatvec=lambda y: Am.T @ y)
+    B = lp.LinearOperator(6, 4, lambda x: Bm @ x, rmatvec=lambda y: Bm.T @ y)
+    x, y = rng.standard_normal(6), rng.standard_normal(5)
+    assert A.shape == (5, 4) and A.nargin == 4 and A.nargout == 5 and A.dtype == np.float64
+    np.testing.assert_allclose((A * B) * x, Am @ Bm @ x)
+    np.testing.assert_allclose(A * B * x, Am @ Bm @ x)
+    np.testing.assert_allclose((A * B).T * y, Bm.T @ Am.T @ y)
+    np.testing.assert_allclose((A * B).H * y, Bm.T @ Am.T @ y)
+    np.testing.assert_allclose(A.T.T * x[:4], Am @ x[:4])
+    assert A.T.T is A
+    np.testing.assert_allclose((2.5 * A) * x[:4], 2.5 * Am @ x[:4])
+    np.testing.assert_allclose((A * 2.5) * x[:4], 2.5 * Am @ x[:4])
+    np.testing.assert_allclose((A / 2) * x[:4], 0.5 * Am @ x[:4])
+    np.testing.assert_allclose((-A) * x[:4], -Am @ x[:4])
+    np.testing.assert_allclose((A + A) * x[:4], 2 * Am @ x[:4])
+    np.testing.assert_allclose((A - 3 * A).T * y, -2 * Am.T @ y)
+    np.testing.assert_allclose(A.to_array(), Am)
+    np.testing.assert_allclose(A.matmat(Bm), Am @ Bm)
+    with pytest.raises(lp.ShapeError):
+        A * B.T
+    with pytest.raises(lp.ShapeError):
+        A * np.ones(7)
+    with pytest.raises(lp.ShapeError):
+        A + B
+    S = lp.LinearOperator(3, 3, lambda v: 2 * v, symmetric=True)
+    assert S.T is S and S.symmetric
+    I = lp.IdentityOperator(3)
+    Dg = lp.DiagonalOperator(np.array([1., 2., 3.]))
+    v = np.array([1., 1., 1.])
+    np.testing.assert_allclose((I - S * Dg) * v, [-1., -3., -5.])
+    np.testing.assert_allclose(lp.ZeroOperator(3, 2) * v, [0., 0.])
+    noT = lp.LinearOperator(3, 3, lambda v: v)
+    with pytest.raises(NotImplementedError):
+        noT.T
+    # accepted by scipy
+    xs, info = spla.cg(S + Dg, v, rtol=1e-12)
+    assert info == 0
+    np.testing.assert_allclose(xs, [1 / 3., 1 / 4., 1 / 5.])
+    w = spla.eigsh(spla.aslinearoperator(S + Dg), k=1, which='LA')[0]
+    np.testing.assert_allclose(w, [5.0])
+    assert S.nMatvec > 0
+    assert not lp.supports_device(A) and lp.supports_device(I) and lp.supports_device(I * Dg)
+
+
+def test_block_diagonal_container():
+    from cosmomap2_amd import linop as lp
+    from cosmomap2_amd.interfaces.blkop import BlockDiagonalLinearOperator
+    A = lp.DiagonalOperator(np.array([1., 2.]))
+    Bm = np.array([[1., 2., 0.], [0., 1., 0.], [3., 0., 1.]])
+    B = lp.LinearOperator(3, 3, lambda x: Bm @ x, rmatvec=lambda y: Bm.T @ y)
+    K = BlockDiagonalLinearOperator([A, B])
+    assert K.shape == (5, 5) and not K.symmetric and len(K.blocks) == 2 and K[1] is B
+    x = np.arange(1., 6.)
+    np.testing.assert_allclose(K * x, np.concatenate([[1., 4.], Bm @ x[2:]]))
+    np.testing.assert_allclose(K.T * x, np.concatenate([[1., 4.], Bm.T @ x[2:]]))
+    with pytest.raises(lp.ShapeError):
+        K * np.ones(4)
+    with pytest.raises(ValueError):
+        BlockDiagonalLinearOperator([1, 2])
+
+
+def test_generators_and_helpers_match_reference(golden):
+    from cosmomap2_amd.utilities import utilities_functions as U
+    from cosmomap2_amd.interfaces.deflationlib import build_hess
+    G = golden
+    np.testing.assert_array_equal(U.angles_gen(0.3, 50), G["gen_angles"])
+    np.random.seed(int(G["gen_seed"]))
+    random.seed(int(G["gen_seed"]))
+    d, pairs, phi, t, diag = U.system_setup(120, 17, 3)
+    np.testing.assert_array_equal(d, G["gen_d"])
+    np.testing.assert_array_equal(pairs, G["gen_pairs"])
+    np.testing.assert_array_equal(phi, G["gen_phi"])
+    np.testing.assert_array_equal(np.asarray(t), G["gen_t"])
+    np.testing.assert_array_equal(np.asarray(diag), G["gen_diag"])
+    with pytest.raises(RuntimeError):
+        U.pairs_gen(10, 2)                                  # utilities_functions.py:117-118
+    assert int(G["gen_pairs_small_raises"]) == 1
+    assert U.checking_output(0) is True and int(G["checking_output_zero"]) == 1
+    with pytest.raises(RuntimeError):
+        U.checking_output(3)
+    with pytest.raises(RuntimeError):
+        U.checking_output(-1)
+    assert U.is_sorted([1, 2, 2, 5]) and not U.is_sorted([2, 1])
+    assert U.bash_colors().bold("x") == "\033[1mx\033[0m"
+    np.testing.assert_array_equal(U.subscan_resize(np.arange(10), [[2, 3], [1, 6]]),
+                                  [1, 2, 6, 7, 8])
+    # build_hess is pure host code: pinned by the reference-executed Hessenberg matrix
+    H = G["arn_H"]
+    j = int(G["arn_j"])
+    cols = [H[:q + 2, q].copy() for q in range(j - 1)] + [np.concatenate([H[:, j - 1], [0.0]])]
+    np.testing.assert_array_equal(build_hess(cols, j), H)

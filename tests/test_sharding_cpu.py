@@ -1,0 +1,137 @@
+"""
+CPU tests of the multi-GPU layer (cosmomap2_amd/sharding.py) with world_size 2 over gloo.
+The per-rank compute is done by the ORACLE (tests may use it); what is under test is the
+host logic that ships: block-aligned TOD partition, the map all-reduce operator, the
+replicated-vector PCG over it and the stop-test synchronisation.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_blocks_partition():
+    from cosmomap2_amd.sharding import shard_blocks
+    sizes = [500, 400, 124, 500, 400, 124, 77]
+    for world in (1, 2, 3, 4, 8, 16):
+        cover = []
+        for r in range(world):
+            b0, b1, s0, s1 = shard_blocks(sizes, world, r)
+            assert 0 <= b0 <= b1 <= len(sizes)
+            assert s0 == sum(sizes[:b0]) and s1 == sum(sizes[:b1])     # cuts at block boundaries
+            cover.append((b0, b1))
+        assert cover[0][0] == 0 and cover[-1][1] == len(sizes)
+        for (a0, a1), (c0, c1) in zip(cover[:-1], cover[1:]):
+            assert a1 == c0                                            # contiguous, disjoint
+    # equal blocks split evenly: C5 = 64 detector blocks over 8 GPUs -> 8 each
+    for r in range(8):
+        b0, b1, s0, s1 = shard_blocks([15625000] * 64, 8, r)
+        assert b1 - b0 == 8 and s1 - s0 == 8 * 15625000
+    with pytest.raises(ValueError):
+        shard_blocks(sizes, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from cosmomap2_amd import linop as lp
+        from cosmomap2_amd.sharding import ShardedLO, shard_blocks, allreduce_sum_, make_sync, world as W
+        assert W() == (rank, world)
+        pol, npix, nb = 3, 48, 6
+        sizes = [700, 300, 500, 800, 200, 500]
+        nt = sum(sizes)
+        rng = np.random.default_rng(123)                    # same global problem on every rank
+        d, pairs, phi, t, diag = orc.system_setup(rng, nt, npix, nb)
+        bands = [np.array([1.0 + 0.5 * ti[0], 0.3 * ti[1]]) for ti in t]
+        c, s = np.cos(2 * phi), np.sin(2 * phi)
+
+        def normal(pix, cc, ss, bl, szs, x):
+            return orc.sparse_rmult(pol, npix, pix, cc, ss, orc.blocklo_mult(
+                szs, bl, True, orc.sparse_mult(pol, pix, cc, ss, x)))
+
+        # ---- this rank's shard: whole noise blocks only
+        b0, b1, s0, s1 = shard_blocks(sizes, world, rank)
+        lp_pix, lc, ls = pairs[s0:s1], c[s0:s1], s[s0:s1]
+        A_local = lp.LinearOperator(pol * npix, pol * npix, lambda x: normal(
+            lp_pix, lc, ls, bands[b0:b1], sizes[b0:b1], x), symmetric=True)
+        A = ShardedLO(A_local)
+        x = rng.standard_normal(pol * npix)
+        y = A * x
+        y_ref = normal(pairs, c, s, bands, sizes, x)
+        assert np.allclose(y, y_ref, rtol=1e-12, atol=1e-12)
+
+        # ---- per-pixel weights: sum of shard sums == global sums (setup all-reduce)
+        z = lambda: np.zeros(npix)
+        loc = [z() for _ in range(6)]
+        orc.lib()
+        import ctypes
+        D_ = ctypes.POINTER(ctypes.c_double)
+        w = np.ones(s1 - s0)
+        orc.lib().orc_weights_accumulate(
+            ctypes.c_int(pol), ctypes.c_int64(s1 - s0),
+            np.ascontiguousarray(lp_pix).ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            w.ctypes.data_as(D_), np.ascontiguousarray(lc).ctypes.data_as(D_),
+            np.ascontiguousarray(ls).ctypes.data_as(D_), *[a.ctypes.data_as(D_) for a in loc])
+        for a in loc:
+            allreduce_sum_(a)
+        pg = pairs.copy()
+        glob = orc.process_time_samples(pg, npix, pol=pol, phi=phi)
+        assert glob.new_npix == npix
+        assert np.allclose(loc[0], glob.counts) and np.allclose(loc[5], glob.sincos)
+
+        # ---- replicated-vector PCG over the sharded operator
+        b_loc = orc.sparse_rmult(pol, npix, lp_pix, lc, ls, orc.blocklo_mult(
+            sizes[b0:b1], bands[b0:b1], True, d[s0:s1]))
+        b = allreduce_sum_(b_loc.copy())
+        M = lambda v: orc.bd_precond_mult(pol, glob, v)
+        its = []
+        xs, info = orc.cg(lambda v: A * v, b, M=M, rtol=1e-8, callback=lambda xk: its.append(1))
+        its1 = []
+        x1, info1 = orc.cg(lambda v: normal(pairs, c, s, bands, sizes, v),
+                           normal_rhs(orc, pol, npix, pairs, c, s, bands, sizes, d), M=M,
+                           rtol=1e-8, callback=lambda xk: its1.append(1))
+        assert info == 0 and info1 == 0 and len(its) == len(its1)
+        assert np.linalg.norm(xs - x1) <= 1e-9 * np.linalg.norm(x1)
+        # every rank must hold the same bits (replicated vectors never diverge)
+        chk = torch.from_numpy(xs.copy())
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi)
+        sync = make_sync()
+        assert sync(float(rank + 1)) == float(world)        # max over ranks
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("%d" % len(its))
+    finally:
+        dist.destroy_process_group()
+
+
+def normal_rhs(orc, pol, npix, pairs, c, s, bands, sizes, d):
+    return orc.sparse_rmult(pol, npix, pairs, c, s, orc.blocklo_mult(sizes, bands, True, d))
+
+
+def test_sharded_operator_and_pcg_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    assert (tmp_path / "ok0").read_text() == (tmp_path / "ok1").read_text()
