@@ -13,6 +13,7 @@ Ownership: the reference keeps *references* to the caller's arrays
 at construction; later host-side mutation is not seen.
 """
 import ctypes
+import os
 
 import numpy as np
 import scipy.linalg as sla
@@ -259,7 +260,7 @@ class _TiledNormalLO(_DeviceOp):
 #: "exact": P^T is always the fixed-order pixel-major reduction (bit-reproducible, equal to
 #: the reference's serial loop).  "tiled": products P.T*N*P with a Toeplitz N run on the
 #: tile-bucketed order (faster, P^T equal to rounding).  "auto": tiled from 2^20 samples up.
-POINTING_MODE = "auto"
+POINTING_MODE = os.environ.get("CM2_POINTING_MODE", "auto")
 
 
 def set_pointing_mode(mode):
