@@ -26,6 +26,8 @@
 // the direct sum at 1e-12, not bit for bit).
 #include "cm2_fft.h"
 
+#include <hipcub/hipcub.hpp>
+
 using namespace cm2;
 
 namespace {
@@ -204,6 +206,7 @@ template <int R1, int R2, int R3, bool INDIRECT>
 __global__ __launch_bounds__(kThreads) void k_overlap_save(
     const PairDesc *__restrict__ pairs, int npairs, int halo, const double2 *__restrict__ W,
     const double *__restrict__ Hperm, const uint32_t *__restrict__ idx,
+    const uint32_t *__restrict__ lst_k, const uint16_t *__restrict__ lst_q,
     const double *__restrict__ v, double *__restrict__ out)
 {
     constexpr int N = R1 * R2 * R3;
@@ -225,19 +228,34 @@ __global__ __launch_bounds__(kThreads) void k_overlap_save(
         const int hop = N - 2 * halo;
         const bool has_b = pd.b_len > 0;
         const int qmax = has_b ? N + hop : N;
+        // (k, q) = (position in the tile-ordered TOD, offset in the union window).  With the
+        // per-pair lists (sorted by k at setup) neighbouring lanes read neighbouring
+        // addresses -- the window's samples of one tile are one contiguous run -- so a wave
+        // touches a handful of cache lines instead of 64; without lists q is the lane's own
+        // time offset and k = idx[t] (one line per lane: the texture-address unit, at about
+        // one lane per clock and CU, then bounds the kernel).
+        const int qm = N + hop;
+        const int64_t ebase = (int64_t)pair_id * qm;
         uint32_t kk[PER2];
+        int qq[PER2];
         double vv[PER2];
 #pragma unroll
         for (int u = 0; u < PER2; ++u) {
-            const int q = threadIdx.x + u * kThreads;
-            const int64_t t = pd.a_start - halo + q;
-            kk[u] = (q < qmax && t >= pd.lo && t < pd.hi) ? idx[t] : kInvalidSample;
+            const int e = threadIdx.x + u * kThreads;
+            if (lst_k) {
+                kk[u] = e < qm ? lst_k[ebase + e] : kInvalidSample;
+                qq[u] = e < qm ? (int)lst_q[ebase + e] : 0xFFFF;
+            } else {
+                const int64_t t = pd.a_start - halo + e;
+                kk[u] = (e < qmax && t >= pd.lo && t < pd.hi) ? idx[t] : kInvalidSample;
+                qq[u] = e < qmax ? e : 0xFFFF;
+            }
         }
 #pragma unroll
         for (int u = 0; u < PER2; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
 #pragma unroll
         for (int u = 0; u < PER2; ++u) {
-            const int q = threadIdx.x + u * kThreads;
+            const int q = qq[u];
             if (q < N) {
                 pre[padi(q)] = vv[u];
                 if (!has_b) pim[padi(q)] = 0.0;
@@ -273,19 +291,41 @@ __global__ __launch_bounds__(kThreads) void k_overlap_save(
     radix_pass<R1, N, true, true, false>(pre, pim, N, W, nullptr);
     __syncthreads();
     if (INDIRECT) {
-        // all index loads first (one round trip), then the scattered stores
-        uint32_t ka[PER], kb[PER];
+        if (lst_k) {
+            constexpr int PER2 = 2 * PER;
+            const int hop = N - 2 * halo;
+            const int qm = N + hop;
+            const int64_t ebase = (int64_t)pair_id * qm;
+            uint32_t kk[PER2];
+            int qq[PER2];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int j = threadIdx.x + u * kThreads;
-            ka[u] = j < pd.a_len ? idx[pd.a_start + j] : kInvalidSample;
-            kb[u] = j < pd.b_len ? idx[pd.b_start + j] : kInvalidSample;
-        }
+            for (int u = 0; u < PER2; ++u) {
+                const int e = threadIdx.x + u * kThreads;
+                kk[u] = e < qm ? lst_k[ebase + e] : kInvalidSample;
+                qq[u] = e < qm ? (int)lst_q[ebase + e] : 0xFFFF;
+            }
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int j = threadIdx.x + u * kThreads;
-            if (ka[u] != kInvalidSample) out[ka[u]] = pre[padi(halo + j)];
-            if (kb[u] != kInvalidSample) out[kb[u]] = pim[padi(halo + j)];
+            for (int u = 0; u < PER2; ++u) {
+                if (kk[u] == kInvalidSample) continue;
+                const int ja = qq[u] - halo, jb = qq[u] - hop - halo;
+                if (ja >= 0 && ja < pd.a_len) out[kk[u]] = pre[padi(qq[u])];
+                else if (jb >= 0 && jb < pd.b_len) out[kk[u]] = pim[padi(qq[u] - hop)];
+            }
+        } else {
+            // all index loads first (one round trip), then the scattered stores
+            uint32_t ka[PER], kb[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int j = threadIdx.x + u * kThreads;
+                ka[u] = j < pd.a_len ? idx[pd.a_start + j] : kInvalidSample;
+                kb[u] = j < pd.b_len ? idx[pd.b_start + j] : kInvalidSample;
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int j = threadIdx.x + u * kThreads;
+                if (ka[u] != kInvalidSample) out[ka[u]] = pre[padi(halo + j)];
+                if (kb[u] != kInvalidSample) out[kb[u]] = pim[padi(halo + j)];
+            }
         }
     } else {
         for (int j = threadIdx.x; j < pd.a_len; j += kThreads)
@@ -435,6 +475,39 @@ __global__ __launch_bounds__(256) void k_spectrum_real(int nb, int64_t lambda,
     }
 }
 
+// keys of the per-pair gather lists: (pair << 32) | position in the tile-ordered TOD, value =
+// offset q in the pair's union window (0xFFFF for slots past the window of a pair without a
+// second segment).  A stable sort by key orders every pair's entries by address.
+__global__ __launch_bounds__(256) void k_list_keys(const PairDesc *__restrict__ pairs, int npairs,
+                                                    int N, int halo,
+                                                    const uint32_t *__restrict__ idx,
+                                                    uint64_t *__restrict__ keys,
+                                                    uint16_t *__restrict__ vals)
+{
+    const int hop = N - 2 * halo, qm = N + hop;
+    const int64_t total = (int64_t)npairs * qm;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t p = e / qm;
+        const int q = (int)(e - p * qm);
+        const PairDesc pd = pairs[p];
+        const int qmax = pd.b_len > 0 ? qm : N;
+        const int64_t t = pd.a_start - halo + q;
+        const uint32_t k = (q < qmax && t >= pd.lo && t < pd.hi) ? idx[t] : kInvalidSample;
+        keys[e] = ((uint64_t)p << 32) | (uint64_t)k;
+        vals[e] = q < qmax ? (uint16_t)q : (uint16_t)0xFFFF;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_list_unpack(int64_t total,
+                                                      const uint64_t *__restrict__ keys,
+                                                      uint32_t *__restrict__ lst_k)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+        lst_k[e] = (uint32_t)(keys[e] & 0xFFFFFFFFull);
+}
+
 // W[t] = exp(-2 pi i t / N)
 __global__ void k_twiddles(int N, double2 *__restrict__ W)
 {
@@ -477,6 +550,10 @@ struct FusedOS {
     double2 *d_W = nullptr;
     double *d_Hperm = nullptr;
     size_t lds_bytes = 0;
+    // address-sorted gather lists of the tile-order path, built for one tile index at a time
+    const void *list_key = nullptr;
+    uint32_t *d_lst_k = nullptr;
+    uint16_t *d_lst_q = nullptr;
     // real-input variant (one segment of 8192 reals per workgroup, two workgroups per CU)
     bool real_variant = false;
     int64_t nsegs = 0;
@@ -488,7 +565,8 @@ struct FusedOS {
 void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
-    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm, f->d_segs, f->d_WM, f->d_WL, f->d_Hs};
+    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm, f->d_segs, f->d_WM, f->d_WL, f->d_Hs,
+                    f->d_lst_k, f->d_lst_q};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete f;
@@ -511,7 +589,8 @@ static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, do
     }
     const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
-        f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx, d_v, d_out);
+        f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx,
+        INDIRECT ? f->d_lst_k : nullptr, INDIRECT ? f->d_lst_q : nullptr, d_v, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -551,9 +630,54 @@ int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream
     return dispatch<false>(f, nullptr, d_v, d_out, stream);
 }
 
-int fused_os_apply_indexed(const FusedOS *f, const uint32_t *d_idx, const double *d_v,
-                           double *d_out, hipStream_t stream)
+static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
 {
+    if (f->d_lst_k) (void)hipFree(f->d_lst_k);
+    if (f->d_lst_q) (void)hipFree(f->d_lst_q);
+    f->d_lst_k = nullptr;
+    f->d_lst_q = nullptr;
+    f->list_key = nullptr;
+    const char *e = getenv("CM2_OS_LISTS");
+    if (f->real_variant || f->npairs == 0 || (e && atoi(e) == 0)) {
+        f->list_key = (const void *)d_idx;                   // per-sample index mode
+        return 0;
+    }
+    const int64_t qm = f->N + f->hop, total = f->npairs * qm;
+    uint64_t *keys_in = nullptr, *keys_out = nullptr;
+    uint16_t *vals_in = nullptr;
+    void *d_temp = nullptr;
+    CM2_HIP(hipMalloc(&keys_in, sizeof(uint64_t) * total));
+    CM2_HIP(hipMalloc(&keys_out, sizeof(uint64_t) * total));
+    CM2_HIP(hipMalloc(&vals_in, sizeof(uint16_t) * total));
+    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
+    k_list_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs, (int)f->npairs, f->N, f->halo,
+                                                       d_idx, keys_in, vals_in);
+    CM2_LAUNCH_OK();
+    int end_bit = 33;
+    while (((int64_t)1 << (end_bit - 32)) <= f->npairs && end_bit < 64) ++end_bit;
+    size_t tb = 0;
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, f->d_lst_q,
+                                               total, 0, end_bit, stream));
+    CM2_HIP(hipMalloc(&d_temp, tb + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, keys_in, keys_out, vals_in, f->d_lst_q,
+                                               total, 0, end_bit, stream));
+    k_list_unpack<<<grid_for(total), kBlock, 0, stream>>>(total, keys_out, f->d_lst_k);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(keys_in);
+    (void)hipFree(keys_out);
+    (void)hipFree(vals_in);
+    (void)hipFree(d_temp);
+    f->list_key = (const void *)d_idx;
+    return 0;
+}
+
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
+                           hipStream_t stream)
+{
+    if (f->list_key != (const void *)d_idx)
+        if (int rc = build_lists(f, d_idx, stream)) return rc;
     return dispatch<true>(f, d_idx, d_v, d_out, stream);
 }
 

@@ -539,6 +539,46 @@ def test_pcg_matches_oracle_iterations_and_solution(cm, oracle, pol, offdiag):
     assert rel_l2(inv * b, xo) < 1e-4 and inv.converged == 0
 
 
+def test_ritz_deflation_basis_speeds_up_pcg(cm, oracle):
+    """Arnoldi (M inner product) -> Ritz vectors -> CoarseLO -> fused M2, all in HBM."""
+    nt, npix, nb, pol = 60000, 400, 4, 3
+    rng = np.random.default_rng(8)
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    lam = 64
+    k = np.arange(lam)
+    band = 0.6 * np.exp(-k / 20.0)
+    band[0] = 1.0 + 2 * band[1:].sum() * 0.98           # nearly singular at DC: ill-conditioned A
+    band[1:] *= -1.0
+    N = cm.I.BlockLO(nt // nb, [band * (1 + 0.05 * b) for b in range(nb)], offdiag=True)
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    A = P.T * N * P
+    b = cm.torch.from_numpy(P.T * (N * d)).cuda()
+    r = 8
+    Z, theta = cm.I.ritz_deflation_basis(A, M, b, r, 40)
+    assert tuple(Z.shape) == (pol * n, r) and np.all(np.diff(theta) >= 0)
+    # the smallest Ritz pair approximates an eigenpair of M A
+    assert theta[0] > 0                                   # M A is SPD in the M^-1 inner product
+    z0 = Z[:, 0].contiguous()
+    res = (M * (A * z0)) - theta[0] * z0
+    assert float(res.norm() / z0.norm()) < 1e-3 * theta[-1]
+    AZ = cm.torch.empty_like(Z)
+    for j in range(r):
+        AZ[:, j] = A * Z[:, j].contiguous()
+    E = cm.I.CoarseLO(Z, AZ, r, apply='eig')
+    M2 = cm.I.TwoLevelPreconditionerLO(M, cm.I.DeflationLO(Z), cm.I.DeflationLO(AZ), E)
+    n1, n2 = [], []
+    x1, i1 = cm.cg(A, b, M=M, rtol=1e-8, maxiter=2000, callback=lambda xk: n1.append(1))
+    x2, i2 = cm.cg(A, b, M=M2, rtol=1e-8, maxiter=2000, callback=lambda xk: n2.append(1))
+    assert i1 == 0 and i2 == 0 and len(n2) <= len(n1)
+    assert float((x2 - x1).norm() / x1.norm()) < 1e-6
+    for j in range(r):                                    # deflated directions are solved exactly
+        zj = Z[:, j].contiguous()
+        assert float(((M2 * (A * zj)) - zj).norm() / zj.norm()) < 1e-8
+
+
 # ------------------------------------------------------- a12 two-level precond ---
 @pytest.mark.parametrize("pol", [1, 2, 3])
 def test_two_level_preconditioner_invariants(cm, pol):
