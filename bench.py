@@ -233,6 +233,19 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "algorithmic_bytes": dom_bytes,
                 "avg_launch_ms": round(dom_mean, 4)}
+    # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE need
+    # rocprofv3 passes of their own, so they are taken from the committed summary of this very
+    # command -- profiles/make_summary.py -- and only when the workload is the same)
+    try:
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_c4.json"))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+        if pmc["workload"] == cfg["label"] and pmc["nt_per_gpu"] == nt:
+            for kname, rec in pmc["kernels"].items():
+                if kname in dom and rec.get("hbm_traffic_bytes"):
+                    roofline["traffic"] = rec["hbm_traffic_bytes"]
+                    roofline["traffic_source"] = "profiles/" + pmcs[-1]
+    except Exception:
+        pass
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
     stage_report = {k: {"ms": round(v[0][0], 4), "GB/s": round(v[1] / (v[0][0] * 1e-3) / 1e9, 1)}
                     for k, v in stages.items()}

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""
+Condense rocprofv3 output of `bench.py` into the tracked summaries of a round.
+
+    python profiles/make_summary.py <dir with kt/ fetch/ write/ bench_default.json> <round tag>
+
+Expects (all produced on the MI355X box, see the command block written into the .md):
+  <dir>/kt/**/_kernel_stats.csv          rocprofv3 --kernel-trace --stats
+  <dir>/fetch/**/_counter_collection.csv rocprofv3 --pmc FETCH_SIZE   (own pass)
+  <dir>/write/**/_counter_collection.csv rocprofv3 --pmc WRITE_SIZE   (own pass)
+  <dir>/bench_default.json               un-profiled `python3 bench.py`
+Writes profiles/<tag>_bench_c4.json, <tag>_rocprofv3_kernel_stats_c4.csv, <tag>_pmc_c4.json/.md.
+FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE counts half the bytes of a
+wide coalesced read (MI355X_MICROARCH.md, HBM section), so HBM traffic = 2*FETCH + WRITE.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles", "k_PtNP_sell", "k_P_time", "k_Pt_sell"]
+
+
+def main(src, tag):
+    here = os.path.dirname(os.path.abspath(__file__))
+    bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+    json.dump(bench, open(os.path.join(here, tag + "_bench_c4.json"), "w"), indent=1)
+    ks = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(ks, os.path.join(here, tag + "_rocprofv3_kernel_stats_c4.csv"))
+    rows = list(csv.DictReader(open(ks)))
+
+    def counters(kind):
+        f = glob.glob(os.path.join(src, kind, "**", "*_counter_collection.csv"), recursive=True)[0]
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        # bench.py launches each hot kernel many times with identical work: take the median
+        return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}
+
+    fe, wr = counters("fetch"), counters("write")
+    nt = bench["config"]["nt_per_gpu"]
+    npix = bench["config"]["npix"]
+    alg = {"k_P_tiles": 28.0 * nt + 24 * npix, "k_overlap_save": 16.0 * nt,
+           "k_Pt_tiles": 28.0 * nt + 24 * npix, "k_PtNP_sell": 28.0 * nt + 48 * npix,
+           "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix}
+    table = {}
+    for r in rows:
+        for h in HOT:
+            if h in r["Name"] and int(r["Calls"]) > 2:
+                f = fe.get(r["Name"])
+                w = wr.get(r["Name"])
+                table[h] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                            "fetch_size_bytes": None if f is None else f * 1024,
+                            "write_size_bytes": None if w is None else w * 1024,
+                            "hbm_traffic_bytes": None if (f is None or w is None)
+                            else 2 * f * 1024 + w * 1024,
+                            "algorithmic_bytes": alg[h]}
+    out = {"workload": bench["config"]["workload"], "nt_per_gpu": nt, "kernels": table,
+           "note": "hbm_traffic_bytes = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE "
+                   "correction); separate --pmc passes"}
+    json.dump(out, open(os.path.join(here, tag + "_pmc_c4.json"), "w"), indent=1)
+
+    md = ["# rocprofv3 summary %s -- `python3 bench.py` (%s)" % (tag, bench["config"]["workload"]), "",
+          "Commands (MI355X box, after `cd /tmp && export TMPDIR=/tmp`):", "",
+          "    rocprofv3 --kernel-trace --stats -d out/kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-pcg",
+          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg",
+          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg",
+          "", "Full kernel table: `%s_rocprofv3_kernel_stats_c4.csv`; machine-readable: `%s_pmc_c4.json`." % (tag, tag),
+          "", "| kernel | calls | avg ms (rocprofv3) | 2*FETCH_SIZE GB | WRITE_SIZE GB | HBM traffic GB | algorithmic GB | GB/s algorithmic |",
+          "|---|---|---|---|---|---|---|---|"]
+    for h, t in table.items():
+        g = lambda b: "-" if b is None else "%.2f" % (b / 1e9)
+        md.append("| `%s` | %d | %.4f | %s | %s | %s | %.2f | %.0f |" % (
+            h, t["calls"], t["avg_ms"], g(None if t["fetch_size_bytes"] is None else 2 * t["fetch_size_bytes"]),
+            g(t["write_size_bytes"]), g(t["hbm_traffic_bytes"]), t["algorithmic_bytes"] / 1e9,
+            t["algorithmic_bytes"] / 1e9 / (t["avg_ms"] * 1e-3)))
+    md += ["", "bench.py HIP-event averages of the same kernels in the un-profiled run (`%s_bench_c4.json`): " % tag
+           + "; ".join("%s %.3f ms" % (k, v["ms"]) for k, v in bench["stages"].items()) + ".",
+           "Step: %.3f ms = %.3g samples/s = %.1f %% of the 8 TB/s HBM peak on 72 B/sample + 48 B/pixel."
+           % (bench["ms_per_step"], bench["value"], 100 * bench["step_frac_of_hbm_peak"])]
+    open(os.path.join(here, tag + "_pmc_c4.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md[10:]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
