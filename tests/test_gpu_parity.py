@@ -152,6 +152,50 @@ def test_tiled_pointing(cm, oracle, pol, nt, npix, tp):
         L.set_pointing_mode("auto")
 
 
+def test_full_size_properties_c2(cm):
+    """BASELINE config C2 at full size (nside 128 IQU, 1e7 samples, diagonal N, generated in
+    HBM): size-independent identities instead of an oracle run -- P^T P 1 = hit counts
+    (exact integers), fused chain == stepwise chain (bit for bit), tiled chain == exact chain
+    (rounding), symmetry x.Ay = y.Ax, M_BD A x = x, linearity."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    from cosmomap2_amd import device as D
+    t = cm.torch
+    nside, nt, nb, pol = 128, 10_000_000, 100, 3
+    npix = 12 * nside * nside
+    g = t.Generator(device="cuda").manual_seed(20161203)
+    pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
+    phi = 0.7 + (2 * np.pi * 2.5 / 200.0) * t.arange(nt, device="cuda", dtype=t.float64)
+    wts = list(np.random.default_rng(1).random(nb) + 0.5)
+    N = cm.I.BlockLO(nt // nb, wts)
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi, w=N._device_diag())
+    n = ces.get_new_pixel[0]
+    assert n == npix                                   # ~51 hits per pixel: nothing is removed
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    hits = t.bincount(pix.long(), minlength=npix).double()
+    P1 = cm.I.SparseLO(n, nt, pix, pol=1)
+    assert t.equal(P1.T * (P1 * t.ones(n, dtype=t.float64, device="cuda")), hits)
+    x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64)
+    y = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64)
+    A = P.T * N * P
+    Ax = A * x
+    assert t.equal(Ax, P.T * (N * (P * x)))            # fused kernel == three stages
+    Ay = A * y
+    dots = D.dot(y, Ax), D.dot(x, Ay)
+    assert abs(dots[0] - dots[1]) <= 1e-12 * abs(dots[0])
+    assert float((M * Ax - x).norm() / x.norm()) < 1e-12          # diagonal N: M_BD = A^-1
+    lin = A * (2.0 * x + y) - (2.0 * Ax + Ay)
+    assert float(lin.norm() / Ax.norm()) < 1e-14
+    # the same pointing with a short Toeplitz band: tile-bucketed chain vs exact chain
+    band = [np.array([1.0 + 0.01 * b, 0.25, -0.05]) for b in range(nb)]
+    Nt = cm.I.BlockLO(nt // nb, band, offdiag=True)
+    exact = P.T * (Nt * (P * x))
+    tiled = L._TiledNormalLO(P, Nt) * x
+    assert float((tiled - exact).norm() / exact.norm()) < 1e-13
+    assert L._use_tiles(P)                              # >= 2^20 samples: the default takes it
+    assert float(((P.T * Nt * P) * x - exact).norm() / exact.norm()) < 1e-13
+
+
 def test_pointing_errors(cm):
     with pytest.raises(RuntimeError):
         cm.I.SparseLO(10, 20, np.zeros(20, dtype=np.int32), pol=4)      # linearoperators.py:549
