@@ -225,6 +225,7 @@ class _TiledNormalLO(_DeviceOp):
     def __init__(self, P, noise):
         self.P, self.noise = P, noise
         self._fused_noise = None
+        self._work = None
         n = P.pol * P.ncols
         super(_TiledNormalLO, self).__init__(n, n, self._mult, symmetric=True)
 
@@ -236,13 +237,16 @@ class _TiledNormalLO(_DeviceOp):
             raise lp.ShapeError("map vector has %d entries, expected %d"
                                 % (x.numel(), P.pol * P.ncols))
         st = D.stream()
-        d_tb = D.empty(max(T.nvalid, 1))
+        if self._work is None or self._work[0].numel() != max(T.nvalid, 1):
+            # TOD-sized scratch is kept for the life of the operator (two buffers of nvalid
+            # doubles): a PCG calls this every iteration and large hipMallocs are slow
+            self._work = (D.empty(max(T.nvalid, 1)), D.empty(max(T.nvalid, 1)))
+        d_tb, v_tb = self._work
         _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)
         if self._fused_noise is None:
             self._fused_noise = self.noise.noise_info()["method"] == 3
         if self._fused_noise:
             # overlap-save kernel reads and writes the tile order directly
-            v_tb = D.empty(max(T.nvalid, 1))
             _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
                       D.ptr(v_tb), st)
             out = D.empty(P.pol * P.ncols)
