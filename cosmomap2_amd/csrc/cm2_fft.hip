@@ -106,33 +106,23 @@ __device__ __forceinline__ void radix_pass(double *__restrict__ pre, double *__r
                 xi[m] *= h;
             }
         }
-        // twiddles w^m, w = exp(-2 pi i (N/n) j / N): one table load, powers by
-        // squaring / one multiplication (depth <= 2 log2 R, error a few ulp)
-        double wr[R], wi[R];
-        if (TWIDDLE) {
-            const double2 w1 = W[((N / n) * j) & (N - 1)];
-            wr[1] = w1.x;
-            wi[1] = w1.y;
-#pragma unroll
-            for (int m = 2; m < R; ++m) {
-                if ((m & 1) == 0) {
-                    const double a = wr[m / 2], b = wi[m / 2];
-                    wr[m] = a * a - b * b;
-                    wi[m] = 2.0 * a * b;
-                } else {
-                    wr[m] = wr[m - 1] * w1.x - wi[m - 1] * w1.y;
-                    wi[m] = wr[m - 1] * w1.y + wi[m - 1] * w1.x;
-                }
-            }
-        }
+        // twiddles w^m, w = exp(-2 pi i (N/n) j / N): one table load, powers by a running
+        // product so that only one of them is live at a time (register pressure; the rounding
+        // error grows linearly, ~R ulp, far below the 1e-12 budget)
+        double2 w1 = double2{1.0, 0.0};
+        if (TWIDDLE) w1 = W[((N / n) * j) & (N - 1)];
         if (!INVERSE) {
             dft_regs<R>(xr, xi);
+            double cr = 1.0, ci = 0.0;
 #pragma unroll
             for (int m = 0; m < R; ++m) {
                 double yr = xr[brev<R>(m)], yi = xi[brev<R>(m)];
                 if (TWIDDLE && m > 0) {
-                    const double tr = yr * wr[m] - yi * wi[m];
-                    yi = yr * wi[m] + yi * wr[m];
+                    const double nr = cr * w1.x - ci * w1.y;
+                    ci = cr * w1.y + ci * w1.x;
+                    cr = nr;
+                    const double tr = yr * cr - yi * ci;
+                    yi = yr * ci + yi * cr;
                     yr = tr;
                 }
                 const int a = base + m * s;
@@ -141,10 +131,14 @@ __device__ __forceinline__ void radix_pass(double *__restrict__ pre, double *__r
             }
         } else {
             if (TWIDDLE) {
+                double cr = 1.0, ci = 0.0;
 #pragma unroll
                 for (int m = 1; m < R; ++m) {
-                    const double tr = xr[m] * wr[m] + xi[m] * wi[m];      // times conj(w^m)
-                    xi[m] = xi[m] * wr[m] - xr[m] * wi[m];
+                    const double nr = cr * w1.x - ci * w1.y;
+                    ci = cr * w1.y + ci * w1.x;
+                    cr = nr;
+                    const double tr = xr[m] * cr + xi[m] * ci;            // times conj(w^m)
+                    xi[m] = xi[m] * cr - xr[m] * ci;
                     xr[m] = tr;
                 }
             }
