@@ -49,6 +49,20 @@ static inline int grid_for(int64_t n, int block = kBlock, int max_blocks = kNumC
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Scratch allocation of a setup routine: freed on every exit path (the CM2_HIP / CM2_CHECK
+// macros return early on failure).  keep() hands the buffer over to a longer-lived owner.
+template <typename T>
+struct DevTemp {
+    T *p = nullptr;
+    DevTemp() = default;
+    DevTemp(const DevTemp &) = delete;
+    DevTemp &operator=(const DevTemp &) = delete;
+    ~DevTemp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * (count ? count : 1)); }
+    T *keep() { T *q = p; p = nullptr; return q; }
+    operator T *() const { return p; }
+};
+
 // full-wave sum via DPP-friendly shuffles (64 lanes), result valid in lane 0
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -637,12 +637,12 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
         return 0;
     }
     const int64_t qm = f->N + f->hop, total = f->npairs * qm;
-    uint64_t *keys_in = nullptr, *keys_out = nullptr;
-    uint16_t *vals_in = nullptr;
-    void *d_temp = nullptr;
-    CM2_HIP(hipMalloc(&keys_in, sizeof(uint64_t) * total));
-    CM2_HIP(hipMalloc(&keys_out, sizeof(uint64_t) * total));
-    CM2_HIP(hipMalloc(&vals_in, sizeof(uint16_t) * total));
+    DevTemp<uint64_t> keys_in, keys_out;
+    DevTemp<uint16_t> vals_in;
+    DevTemp<char> d_temp;
+    CM2_HIP(keys_in.alloc(total));
+    CM2_HIP(keys_out.alloc(total));
+    CM2_HIP(vals_in.alloc(total));
     CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
     CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
     k_list_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs, (int)f->npairs, f->N, f->halo,
@@ -651,18 +651,14 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
     int end_bit = 33;
     while (((int64_t)1 << (end_bit - 32)) <= f->npairs && end_bit < 64) ++end_bit;
     size_t tb = 0;
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, f->d_lst_q,
-                                               total, 0, end_bit, stream));
-    CM2_HIP(hipMalloc(&d_temp, tb + 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, keys_in, keys_out, vals_in, f->d_lst_q,
-                                               total, 0, end_bit, stream));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               f->d_lst_q, total, 0, end_bit, stream));
+    CM2_HIP(d_temp.alloc(tb + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               f->d_lst_q, total, 0, end_bit, stream));
     k_list_unpack<<<grid_for(total), kBlock, 0, stream>>>(total, keys_out, f->d_lst_k);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(keys_in);
-    (void)hipFree(keys_out);
-    (void)hipFree(vals_in);
-    (void)hipFree(d_temp);
     f->list_key = (const void *)d_idx;
     return 0;
 }

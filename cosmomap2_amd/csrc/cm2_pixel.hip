@@ -69,10 +69,8 @@ extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const i
     CM2_CHECK(pol != 3 || (d_cosine && d_sine), "cm2_weights_accumulate: NULL output");
     hipStream_t stream = as_stream(stream_);
     PixIndex ix;
-    if (int rc = build_pixindex(ix, d_pix, nt, npix, stream)) {
-        ix.release();
-        return rc;
-    }
+    struct IxGuard { PixIndex *ix; ~IxGuard() { ix->release(); } } guard{&ix};
+    if (int rc = build_pixindex(ix, d_pix, nt, npix, stream)) return rc;
     const int g = grid_for(npix);
 #define CM2_W(POL)                                                                          \
     k_weights<POL><<<g, kBlock, 0, stream>>>(npix, ix.d_ptr, ix.d_sorted_t, d_w, d_cos,     \
@@ -82,7 +80,6 @@ extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const i
 #undef CM2_W
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    ix.release();
     return 0;
 }
 
@@ -152,16 +149,16 @@ extern "C" int cm2_pixel_compact(int64_t npix, const uint8_t *d_keep, int32_t *d
 {
     CM2_CHECK(d_keep && d_old2new && h_new_npix, "cm2_pixel_compact: NULL argument");
     hipStream_t stream = as_stream(stream_);
-    int32_t *flags = nullptr;
-    void *d_temp = nullptr;
+    DevTemp<int32_t> flags;
+    DevTemp<char> d_temp;
     size_t tb = 0;
-    CM2_HIP(hipMalloc(&flags, sizeof(int32_t) * (npix + 1)));
+    CM2_HIP(flags.alloc(npix + 1));
     k_keep_to_i32<<<grid_for(npix), kBlock, 0, stream>>>(npix, d_keep, flags);
     CM2_LAUNCH_OK();
     // exclusive prefix sum of the keep flags = rank among kept pixels
-    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, d_old2new, npix, stream));
-    CM2_HIP(hipMalloc(&d_temp, tb + 16));
-    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb, flags, d_old2new, npix, stream));
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags.p, d_old2new, npix, stream));
+    CM2_HIP(d_temp.alloc(tb + 16));
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb, flags.p, d_old2new, npix, stream));
     int32_t last_rank = 0;
     uint8_t last_keep = 0;
     CM2_HIP(hipMemcpyAsync(&last_rank, d_old2new + (npix - 1), sizeof(int32_t),
@@ -172,8 +169,6 @@ extern "C" int cm2_pixel_compact(int64_t npix, const uint8_t *d_keep, int32_t *d
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
     *h_new_npix = (int64_t)last_rank + (last_keep ? 1 : 0);
-    (void)hipFree(flags);
-    (void)hipFree(d_temp);
     return 0;
 }
 

@@ -59,14 +59,14 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
         CM2_HIP(hipStreamSynchronize(stream));
         return 0;
     }
-    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
-    unsigned int *d_bad = nullptr;
-    void *d_temp = nullptr;
-    CM2_HIP(hipMalloc(&keys_in, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&keys_out, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&vals_in, sizeof(uint32_t) * nt));
+    DevTemp<uint32_t> keys_in, keys_out, vals_in;
+    DevTemp<unsigned int> d_bad;
+    DevTemp<char> d_temp;
+    CM2_HIP(keys_in.alloc(nt));
+    CM2_HIP(keys_out.alloc(nt));
+    CM2_HIP(vals_in.alloc(nt));
     CM2_HIP(hipMalloc(&ix.d_sorted_t, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&d_bad, sizeof(unsigned int)));
+    CM2_HIP(d_bad.alloc(1));
     CM2_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream));
     k_make_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, keys_in, vals_in, d_bad);
     CM2_LAUNCH_OK();
@@ -74,11 +74,11 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
     int end_bit = 1;
     while (((int64_t)1 << end_bit) <= npix) ++end_bit;   // keys take values 0..npix
     size_t temp_bytes = 0;
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in,
-                                               ix.d_sorted_t, nt, 0, end_bit, stream));
-    CM2_HIP(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, keys_in, keys_out, vals_in,
-                                               ix.d_sorted_t, nt, 0, end_bit, stream));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in.p, keys_out.p,
+                                               vals_in.p, ix.d_sorted_t, nt, 0, end_bit, stream));
+    CM2_HIP(d_temp.alloc(temp_bytes + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, temp_bytes, keys_in.p, keys_out.p,
+                                               vals_in.p, ix.d_sorted_t, nt, 0, end_bit, stream));
     k_lower_bound<<<grid_for(npix + 1), kBlock, 0, stream>>>(keys_out, nt, npix, ix.d_ptr);
     CM2_LAUNCH_OK();
 
@@ -88,11 +88,6 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
     CM2_HIP(hipMemcpyAsync(&h_nvalid, ix.d_ptr + npix, sizeof(int64_t), hipMemcpyDeviceToHost,
                            stream));
     CM2_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(keys_in);
-    (void)hipFree(keys_out);
-    (void)hipFree(vals_in);
-    (void)hipFree(d_bad);
-    (void)hipFree(d_temp);
     CM2_CHECK(h_bad == 0, "%u samples have a pixel id outside [-1, npix=%lld)", h_bad,
               (long long)npix);
     ix.nvalid = h_nvalid;

@@ -339,27 +339,32 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
     p->nslots = ((npix + 63) / 64) * 64;
     p->nslices = p->nslots / 64;
 
-    int32_t *cnt_in = nullptr, *ids_in = nullptr;
-    int64_t *d_len = nullptr;
-    void *d_temp = nullptr;
+    struct PlanGuard {             // frees the half-built plan and the pixel index on early return
+        cm2_pointing *plan;
+        PixIndex *ix;
+        ~PlanGuard() { if (plan) free_plan(plan); ix->release(); }
+    } guard{p, &ix};
+    DevTemp<int32_t> cnt_in, ids_in;
+    DevTemp<int64_t> d_len;
+    DevTemp<char> d_temp;
     size_t tb1 = 0, tb2 = 0;
-    CM2_HIP(hipMalloc(&cnt_in, sizeof(int32_t) * npix));
-    CM2_HIP(hipMalloc(&ids_in, sizeof(int32_t) * npix));
+    CM2_HIP(cnt_in.alloc(npix));
+    CM2_HIP(ids_in.alloc(npix));
     CM2_HIP(hipMalloc(&p->d_sell_pix, sizeof(int32_t) * p->nslots));
     CM2_HIP(hipMalloc(&p->d_sell_cnt, sizeof(int32_t) * p->nslots));
     CM2_HIP(hipMalloc(&p->d_slice_ptr, sizeof(int64_t) * (p->nslices + 1)));
-    CM2_HIP(hipMalloc(&d_len, sizeof(int64_t) * (p->nslices + 1)));
+    CM2_HIP(d_len.alloc(p->nslices + 1));
     k_counts<<<grid_for(npix), kBlock, 0, stream>>>(ix.d_ptr, npix, cnt_in, ids_in);
     CM2_LAUNCH_OK();
     // pixels by descending hit count (stable): equal-length lanes share a slice
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb1, cnt_in, p->d_sell_cnt,
-                                                         ids_in, p->d_sell_pix, npix, 0, 32,
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb1, cnt_in.p, p->d_sell_cnt,
+                                                         ids_in.p, p->d_sell_pix, npix, 0, 32,
                                                          stream));
-    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_len, p->d_slice_ptr,
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_len.p, p->d_slice_ptr,
                                              p->nslices + 1, stream));
-    CM2_HIP(hipMalloc(&d_temp, (tb1 > tb2 ? tb1 : tb2) + 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_temp, tb1, cnt_in, p->d_sell_cnt,
-                                                         ids_in, p->d_sell_pix, npix, 0, 32,
+    CM2_HIP(d_temp.alloc((tb1 > tb2 ? tb1 : tb2) + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_temp.p, tb1, cnt_in.p, p->d_sell_cnt,
+                                                         ids_in.p, p->d_sell_pix, npix, 0, 32,
                                                          stream));
     if (p->nslots > npix) {
         k_pad_slots<<<1, kBlock, 0, stream>>>(npix, p->nslots, p->d_sell_pix, p->d_sell_cnt);
@@ -368,8 +373,8 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
     k_slice_len<<<(int)((p->nslices + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
         p->d_sell_cnt, p->nslices, d_len);
     CM2_LAUNCH_OK();
-    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb2, d_len, p->d_slice_ptr, p->nslices + 1,
-                                             stream));
+    CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb2, d_len.p, p->d_slice_ptr,
+                                             p->nslices + 1, stream));
     CM2_HIP(hipMemcpyAsync(&p->sell_len, p->d_slice_ptr + p->nslices, sizeof(int64_t),
                            hipMemcpyDeviceToHost, stream));
     CM2_HIP(hipStreamSynchronize(stream));
@@ -390,11 +395,7 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
 #undef CM2_FILL
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(cnt_in);
-    (void)hipFree(ids_in);
-    (void)hipFree(d_len);
-    (void)hipFree(d_temp);
-    ix.release();
+    guard.plan = nullptr;          // success: the caller owns the plan (the index is still released)
     *out = p;
     return 0;
 }

@@ -240,6 +240,8 @@ static int tile_block()
 }
 
 // ------------------------------------------------------------------ C ABI -------
+extern "C" int cm2_tiles_destroy(cm2_tiles *t);
+
 extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
@@ -266,28 +268,29 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     CM2_CHECK(slice_samples >= 256, "cm2_tiles_create: slice too short");
     hipStream_t stream = as_stream(stream_);
     cm2_tiles *t = new cm2_tiles();
+    struct Guard { cm2_tiles *t; ~Guard() { if (t) cm2_tiles_destroy(t); } } guard{t};
     t->nt = nt; t->npix = npix; t->pol = pol; t->tp = tile_pixels;
     t->ntiles = (npix + tile_pixels - 1) / tile_pixels;
 
-    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *tb_src = nullptr;
-    int64_t *d_off = nullptr;
-    void *d_temp = nullptr;
-    CM2_HIP(hipMalloc(&keys_in, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&keys_out, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&vals_in, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&tb_src, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&d_off, sizeof(int64_t) * (t->ntiles + 1)));
+    DevTemp<uint32_t> keys_in, keys_out, vals_in, tb_src;
+    DevTemp<int64_t> d_off;
+    DevTemp<char> d_temp;
+    CM2_HIP(keys_in.alloc(nt));
+    CM2_HIP(keys_out.alloc(nt));
+    CM2_HIP(vals_in.alloc(nt));
+    CM2_HIP(tb_src.alloc(nt));
+    CM2_HIP(d_off.alloc(t->ntiles + 1));
     k_tile_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, tile_pixels, (uint32_t)t->ntiles,
                                                      keys_in, vals_in);
     CM2_LAUNCH_OK();
     int end_bit = 1;
     while (((int64_t)1 << end_bit) <= t->ntiles) ++end_bit;
     size_t tb = 0;
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, tb_src, nt,
-                                               0, end_bit, stream));
-    CM2_HIP(hipMalloc(&d_temp, tb + 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, keys_in, keys_out, vals_in, tb_src, nt,
-                                               0, end_bit, stream));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               tb_src.p, nt, 0, end_bit, stream));
+    CM2_HIP(d_temp.alloc(tb + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               tb_src.p, nt, 0, end_bit, stream));
     k_tile_bounds<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
         keys_out, nt, t->ntiles, d_off);
     CM2_LAUNCH_OK();
@@ -332,12 +335,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         CM2_HIP(hipMemcpy(t->d_item_k1, it_k1.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
     }
     CM2_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(keys_in);
-    (void)hipFree(keys_out);
-    (void)hipFree(vals_in);
-    (void)hipFree(tb_src);
-    (void)hipFree(d_off);
-    (void)hipFree(d_temp);
+    guard.t = nullptr;
     *out = t;
     return 0;
 }
