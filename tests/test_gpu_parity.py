@@ -316,6 +316,61 @@ def test_toeplitz_real_input_fft_variant(cm, oracle, monkeypatch):
     assert rel_l2(Np * v, ref) < 1e-12
 
 
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_toeplitz_tiny_and_ragged_blocks(cm, oracle, method):
+    """Blocks shorter than the band, of length 1, and ragged sizes: zero boundary everywhere."""
+    rng = np.random.default_rng(31 + method)
+    for lam, sizes in [(33, [5, 1, 7, 100, 2]), (9, [3, 3, 3]), (130, [64, 700, 129, 1]),
+                       (600, [599, 601, 50])]:
+        k = np.arange(lam)
+        bands = [np.exp(-k / (0.3 * lam)) * (1.0 + 0.1 * b) for b in range(len(sizes))]
+        v = rng.standard_normal(sum(sizes))
+        ref = oracle.blocklo_mult(sizes, bands, True, v)
+        N = cm.I.BlockLO(sizes, bands, offdiag=True, method=method)
+        got = N * v
+        if method == 1:
+            np.testing.assert_array_equal(got, ref)
+        else:
+            assert rel_l2(got, ref) < 1e-12, (lam, sizes)
+
+
+@pytest.mark.parametrize("pol", [1, 3])
+def test_pointing_degenerate_shapes(cm, oracle, pol):
+    """One sample, wave-size boundaries, one hot pixel holding almost every sample, a noise
+    block whose samples are all flagged -- exact and tile-bucketed forms against the oracle."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(17)
+    cases = []
+    for nt in (1, 63, 64, 65, 257):
+        cases.append((nt, 3, rng.integers(0, 3, nt).astype(np.int32)))
+    hot = rng.integers(0, 200, 50000).astype(np.int32)
+    hot[rng.random(50000) < 0.9] = 77                      # 90 % of the samples in one pixel
+    cases.append((50000, 200, hot))
+    dead = rng.integers(0, 130, 4000).astype(np.int32)
+    dead[1000:2000] = -1                                    # second noise block fully flagged
+    cases.append((4000, 130, dead))
+    for nt, npix, pairs in cases:
+        phi = oracle.angles_gen(0.4, nt)
+        c, s = np.cos(2 * phi), np.sin(2 * phi)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        x = rng.standard_normal(pol * npix)
+        v = rng.standard_normal(nt)
+        np.testing.assert_array_equal(P * x, oracle.sparse_mult(pol, pairs, c, s, x))
+        np.testing.assert_array_equal(P.T * v, oracle.sparse_rmult(pol, npix, pairs, c, s, v))
+        if nt >= 4:
+            sizes = [nt // 4] * 3 + [nt - 3 * (nt // 4)]
+            bands = [np.array([1.0, 0.3, -0.1][:min(3, max(1, sz))]) for sz in sizes]
+            bands = [np.pad(b, (0, 3 - len(b))) for b in bands]
+            N = cm.I.BlockLO(sizes, bands, offdiag=True)
+            exact = P.T * (N * (P * x))
+            tiled = L._TiledNormalLO(P, N) * x
+            denom = np.linalg.norm(exact)
+            # the per-pixel terms are added in a different order (LDS atomics): a pixel that
+            # sums 45 000 terms of both signs loses ~sqrt(n) ulp to cancellation
+            assert np.linalg.norm(tiled - exact) <= 1e-11 * max(denom, 1.0)
+
+
 def test_blocklo_diag_and_errors(cm, oracle):
     sizes = 2 * [500, 400, 124]
     t = list(np.random.default_rng(2).random(6))
