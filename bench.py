@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
+    ap.add_argument("--no-filters", action="store_true",
+                    help="skip the FilterLO / GroundFilterLO timing (SURVEY 8f rows)")
     ap.add_argument("--deflation", type=int, default=32,
                     help="rank of the deflation space of the two-level PCG run (0 = skip)")
     ap.add_argument("--arnoldi-steps", type=int, default=96)
@@ -299,6 +301,31 @@ def main():
                                 "smallest_ritz": float(theta[0]), "largest_kept_ritz": float(theta[-1]),
                                 "rel_l2_vs_block_diagonal_solution": rel}
 
+    # ---- 8(f) rows: sub-scan and ground filters on the same TOD (rank 0, untimed extras) ----
+    filters = None
+    if rank == 0 and world == 1 and not args.no_filters:
+        from cosmomap2_amd.interfaces import FilterLO, GroundFilterLO
+        sub, gap = 2000, 40                       # sub-scan and turnaround lengths (samples)
+        starts = np.arange(0, bsize - sub + 1, sub + gap)
+        sizes = np.full(starts.size, sub)
+        pix_f = pix.clone()
+        pix_f[torch.rand(nt, generator=gen, device=dev) < 0.05] = -1
+        filters = {"subscan_samples": sub, "chunks": int(starts.size) * nb, "flag_fraction": 0.05,
+                   "algorithmic_bytes_per_sample": 20}
+        for order in (0, 2):
+            F = FilterLO(nt, [sizes, starts], bsize, nb, pix_f, poly_order=order)
+            mean_ms, med_ms = ev_time(lambda: F * d, reps)
+            filters["poly%d_ms" % order] = round(med_ms, 4)
+            filters["poly%d_GBps" % order] = round(20.0 * nt / (med_ms * 1e-3) / 1e9, 1)
+            del F
+        az = ((torch.arange(nt, device=dev, dtype=torch.int64) % (2 * (sub + gap))) - (sub + gap)
+              ).abs().to(torch.int32)             # triangle-wave azimuth -> sub+gap+1 ground bins
+        Fg = GroundFilterLO(az)
+        mean_ms, med_ms = ev_time(lambda: Fg * d, reps)
+        filters["ground_bins"] = Fg.nbins
+        filters["ground_ms"] = round(med_ms, 4)
+        del Fg, az, pix_f
+
     # ---- CPU baseline: the oracle (1 core, reference-unfused) on a bounded sample -----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -352,6 +379,7 @@ def main():
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "stages": stage_report,
             "pcg": pcg,
+            "filters": filters,
             "cpu_baseline": cpu,
             "setup_seconds": round(t_setup, 2),
         }

@@ -68,6 +68,13 @@ PROTOTYPES = {
     "cm2_cos_sin_2phi": [_i64, _vp, _vp, _vp, _vp],
     "cm2_m2_finish": [_int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp, _vp],
+    "cm2_filter_create": [ctypes.POINTER(_vp), _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _i64,
+                          _vp],
+    "cm2_filter_destroy": [_vp],
+    "cm2_filter_info": [_vp, _vp],
+    "cm2_filter_apply": [_vp, _vp, _vp, _vp],
+    "cm2_ground_bin_sums": [_i64, _int, _vp, _vp, _vp, _vp],
+    "cm2_ground_subtract": [_i64, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPE = {"cm2_last_error": ctypes.c_char_p, "cm2_reduce_work_doubles": _i64,
             "cm2_gemm_tn_work_doubles": _i64}

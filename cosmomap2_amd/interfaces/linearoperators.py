@@ -27,7 +27,7 @@ torch = D.torch
 
 __all__ = ["SparseLO", "ToeplitzLO", "BlockLO", "BlockDiagonalLO",
            "BlockDiagonalPreconditionerLO", "InverseLO", "CoarseLO", "DeflationLO",
-           "TwoLevelPreconditionerLO", "set_pointing_mode", "lp"]
+           "TwoLevelPreconditionerLO", "FilterLO", "GroundFilterLO", "set_pointing_mode", "lp"]
 
 _I64P = ctypes.POINTER(ctypes.c_int64)
 _DBLP = ctypes.POINTER(ctypes.c_double)
@@ -744,3 +744,214 @@ class TwoLevelPreconditionerLO(_DeviceOp):
                   *(w.ptrs() + [D.ptr(self.Mbd._d_det), D.ptr(self.Mbd._d_mask), D.ptr(out),
                                 D.stream()]))
         return D.like_input(out, x)
+
+
+# ==================================================================== FilterLO ===
+def filter_plan(subscans, tstart, nsamples, nbolos, poly_order, legendres):
+    """Host-side set-up of :class:`FilterLO` (index arithmetic only, no TOD data).
+
+    Returns ``(starts, lens, table_off, table)`` as cm2_filter_create wants them.
+    Chunks follow the loops of linearoperators.py:134-140 (CES -> detector pair ->
+    sub-scan) and are then put in ascending order.  For poly_order > 0 ``table`` is the
+    concatenation of one Legendre block per distinct chunk length (``legendres[n]``,
+    :206-213) and ``table_off[s]`` the offset of chunk s's block.
+    """
+    starts, lens = [], []
+    offset = 0
+    for subsc, ts, ns, nb in zip(subscans, tstart, nsamples, nbolos):
+        sub = np.asarray(subsc, dtype=np.int64).reshape(-1)
+        t0 = np.asarray(ts, dtype=np.int64).reshape(-1)
+        if sub.size != t0.size:
+            raise lp.ShapeError("%d sub-scan sizes but %d sub-scan starts" % (sub.size, t0.size))
+        bolo = np.arange(int(nb), dtype=np.int64)[:, None] * int(ns) + offset
+        starts.append((t0[None, :] + bolo).reshape(-1))
+        lens.append(np.tile(sub, int(nb)))
+        offset += int(nb) * int(ns)
+    starts = np.concatenate(starts) if starts else np.zeros(0, dtype=np.int64)
+    lens = np.concatenate(lens) if lens else np.zeros(0, dtype=np.int64)
+    order = np.argsort(starts, kind="stable")
+    starts, lens = np.ascontiguousarray(starts[order]), np.ascontiguousarray(lens[order])
+    if poly_order == 0:
+        return starts, lens, None, None
+
+    K = poly_order + 1
+    table_off = np.zeros(starts.size, dtype=np.int64)
+    blocks, at = [], 0
+    for n in np.unique(lens):
+        n = int(n)
+        if n == 0:
+            continue
+        L = np.ascontiguousarray(legendres[n], dtype=np.float64)
+        if L.shape != (n, K):
+            raise lp.ShapeError("Legendre table for length %d has shape %r" % (n, L.shape))
+        blocks.append(L.reshape(-1))
+        table_off[lens == n] = at
+        at += n * K
+    table = np.concatenate(blocks) if blocks else np.zeros(0)
+    return starts, lens, table_off, table
+
+
+class _FilterHandle(object):
+    def __init__(self, handle, keep):
+        self.h = handle
+        self.keep = keep                   # tensors the C side borrows
+
+    def __del__(self):
+        if self.h:
+            try:
+                _hip.load().cm2_filter_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class FilterLO(_DeviceOp):
+    """
+    Sub-scan filter of a time stream (reference: linearoperators.py:94-283).
+
+    ``FilterLO(size, subscan_nsample, samples_per_bolopair, bolos_per_ces, pix_samples,
+    poly_order=0, npool=4)``: ``subscan_nsample = [sizes, starts]`` of the sub-scans of
+    one detector pair (lists of such arrays, with lists of ``samples_per_bolopair`` /
+    ``bolos_per_ces``, for several CES, :263-273).  ``poly_order=0`` subtracts the mean
+    of the unflagged samples of each chunk (``mult``, :129-168); ``poly_order>0``
+    removes the Legendre polynomials up to that order (``polyfilter_multithreads`` ->
+    ``globalprocsfilter``, :246-261, :286-322).  Flagged samples (pixel < 0) do not
+    enter the fit.  ``npool`` sized the reference's multiprocessing pool and is
+    ignored: one wavefront per chunk does the work.
+
+    The flags are snapshotted at construction (the reference re-reads ``pix_samples``
+    on every call).  Chunks must not overlap.
+    """
+
+    def __init__(self, size, subscan_nsample, samples_per_bolopair, bolos_per_ces, pix_samples,
+                 poly_order=0, npool=4):
+        self.n = int(size)
+        self.nsamples = samples_per_bolopair
+        self.nbolos = bolos_per_ces
+        self.subscans = subscan_nsample[0]
+        self.tstart = subscan_nsample[1]
+        if not (type(self.nsamples) is list):
+            self.nsamples = [self.nsamples]
+            self.nbolos = [self.nbolos]
+            self.subscans = [self.subscans]
+            self.tstart = [self.tstart]
+        self.pixels = pix_samples
+        self.poly_order = int(poly_order)
+        if self.poly_order < 0:
+            raise ValueError("poly_order must be >= 0, got %r" % (poly_order,))
+        if self.poly_order > 7:
+            raise ValueError("poly_order up to 7 is supported, got %d" % self.poly_order)
+        D.require_gpu()
+        self._d_pix = D.i32(pix_samples)
+        if self._d_pix.numel() != self.n:
+            raise lp.ShapeError("pix_samples has %d entries, expected size=%d"
+                                % (self._d_pix.numel(), self.n))
+        self._handles = {}
+        if self.poly_order > 0:
+            self.compute_legendres()
+        mv = self.mult if self.poly_order == 0 else self.polyfilter_multithreads
+        self._plan_for(self.poly_order)
+        super(FilterLO, self).__init__(nargin=self.n, nargout=self.n, matvec=mv, symmetric=False)
+
+    def compute_legendres(self):
+        """``self.legendres = {chunk length: normalised Legendre table}`` (:206-213)."""
+        from ..utilities.linear_algebra_funcs import get_legendre_polynomials
+        sizes = []
+        for array in self.subscans:
+            for i in np.asarray(array).reshape(-1):
+                if int(i) not in sizes:
+                    sizes.append(int(i))
+        self.legendres = {n: get_legendre_polynomials(self.poly_order, n) for n in sizes}
+
+    def _plan_for(self, order):
+        h = self._handles.get(order)
+        if h is not None:
+            return h
+        starts, lens, toff, table = filter_plan(
+            self.subscans, self.tstart, self.nsamples, self.nbolos, order,
+            getattr(self, "legendres", None))
+        if starts.size and (starts[0] < 0 or (starts + lens).max() > self.n):
+            raise lp.ShapeError("a sub-scan chunk lies outside the %d samples" % self.n)
+        p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        handle = ctypes.c_void_p()
+        _hip.call("cm2_filter_create", ctypes.byref(handle), self.n, int(starts.size), p(starts),
+                  p(lens), D.ptr(self._d_pix), int(order), p(toff), p(table),
+                  0 if table is None else int(table.size), D.stream())
+        h = self._handles[order] = _FilterHandle(handle, self._d_pix)
+        return h
+
+    def filter_info(self):
+        info = (ctypes.c_int64 * 7)()
+        _hip.call("cm2_filter_info", self._plan_for(self.poly_order).h, info)
+        return dict(nt=info[0], nchunks=info[1], poly_order=info[2], covered=info[3],
+                    skipped=info[4], unflagged=info[5], flagged=info[6])
+
+    def _apply(self, order, d):
+        x = D.f64(d)
+        if x.numel() != self.n:
+            raise lp.ShapeError("time-domain vector has %d entries, expected %d"
+                                % (x.numel(), self.n))
+        out = D.empty(self.n)
+        _hip.call("cm2_filter_apply", self._plan_for(order).h, D.ptr(x), D.ptr(out), D.stream())
+        return D.like_input(out, d)
+
+    def mult(self, d):
+        """Offset removal per chunk (:129-168), whatever ``poly_order`` is."""
+        return self._apply(0, d)
+
+    def polyfilter(self, d):
+        """Legendre filtering up to ``poly_order`` (:170-204)."""
+        if self.poly_order == 0:
+            raise AttributeError("polyfilter needs poly_order > 0 (no Legendre tables were built)")
+        return self._apply(self.poly_order, d)
+
+    polyfilter_multithreads = polyfilter
+
+
+# ============================================================== GroundFilterLO ===
+class GroundFilterLO(_DeviceOp):
+    """
+    Ground-template filter ``v - G (G^T G)^-1 G^T v`` (reference: linearoperators.py:24-61):
+    ``ground[t]`` is the azimuth bin of sample t (-1 = none), ``G`` the pol=1 pointing
+    onto ``max(ground)+1`` bins and ``(G^T G)^-1`` the inverse hit count per bin (empty
+    bins give 0, :788-790).
+    """
+
+    def counts_in_groundbins(self, g):
+        """Samples per ground bin (:26-46), as the GPU scatter of a vector of ones."""
+        ones = D.empty(self.n)
+        ones.fill_(1.0)
+        return D.to_host(self._bin_sums(ones))
+
+    LDS_BINS = 8192          # cm2_ground_bin_sums keeps one histogram per workgroup in LDS
+
+    def _bin_sums(self, x):
+        """G^T x: LDS histogram when the bins fit, else the pixel-major P^T of SparseLO."""
+        if self.nbins > self.LDS_BINS:
+            return self._G.rmult(x)
+        sums = D.empty(self.nbins)
+        _hip.call("cm2_ground_bin_sums", self.n, self.nbins, D.ptr(self._G._d_pix), D.ptr(x),
+                  D.ptr(sums), D.stream())
+        return sums
+
+    def mult(self, v):
+        x = D.f64(v)
+        if x.numel() != self.n:
+            raise lp.ShapeError("time-domain vector has %d entries, expected %d"
+                                % (x.numel(), self.n))
+        binned = self._invGtG.mult(self._bin_sums(x))
+        out = D.empty(self.n)
+        _hip.call("cm2_ground_subtract", self.n, D.ptr(self._G._d_pix), D.ptr(binned), D.ptr(x),
+                  D.ptr(out), D.stream())
+        return D.like_input(out, v)
+
+    def __init__(self, ground):
+        g = ground.detach().cpu().numpy() if D.is_tensor(ground) else np.asarray(ground)
+        self.nbins = int(g.max()) + 1
+        self.n = len(g)
+        self._G = G = SparseLO(self.nbins, self.n, ground)
+        G.counts = self.counts_in_groundbins(ground)
+        self._invGtG = invGtG = BlockDiagonalPreconditionerLO(G, self.nbins)
+        self.Pg = G * invGtG * G.T
+        super(GroundFilterLO, self).__init__(nargin=self.n, nargout=self.n, matvec=self.mult,
+                                             symmetric=True)

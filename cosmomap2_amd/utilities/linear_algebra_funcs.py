@@ -5,6 +5,8 @@
 * ``dgemm(A, B)``    = ``A.T @ B.T``   (BLAS gemm with a=A.T, trans_b -- :27-29)
 * ``norm2(q)``       = ``||q||_2``     (BLAS nrm2 -- :31-37)
 * ``scalprod(a, b)`` = ``a . b``       (BLAS dot -- :39-44)
+* ``get_legendre_polynomials(polyorder, size)``: set-up table of FilterLO (:47-59),
+  a few KB built once on the host (the filter itself runs on the GPU)
 
 NumPy inputs are uploaded and the result comes back as NumPy / float; tensors already
 in HBM are used in place (``dgemm`` then returns a tensor).
@@ -18,7 +20,7 @@ from .. import device as D
 
 torch = D.torch
 
-__all__ = ["dgemm", "norm2", "scalprod"]
+__all__ = ["dgemm", "norm2", "scalprod", "get_legendre_polynomials"]
 
 
 def dgemm(A, B):
@@ -57,3 +59,16 @@ def norm2(q):
     """Euclidean norm."""
     dq = D.f64(q).reshape(-1)
     return math.sqrt(D.dot(dq, dq))
+
+
+def get_legendre_polynomials(polyorder, size):
+    """``size x (polyorder+1)`` matrix whose columns are the Legendre polynomials on
+    ``linspace(-1, 1, size)``, each scaled to unit 2-norm (reference :47-59)."""
+    from scipy.linalg import get_blas_funcs
+    from scipy.special import legendre
+    legendres = np.empty([size, polyorder + 1])
+    x = np.linspace(-1, 1, size)
+    for i in range(polyorder + 1):
+        col = legendre(i)(x)
+        legendres[:, i] = col / get_blas_funcs('nrm2', (col,))(col)
+    return legendres

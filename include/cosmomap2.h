@@ -239,6 +239,57 @@ int cm2_m2_finish(int pol, int64_t npix, int r, const double *d_Z, const double 
                   const double *d_sin2, const double *d_sincos, const double *d_det,
                   const uint8_t *d_mask, double *d_out, void *stream);
 
+/* ---- f1: sub-scan filtering of a time stream --------------------------------
+ * Replaces FilterLO (interfaces/linearoperators.py:94-322).  The time stream is
+ * cut into `nseg` chunks (one per CES x detector pair x sub-scan, the loops at
+ * :134-140); h_start must be ascending and the chunks must not overlap.
+ * Samples outside every chunk are 0 in the output (vec_out = d*0, :130).
+ * Flags (pixel id < 0) are read from d_pix at create time and at every apply;
+ * they must not change in between (the per-chunk bases below depend on them).
+ *
+ * order == 0  (FilterLO.mult :129-168): out = d - mean(unflagged d) on every
+ *   sample of the chunk; a chunk without unflagged samples (or with a non-finite
+ *   mean) stays 0.  h_table_off/h_table are ignored (may be NULL).
+ * order  > 0  (globalprocsfilter :286-322): K = order+1 (K <= 8).  h_table holds
+ *   one n x K row-major block of normalised Legendre columns for every distinct
+ *   chunk length n (get_legendre_polynomials, utilities/linear_algebra_funcs.py:
+ *   47-59); h_table_off[s] is the offset (in doubles) of chunk s's block.  Per chunk,
+ *   with m the number of unflagged samples:
+ *     m <= order : chunk left at 0 (:303-304);
+ *     m == n     : out = d - sum_k <L_k,d> L_k with the table columns as they are
+ *                  (:317-321);
+ *     otherwise  : out = d - Q Q^T d on the unflagged samples and 0 on the flagged
+ *                  ones, Q an orthonormal basis of the polynomials of degree <= order
+ *                  on the unflagged samples (:307-315, where Q comes from
+ *                  qr(legendres[unflagged])).  Here Q is built once at create time
+ *                  from the three-term recurrence of the discrete orthogonal
+ *                  polynomials of those samples; same projector, and no loss of
+ *                  orthogonality when the restricted Legendre block is ill
+ *                  conditioned. */
+typedef struct cm2_filter cm2_filter;
+int cm2_filter_create(cm2_filter **out, int64_t nt, int64_t nseg, const int64_t *h_start,
+                      const int64_t *h_len, const int32_t *d_pix, int order,
+                      const int64_t *h_table_off, const double *h_table, int64_t table_len,
+                      void *stream);
+void cm2_filter_destroy(cm2_filter *f);
+/* info[7] = nt, nseg, order, samples inside chunks, then (order > 0) the number of
+ * chunks skipped / without flags / with flags */
+int cm2_filter_info(const cm2_filter *f, int64_t *info);
+/* d_out = F d_in (nt doubles each; d_out must not alias d_in) */
+int cm2_filter_apply(const cm2_filter *f, const double *d_in, double *d_out, void *stream);
+
+/* ---- f2: ground-template filter  (GroundFilterLO, :24-61) --------------------
+ * d_out[t] = d_v[t] - binned[d_bin[t]]   (d_out[t] = d_v[t] where d_bin[t] < 0),
+ * the last step of v - G (G^T G)^-1 G^T v once binned = (G^T G)^-1 G^T v has
+ * been formed with cm2_Pt_apply and cm2_bdprecond_apply (pol = 1). */
+/* d_sums[b] = sum of d_v[t] over the samples with d_bin[t] == b  (G^T v, pol = 1) for
+ * nbins <= 8192: LDS histogram per workgroup, then atomic adds -- the order of the terms
+ * is not fixed (equal to the serial loop :394-400 to rounding).  More bins: cm2_Pt_apply. */
+int cm2_ground_bin_sums(int64_t nt, int nbins, const int32_t *d_bin, const double *d_v,
+                        double *d_sums, void *stream);
+int cm2_ground_subtract(int64_t nt, const int32_t *d_bin, const double *d_binned,
+                        const double *d_v, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,3 +209,28 @@ void orc_PtNP_diag(int pol, int64_t nt, int64_t npix, const int32_t *pix,
     for (i = 0; i < nt; ++i) tod[i] = w[i] * tod[i];
     orc_Pt_apply(pol, nt, npix, pix, c, s, tod, out);
 }
+
+/* ---- f1: FilterLO, poly_order = 0: per-sub-scan offset removal
+ *      (interfaces/linearoperators.py:129-168; the inline C at :141-156 is the
+ *      sequential masked mean).  seg_start/seg_len list every (bolo, sub-scan)
+ *      chunk in the order the Python loops visit them.  A chunk with no
+ *      unflagged sample has mean 0/0 = NaN and is skipped (:163-164): its
+ *      output stays 0.  Otherwise EVERY sample of the chunk, flagged ones
+ *      included, gets d - mean (:165).  `out` must be zero on entry (:130).  ---- */
+void orc_filter_mean(int64_t nseg, const int64_t *seg_start, const int64_t *seg_len,
+                     const int32_t *pix, const double *d, double *out)
+{
+    int64_t s, j;
+    for (s = 0; s < nseg; ++s) {
+        const int64_t a = seg_start[s], b = a + seg_len[s];
+        double mean = 0., counter = 0.;
+        for (j = a; j < b; ++j) {
+            if (pix[j] == -1) continue;
+            mean += d[j];
+            counter += 1.;
+        }
+        mean = mean / counter;
+        if (isnan(mean) || isinf(mean)) continue;
+        for (j = a; j < b; ++j) out[j] = d[j] - mean;
+    }
+}

@@ -457,3 +457,115 @@ def system_setup(rng, nt, npix, nb, bandsize=2):
     t = [rng.random(bandsize) for _ in range(nb)]
     diag = [ti[0] for ti in t]
     return d, pairs, phi, t, diag
+
+
+# --------------------------------------------------------------------------
+# f1  FilterLO  (interfaces/linearoperators.py:94-322)
+# --------------------------------------------------------------------------
+def filter_normalise_args(subscan_nsample, samples_per_bolopair, bolos_per_ces):
+    """__init__ :263-273: scalars (one CES) are wrapped into one-element lists."""
+    nsamples, nbolos = samples_per_bolopair, bolos_per_ces
+    subscans, tstart = subscan_nsample[0], subscan_nsample[1]
+    if not isinstance(nsamples, list):
+        nsamples, nbolos, subscans, tstart = [nsamples], [nbolos], [subscans], [tstart]
+    return subscans, tstart, nsamples, nbolos
+
+
+def filter_segments(subscans, tstart, nsamples, nbolos):
+    """(start, length) of every chunk in the visiting order of the loops at
+    :134-140 / :175-182: CES -> detector pair -> sub-scan."""
+    starts, lens = [], []
+    offset = 0
+    for subsc, ts, ns, nb in zip(subscans, tstart, nsamples, nbolos):
+        for bolo_iter in range(int(nb)):
+            for i, j in zip(subsc, ts):
+                starts.append(int(j) + int(ns) * bolo_iter + offset)
+                lens.append(int(i))
+        offset += int(nb) * int(ns)
+    return np.asarray(starts, dtype=np.int64), np.asarray(lens, dtype=np.int64)
+
+
+def get_legendre_polynomials(polyorder, size):
+    """utilities/linear_algebra_funcs.py:47-59: columns L_k(linspace(-1,1,size))/||.||_2"""
+    from scipy.special import legendre
+    out = np.empty([size, polyorder + 1])
+    x = np.linspace(-1, 1, size)
+    for i in range(polyorder + 1):
+        L = legendre(i)
+        out[:, i] = L(x) / norm2(L(x))
+    return out
+
+
+def filter_mean(d, pixs, subscan_nsample, samples_per_bolopair, bolos_per_ces):
+    """FilterLO.mult :129-168 (poly_order = 0) through orc_filter_mean."""
+    starts, lens = filter_segments(*filter_normalise_args(
+        subscan_nsample, samples_per_bolopair, bolos_per_ces))
+    d = _f64(d)
+    pix = _i32(pixs)
+    out = np.zeros_like(d)
+    lib().orc_filter_mean(ctypes.c_int64(len(starts)), starts.ctypes.data_as(_I64),
+                          lens.ctypes.data_as(_I64), pix.ctypes.data_as(_I32), _d(d), _d(out))
+    return out
+
+
+def filter_poly(d, pixs, subscan_nsample, samples_per_bolopair, bolos_per_ces, poly_order):
+    """poly_order > 0: polyfilter_multithreads -> globalprocsfilter :286-322
+    (same arithmetic as polyfilter :170-204): per chunk, with `valid` the
+    unflagged samples (:301-302):
+      * fewer than poly_order+1 valid samples -> chunk left at 0 (:303-304);
+      * some flagged: basis = Q of qr(legendres[valid]) (:307-308), projection
+        removed on the valid samples only, flagged ones stay 0 (:310-315);
+      * none flagged: basis = the normalised Legendre columns themselves
+        (NOT re-orthogonalised), d - sum_k <L_k,d> L_k on the chunk (:317-321)."""
+    subscans, tstart, nsamples, nbolos = filter_normalise_args(
+        subscan_nsample, samples_per_bolopair, bolos_per_ces)
+    starts, lens = filter_segments(subscans, tstart, nsamples, nbolos)
+    d = _f64(d)
+    valid = np.asarray(pixs) >= 0                                    # :256
+    legendres = {}
+    for n in lens:                                                   # :206-213
+        if int(n) not in legendres:
+            legendres[int(n)] = get_legendre_polynomials(poly_order, int(n))
+    out = d * 0.
+    for a, n in zip(starts, lens):
+        b = a + n
+        m = valid[a:b]
+        size = int(np.count_nonzero(m))
+        if size <= poly_order:
+            continue
+        basis = legendres[int(n)]
+        if size != n:
+            basis, _ = np.linalg.qr(basis[m])
+            dd = d[a:b][m]
+        else:
+            dd = d[a:b]
+        p = np.zeros(size)
+        for k in range(poly_order + 1):
+            fb = basis[:, k]
+            p += scalprod(fb, dd) * fb
+        if size != n:
+            seg = out[a:b]
+            seg[m] = dd - p
+        else:
+            out[a:b] = dd - p
+    return out
+
+
+# --------------------------------------------------------------------------
+# f2  GroundFilterLO  (interfaces/linearoperators.py:24-61)
+# --------------------------------------------------------------------------
+def ground_filter(ground, v):
+    """v - G (G^T G)^-1 G^T v with G the pol=1 pointing of the ground-bin ids
+    (:52-60): nbins = max(ground)+1 (:50), bins nobody hit invert to 0 through
+    BlockDiagonalPreconditionerLO's pol=1 branch (:788-790)."""
+    ground = np.asarray(ground)
+    nbins = int(ground.max()) + 1
+    ok = ground >= 0
+    hits = np.bincount(ground[ok], minlength=nbins).astype(np.float64)
+    gtv = np.bincount(ground[ok], weights=np.asarray(v, dtype=np.float64)[ok], minlength=nbins)
+    inv = np.zeros(nbins)
+    nz = hits != 0
+    inv[nz] = 1. / hits[nz]
+    binned = inv * gtv
+    back = np.where(ok, binned[np.where(ok, ground, 0)], 0.)
+    return v - back

@@ -26,6 +26,7 @@ from types import SimpleNamespace
 
 import numpy as np
 import scipy.linalg
+import scipy.special
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_golden.npz")
@@ -259,6 +260,42 @@ def main():
         G["arn_nonfinite_raises"] = np.int64(1)
     out0 = quiet(dl["arnoldi"], op, Aar.dot(np.ones(n)), x0=np.ones(n), tol=1e-5)
     G["arn_zero_residual_returns_j0"] = np.int64(out0[2] == 0 and out0[0] is None)
+
+    # ---- FilterLO, poly_order>0: interfaces/linearoperators.py:170-213 and
+    #      utilities/linear_algebra_funcs.py:47-59.  polyfilter is the serial twin of
+    #      the Pool worker globalprocsfilter (:286-322, needs Python 2's time.clock);
+    #      the poly_order=0 path (:129-168) is a weave loop and is not run here.
+    rngf = np.random.default_rng(20161203)
+    la2 = extract("utilities/linear_algebra_funcs.py", ["get_legendre_polynomials"],
+                  {"np": np, "legendre": scipy.special.legendre, "norm2": la["norm2"]})
+    G["leg_3_17"] = la2["get_legendre_polynomials"](3, 17)
+    G["leg_1_2"] = la2["get_legendre_polynomials"](1, 2)
+    fbase = {"np": np, "scalprod": la["scalprod"],
+             "get_legendre_polynomials": la2["get_legendre_polynomials"]}
+    fl = extract("interfaces/linearoperators.py",
+                 ["FilterLO.polyfilter", "FilterLO.compute_legendres"], fbase)
+    subscans = [np.array([40, 55, 40, 50]), np.array([60, 30, 50, 3])]
+    tstart = [np.array([3, 45, 102, 145]), np.array([0, 62, 95, 146])]
+    nsamples, nbolos = [200, 150], [3, 2]
+    ntf = 200 * 3 + 150 * 2
+    pixf = rngf.integers(0, 50, size=ntf).astype(np.int64)
+    pixf[rngf.random(ntf) < 0.12] = -1
+    pixf[3:43] = -1                              # a fully flagged chunk
+    pixf[200 + 45:200 + 100] = -1                # a chunk with 2 valid samples only
+    pixf[200 + 50] = 7
+    pixf[200 + 77] = 9
+    pixf[400 + 102:400 + 142] = np.abs(pixf[400 + 102:400 + 142])   # chunks without any flag
+    pixf[600:660] = np.abs(pixf[600:660])
+    df = rngf.standard_normal(ntf) + 0.01 * np.arange(ntf)
+    G["filt_subscan0"], G["filt_subscan1"] = subscans
+    G["filt_tstart0"], G["filt_tstart1"] = tstart
+    G["filt_nsamples"], G["filt_nbolos"] = np.array(nsamples), np.array(nbolos)
+    G["filt_pix"], G["filt_d"] = pixf, df
+    for order in (1, 2, 3):
+        me = SimpleNamespace(subscans=subscans, tstart=tstart, nsamples=nsamples, nbolos=nbolos,
+                             pixels=pixf, poly_order=order)
+        fl["FilterLO.compute_legendres"](me)
+        G["filt_out%d" % order] = fl["FilterLO.polyfilter"](me, df.copy())
 
     np.savez_compressed(OUT, **G)
     print("wrote %s (%d arrays, %d bytes)" % (OUT, len(G), os.path.getsize(OUT)))

@@ -733,3 +733,199 @@ def test_two_level_preconditioner_invariants(cm, pol):
     x2, i2 = cm.cg(A, b, M=M2f, tol=1e-8, callback=lambda xk: n2.append(1))
     assert i1 == 0 and i2 == 0 and len(n2) <= len(n1) + 1
     assert rel_l2(x2, x1) < 1e-6
+
+
+# ------------------------------------------------------------- f1: FilterLO -------
+def _golden_filter_args(golden):
+    ss = [[golden["filt_subscan0"], golden["filt_subscan1"]],
+          [golden["filt_tstart0"], golden["filt_tstart1"]]]
+    return ss, [int(x) for x in golden["filt_nsamples"]], [int(x) for x in golden["filt_nbolos"]]
+
+
+def _structural_zeros(oracle, nt, pix, ss, ns, nb, order):
+    """Samples the filter must leave at exactly 0 (gaps, skipped chunks, flagged samples of
+    the Legendre fit): those at 0 for two unrelated inputs."""
+    z = np.ones(nt, dtype=bool)
+    for seed in (1, 2):
+        x = np.random.default_rng(seed).standard_normal(nt) + 10.0
+        f = (oracle.filter_mean(x, pix, ss, ns, nb) if order == 0 else
+             oracle.filter_poly(x, pix, ss, ns, nb, order))
+        z &= f == 0
+    return z
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_filter_lo_against_reference_vectors(cm, oracle, golden, order):
+    ss, ns, nb = _golden_filter_args(golden)
+    d, pix = golden["filt_d"], golden["filt_pix"]
+    F = cm.I.FilterLO(d.size, ss, ns, nb, pix, poly_order=order)
+    y = F * d
+    if order == 0:
+        ref = oracle.filter_mean(d, pix, ss, ns, nb)        # weave loop: oracle only
+    else:
+        ref = golden["filt_out%d" % order]                  # the reference's polyfilter output
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-13 * np.abs(d).max())
+    assert not y[_structural_zeros(oracle, d.size, pix, ss, ns, nb, order)].any()
+    assert F.filter_info()["nchunks"] == 20
+    if order:
+        np.testing.assert_array_equal(F.legendres[40], oracle.get_legendre_polynomials(order, 40))
+        np.testing.assert_allclose(F.mult(d), oracle.filter_mean(d, pix, ss, ns, nb), atol=1e-12)
+
+
+def _random_scan(rng, nces, lo=150, hi=900):
+    subs, ts, ns, nb = [], [], [], []
+    for _ in range(nces):
+        nsub = int(rng.integers(5, 40))
+        sizes = rng.integers(lo, hi, size=nsub)
+        gaps = rng.integers(0, 60, size=nsub)
+        starts = np.cumsum(gaps + np.concatenate([[0], sizes[:-1]]))
+        subs.append(sizes)
+        ts.append(starts)
+        ns.append(int(starts[-1] + sizes[-1] + rng.integers(0, 50)))
+        nb.append(int(rng.integers(2, 9)))
+    return subs, ts, ns, nb
+
+
+@pytest.mark.parametrize("order", [0, 1, 3, 7])
+def test_filter_lo_random_scans(cm, oracle, order):
+    rng = np.random.default_rng(100 + order)
+    subs, ts, ns, nb = _random_scan(rng, 6)
+    nt = int(sum(a * b for a, b in zip(ns, nb)))
+    pix = rng.integers(0, 1000, size=nt).astype(np.int32)
+    pix[rng.random(nt) < 0.1] = -1
+    blk = rng.integers(0, nt - 3000)
+    pix[blk:blk + 3000] = -1                               # a long flagged stretch
+    d = rng.standard_normal(nt) + 3.0 + 1e-3 * np.arange(nt)
+    F = cm.I.FilterLO(nt, [subs, ts], ns, nb, pix, poly_order=order)
+    ref = (oracle.filter_mean(d, pix, [subs, ts], ns, nb) if order == 0 else
+           oracle.filter_poly(d, pix, [subs, ts], ns, nb, order))
+    y = F * d
+    # Chunk by chunk: the reference orthonormalises legendres[unflagged] by QR, whose span is
+    # accurate to cond * eps; the kernel's recurrence basis is orthonormal to rounding.  So the
+    # two agree to ~1e-14 * cond relative to the chunk's input (which rides on an offset + ramp
+    # of ~400 that the filter removes), and to 1e-14 where no flag or no inverse is involved.
+    starts, lens = oracle.filter_segments(*oracle.filter_normalise_args([subs, ts], ns, nb))
+    worst = 0.0
+    for a, n in zip(starts, lens):
+        m = pix[a:a + n] >= 0
+        cond = 1.0
+        if order and order < m.sum() < n:
+            cond = np.linalg.cond(oracle.get_legendre_polynomials(order, int(n))[m])
+        err = np.linalg.norm(y[a:a + n] - ref[a:a + n])
+        worst = max(worst, err / (1e-14 * cond * np.linalg.norm(d[a:a + n])))
+    assert worst < 20.0, worst
+    assert not y[_structural_zeros(oracle, nt, pix, [subs, ts], ns, nb, order)].any()
+    # device-resident input -> device-resident output, identical numbers
+    yd = F * cm.torch.from_numpy(d).cuda()
+    assert yd.is_cuda
+    np.testing.assert_array_equal(yd.cpu().numpy(), y)
+    # filtering twice changes nothing where the basis is orthonormal on the kept samples
+    if order == 0:
+        assert rel_l2(F * y, y) < 1e-13
+
+
+def test_filter_lo_conventions_and_errors(cm, oracle):
+    from cosmomap2_amd._hip import HipError
+    rng = np.random.default_rng(9)
+    nt, ns, nb = 3000, 1000, 3
+    pix = rng.integers(0, 50, size=nt).astype(np.int64)
+    pix[::7] = -1
+    d = rng.standard_normal(nt)
+    sizes, starts = np.array([300, 250, 400]), np.array([10, 320, 590])
+    # one CES given as scalars (:269-273), sub-scans listed out of order
+    F = cm.I.FilterLO(nt, [sizes[::-1], starts[::-1]], ns, nb, pix, poly_order=2)
+    ref = oracle.filter_poly(d, pix, [sizes, starts], ns, nb, 2)
+    assert rel_l2(F * d, ref) < 1e-12
+    # no chunk at all: everything is filtered to 0 (:130)
+    F0 = cm.I.FilterLO(nt, [np.array([], dtype=int), np.array([], dtype=int)], ns, nb, pix)
+    assert not (F0 * d).any()
+    # zero-length and one-sample chunks; a chunk whose samples are all flagged
+    p2 = pix.copy()
+    p2[100:140] = -1
+    F1 = cm.I.FilterLO(nt, [np.array([0, 1, 40, 5]), np.array([3, 50, 100, 200])], ns, nb, p2)
+    np.testing.assert_allclose(F1 * d, oracle.filter_mean(
+        d, p2, [np.array([0, 1, 40, 5]), np.array([3, 50, 100, 200])], ns, nb), atol=1e-14)
+    with pytest.raises(HipError):                          # overlapping chunks
+        cm.I.FilterLO(nt, [np.array([300, 300]), np.array([0, 200])], ns, nb, pix)
+    with pytest.raises(Exception):                         # chunk past the end
+        cm.I.FilterLO(nt, [np.array([300]), np.array([900])], ns, nb, pix)
+    with pytest.raises(Exception):
+        cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix[:-1])
+    with pytest.raises(Exception):
+        F * d[:-1]
+
+
+def test_filter_lo_in_operator_products(cm, oracle):
+    """Mbd * P.T * F * d as in the reference's src/test_poly.py:121-140."""
+    rng = np.random.default_rng(21)
+    pol, npix, ns, nb = 3, 300, 4000, 5
+    nt = ns * nb
+    d, pairs, phi, t, diag = make_problem(oracle, 77, nt, npix, nb, pol, flag_frac=0.05)
+    sizes, starts = np.array([900, 950, 1000, 1000]), np.array([20, 940, 1900, 2950])
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    CES = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n2 = CES.get_new_pixel[0]
+    P = cm.I.SparseLO(n2, nt, pairs, pol=pol, angle_processed=CES)
+    Mbd = cm.I.BlockDiagonalPreconditionerLO(CES, n2, pol)
+    F1 = cm.I.FilterLO(nt, [sizes, starts], ns, nb, P.pairs, poly_order=1)
+    m = Mbd * P.T * F1 * d
+    fd = oracle.filter_poly(d, po, [sizes, starts], ns, nb, 1)
+    ref = oracle.bd_precond_mult(pol, ro, oracle.sparse_rmult(pol, ro.new_npix, po, ro.cos,
+                                                              ro.sin, fd))
+    assert rel_l2(m, ref) < 1e-12
+
+
+def test_filter_lo_full_size_properties(cm):
+    """2e7 samples, 40000 chunks: zero mean of the kept samples in every chunk, flagged samples
+    and gaps at 0, linearity, and F(F d) = F d for the QR-orthonormalised chunks."""
+    torch = cm.torch
+    rng = np.random.default_rng(1)
+    ns, nb, L = 100000, 200, 500
+    nt = ns * nb
+    starts = np.arange(0, ns, L)
+    sizes = np.full(starts.size, L - 10)                   # a 10-sample gap after every chunk
+    pix = rng.integers(0, 1 << 20, size=nt).astype(np.int32)
+    pix[rng.random(nt) < 0.08] = -1
+    d = torch.from_numpy(rng.standard_normal(nt) + 5.0).cuda()
+    e = torch.from_numpy(rng.standard_normal(nt)).cuda()
+    valid = torch.from_numpy(pix >= 0).cuda()
+    F0 = cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=0)
+    F2 = cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=2)
+    y0, y2 = F0 * d, F2 * d
+    gaps = torch.ones(nt, dtype=torch.bool, device="cuda").view(-1, L)
+    gaps[:, :L - 10] = False
+    assert not y0.view(-1, L)[gaps].any() and not y2.view(-1, L)[gaps].any()
+    assert not y2[~valid].any()
+    kept = torch.where(valid, y0, torch.zeros_like(y0)).view(-1, L).sum(dim=1)
+    assert kept.abs().max().item() < 1e-10
+    kept2 = torch.where(valid, y2, torch.zeros_like(y2)).view(-1, L).sum(dim=1)
+    assert kept2.abs().max().item() < 1e-10                # order >= 0 removes the offset too
+    lin = F2 * (d + 0.5 * e)
+    assert (lin - y2 - 0.5 * (F2 * e)).abs().max().item() < 1e-11
+    assert (F2 * y2 - y2).abs().max().item() < 1e-11       # every chunk here has flags -> Q Q^T
+    assert (F0 * y0 - y0).abs().max().item() < 1e-12
+
+
+# -------------------------------------------------------- f2: GroundFilterLO ------
+@pytest.mark.parametrize("nbins", [400, 9000])           # LDS histogram / pixel-major P^T
+def test_ground_filter_lo(cm, nbins):
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    nt = 200000
+    g = rng.integers(-1, nbins, size=nt)
+    g[g == 17] = 18                                        # an empty bin -> 1/0 guarded (:788-790)
+    g[-1] = nbins - 1
+    v = rng.standard_normal(nt)
+    Fg = cm.I.GroundFilterLO(g)
+    assert Fg.nbins == nbins and Fg.n == nt
+    ref = O.ground_filter(g, v)
+    y = Fg * v
+    assert rel_l2(y, ref) < 1e-13
+    np.testing.assert_array_equal(y[g == -1], v[g == -1])
+    assert rel_l2(Fg.Pg * v, v - ref) < 1e-12              # the explicit product of :57
+    np.testing.assert_array_equal(Fg.counts_in_groundbins(g),
+                                  np.bincount(g[g >= 0], minlength=nbins).astype(float))
+    yd = Fg * cm.torch.from_numpy(v).cuda()
+    assert rel_l2(yd.cpu().numpy(), y) < 1e-14             # atomic order differs run to run
+    assert rel_l2(Fg * y, y) < 1e-12                       # projector

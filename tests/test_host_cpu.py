@@ -40,12 +40,16 @@ def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from cosmomap2_amd import _hip, cg
-    from cosmomap2_amd.interfaces import SparseLO, BlockLO, ToeplitzLO, DeflationLO
+    from cosmomap2_amd.interfaces import (SparseLO, BlockLO, ToeplitzLO, DeflationLO, FilterLO,
+                                          GroundFilterLO)
     from cosmomap2_amd.utilities import ProcessTimeSamples, norm2
     for make in (lambda: SparseLO(10, 20, np.zeros(20, dtype=np.int32)),
                  lambda: BlockLO(10, [1.0, 2.0]),
                  lambda: ToeplitzLO(np.ones(2), 10),
                  lambda: DeflationLO(np.ones((10, 2))),
+                 lambda: FilterLO(20, [np.array([5]), np.array([0])], 10, 2,
+                                  np.zeros(20, dtype=np.int32)),
+                 lambda: GroundFilterLO(np.zeros(20, dtype=np.int32)),
                  lambda: ProcessTimeSamples(np.zeros(20, dtype=np.int32), 10),
                  lambda: norm2(np.ones(4)),
                  lambda: cg(np.eye(3), np.ones(3))):
@@ -150,3 +154,61 @@ def test_generators_and_helpers_match_reference(golden):
     j = int(G["arn_j"])
     cols = [H[:q + 2, q].copy() for q in range(j - 1)] + [np.concatenate([H[:, j - 1], [0.0]])]
     np.testing.assert_array_equal(build_hess(cols, j), H)
+
+
+def _stieltjes_basis(x, K):
+    """NumPy statement of what k_filter_setup builds per flagged chunk: the orthonormal
+    polynomials of the point set x by the three-term recurrence."""
+    P, nrm, alpha, beta = [np.ones(x.size)], [float(x.size)], [], [0.0]
+    for k in range(K - 1):
+        alpha.append(np.dot(x * P[k], P[k]) / nrm[k])
+        nxt = (x - alpha[k]) * P[k] - (beta[k] * P[k - 1] if k else 0.0)
+        P.append(nxt)
+        nrm.append(np.dot(nxt, nxt))
+        beta.append(nrm[k + 1] / nrm[k])
+    return np.array([p / np.sqrt(n) for p, n in zip(P, nrm)]).T
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_filter_plan_reproduces_reference_polyfilter(golden, order):
+    """The set-up FilterLO hands to the library (sorted chunks, shared Legendre tables) and
+    the kernel's formula (table columns for chunks without flags, recurrence-built
+    orthonormal polynomials for the others), evaluated with NumPy, against the reference's
+    polyfilter output."""
+    from cosmomap2_amd.interfaces.linearoperators import filter_plan
+    from cosmomap2_amd.utilities.linear_algebra_funcs import get_legendre_polynomials
+    subs = [golden["filt_subscan0"], golden["filt_subscan1"]]
+    ts = [golden["filt_tstart0"], golden["filt_tstart1"]]
+    ns, nb = list(golden["filt_nsamples"]), list(golden["filt_nbolos"])
+    d, valid = golden["filt_d"], golden["filt_pix"] >= 0
+    K = order + 1
+    leg = {int(n): get_legendre_polynomials(order, int(n)) for a in subs for n in a}
+    st, ln, toff, table = filter_plan(subs, ts, ns, nb, order, leg)
+    assert (np.diff(st) > 0).all() and st.size == 3 * 4 + 2 * 4
+    out = np.zeros_like(d)
+    for s in range(st.size):
+        a, n = st[s], ln[s]
+        m = valid[a:a + n]
+        T = table[toff[s]:toff[s] + n * K].reshape(n, K)
+        np.testing.assert_array_equal(T, leg[int(n)])
+        if m.sum() <= order:
+            continue
+        if m.all():
+            out[a:a + n] = d[a:a + n] - T @ (T.T @ d[a:a + n])
+            continue
+        j = np.nonzero(m)[0]
+        Q = _stieltjes_basis((2.0 * j - (j[0] + j[-1])) / (j[-1] - j[0]), K)
+        np.testing.assert_allclose(Q.T @ Q, np.eye(K), atol=1e-13)
+        out[a:a + n][m] = d[a:a + n][m] - Q @ (Q.T @ d[a:a + n][m])
+    np.testing.assert_allclose(out, golden["filt_out%d" % order], rtol=0, atol=1e-12)
+
+
+def test_filter_plan_order0_and_ces_offsets():
+    from cosmomap2_amd.interfaces.linearoperators import filter_plan
+    st, ln, toff, table = filter_plan(
+        [np.array([4, 3]), np.array([5])], [np.array([1, 6]), np.array([2])], [10, 8], [2, 3],
+        0, None)
+    # CES 0: pairs at 0 and 10; CES 1 starts at 20: pairs at 20, 28, 36
+    assert list(st) == [1, 6, 11, 16, 22, 30, 38]
+    assert list(ln) == [4, 3, 4, 3, 5, 5, 5]
+    assert toff is None and table is None

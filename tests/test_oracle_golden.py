@@ -152,3 +152,61 @@ def test_cg_recurrence_equals_local_scipy(oracle):
         np.testing.assert_array_equal(xs, xo)
     x, info = oracle.cg(lambda v: A @ v, b, rtol=1e-14, maxiter=3)
     assert info == 3
+
+
+# ---------------------------------------------------------------- f1: FilterLO ----
+def _filter_case(golden):
+    ss = [[golden["filt_subscan0"], golden["filt_subscan1"]],
+          [golden["filt_tstart0"], golden["filt_tstart1"]]]
+    return ss, list(golden["filt_nsamples"]), list(golden["filt_nbolos"])
+
+
+def test_legendre_tables(golden, oracle):
+    np.testing.assert_array_equal(oracle.get_legendre_polynomials(3, 17), golden["leg_3_17"])
+    np.testing.assert_array_equal(oracle.get_legendre_polynomials(1, 2), golden["leg_1_2"])
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_filter_poly_equals_reference_polyfilter(golden, oracle, order):
+    ss, ns, nb = _filter_case(golden)
+    y = oracle.filter_poly(golden["filt_d"], golden["filt_pix"], ss, ns, nb, order)
+    np.testing.assert_array_equal(y, golden["filt_out%d" % order])
+
+
+def test_filter_mean_properties(golden, oracle):
+    """poly_order=0 is a weave loop in the reference (:141-162), so it is pinned by what
+    the loop must do rather than by an executed vector."""
+    ss, ns, nb = _filter_case(golden)
+    d, pix = golden["filt_d"], golden["filt_pix"]
+    y = oracle.filter_mean(d, pix, ss, ns, nb)
+    starts, lens = oracle.filter_segments(*oracle.filter_normalise_args(ss, ns, nb))
+    covered = np.zeros(d.size, dtype=bool)
+    for a, n in zip(starts, lens):
+        v = pix[a:a + n] != -1
+        if not v.any():
+            assert not y[a:a + n].any()                  # NaN mean -> chunk skipped (:163-164)
+            continue
+        covered[a:a + n] = True
+        mean = d[a:a + n][v].sum() / v.sum()
+        np.testing.assert_allclose(y[a:a + n], d[a:a + n] - mean, rtol=0, atol=1e-13)
+        assert abs(y[a:a + n][v].sum()) < 1e-11         # offset of the unflagged samples is gone
+    assert not y[~covered].any()                         # vec_out = d*0 outside the chunks (:130)
+    np.testing.assert_allclose(oracle.filter_mean(y, pix, ss, ns, nb), y, atol=1e-13)  # idempotent
+    # single-CES call convention (:269-273)
+    one = oracle.filter_mean(d[:600], pix[:600], [ss[0][0], ss[1][0]], ns[0], nb[0])
+    np.testing.assert_array_equal(one, y[:600])
+
+
+def test_ground_filter_oracle():
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    g = rng.integers(-1, 12, size=500)
+    g[g == 7] = 3                                        # an empty bin
+    v = rng.standard_normal(500)
+    y = O.ground_filter(g, v)
+    for b in range(12):
+        sel = g == b
+        if sel.any():
+            np.testing.assert_allclose(y[sel], v[sel] - v[sel].mean(), atol=1e-13)
+    np.testing.assert_array_equal(y[g == -1], v[g == -1])
+    np.testing.assert_allclose(O.ground_filter(g, y), y, atol=1e-13)
