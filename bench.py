@@ -93,9 +93,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # CM2_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than
+        # ranks (ranks then share a card); the driver's runs use RCCL, one rank per GPU.
+        backend = os.environ.get("CM2_DIST_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % ndev if backend != "nccl" else local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if world != args.gpus and rank == 0:

@@ -929,3 +929,40 @@ def test_ground_filter_lo(cm, nbins):
     yd = Fg * cm.torch.from_numpy(v).cuda()
     assert rel_l2(yd.cpu().numpy(), y) < 1e-14             # atomic order differs run to run
     assert rel_l2(Fg * y, y) < 1e-12                       # projector
+
+
+def test_pcg_with_filter_as_noise_operator(cm, oracle):
+    """A = P^T F P, the operator of the production runs (src/test_M2_precond_onto_real_data.py:
+    79-86): PCG with M_BD against the oracle's PCG on the oracle's operators."""
+    pol, npix, ns, nb = 3, 400, 6000, 6
+    nt = ns * nb
+    d, pairs, phi, t, diag = make_problem(oracle, 5, nt, npix, nb, pol, flag_frac=0.04)
+    sizes = np.array([1400, 1500, 1450, 1500])
+    starts = np.array([0, 1440, 2980, 4470])
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    CES = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n = CES.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=CES)
+    M = cm.I.BlockDiagonalPreconditionerLO(CES, n, pol)
+    for order in (0, 2):
+        F = cm.I.FilterLO(nt, [sizes, starts], ns, nb, P.pairs, poly_order=order)
+        A = P.T * F * P
+        filt = ((lambda v: oracle.filter_mean(v, po, [sizes, starts], ns, nb)) if order == 0 else
+                (lambda v: oracle.filter_poly(v, po, [sizes, starts], ns, nb, order)))
+
+        def A_o(x):
+            return oracle.sparse_rmult(pol, n, po, ro.cos, ro.sin,
+                                       filt(oracle.sparse_mult(pol, po, ro.cos, ro.sin, x)))
+        x = np.random.default_rng(order).standard_normal(pol * n)
+        assert rel_l2(A * x, A_o(x)) < 1e-12
+        xd = cm.torch.from_numpy(x).cuda()
+        assert rel_l2((A * xd).cpu().numpy(), A_o(x)) < 1e-12       # stays in HBM
+        b = P.T * F * d
+        its, itso = [], []
+        xs, info = cm.cg(A, b, M=M, rtol=1e-8, maxiter=200, callback=lambda xk: its.append(1))
+        xo, info_o = oracle.cg(A_o, b, M=lambda v: oracle.bd_precond_mult(pol, ro, v), rtol=1e-8,
+                               maxiter=200, callback=lambda xk: itso.append(1))
+        assert info == 0 and info_o == 0
+        assert abs(len(its) - len(itso)) <= 1, (len(its), len(itso))
+        assert rel_l2(A * xs, b) < 1e-7
