@@ -966,3 +966,82 @@ def test_pcg_with_filter_as_noise_operator(cm, oracle):
         assert info == 0 and info_o == 0
         assert abs(len(its) - len(itso)) <= 1, (len(its), len(itso))
         assert rel_l2(A * xs, b) < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("tp,lam", [(2048, 40), (64, 40), (1024, 300), (2048, 1500)])
+def test_overlap_save_on_tile_order_list_modes(cm, oracle, monkeypatch, mode, tp, lam):
+    """The two ways the fused overlap-save kernel reaches the tile-ordered TOD (per-sample
+    index, address-sorted lists per segment pair) give the same result, with flagged samples,
+    ragged blocks whose last pair ends mid-window, and tiles so small (64 pixels) that every
+    sample is its own address run."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    monkeypatch.setenv("CM2_OS_LISTS", mode)
+    pol, nt, npix, nblk = 3, 240000, 70000, 3
+    d, pairs, phi, t, diag = make_problem(oracle, 900 + lam, nt, npix, nblk, pol, flag_frac=0.07)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+    L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+    sizes = [100000, 60000, 80000]
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
+    x = np.random.default_rng(1).standard_normal(pol * npix)
+    Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+    Nd = cm.I.BlockLO(sizes, bands, offdiag=True, method=(1 if lam <= 300 else 2))
+    exact = P.T * (Nd * (P * x))
+    assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12
+
+
+def test_full_size_properties_c4(cm):
+    """BASELINE config C4 at full size (nside 256 IQU, 1e8 samples, 100 Toeplitz blocks with
+    lambda = 2048, generated in HBM).  No oracle run at this size (the direct band sum is
+    2e11 multiply-adds per matvec on one core); instead: the tile-order chain with the LDS
+    FFT against the time-order chain built from independent pieces (exact pixel-major P^T,
+    rocFFT overlap-save), symmetry, positivity, linearity, and the zero boundary between
+    noise blocks."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import toeplitz_band
+    from cosmomap2_amd.interfaces import linearoperators as L
+    from cosmomap2_amd import device as D
+    t = cm.torch
+    nside, nt, nb, pol, lam = 256, 100_000_000, 100, 3, 2048
+    npix = 12 * nside * nside
+    g = t.Generator(device="cuda").manual_seed(20161204)
+    pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
+    phi = 0.3 + (2 * np.pi * 2.5 / 200.0) * t.arange(nt, device="cuda", dtype=t.float64)
+    rng = np.random.default_rng(11)
+    bands = [toeplitz_band(lam, rng) for _ in range(nb)]
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
+    del phi
+    n = ces.get_new_pixel[0]
+    assert n == npix
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    Nf = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=3)       # LDS FFT
+    Nr = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=2)       # rocFFT
+    x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
+    y = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
+    A = P.T * Nf * P
+    assert L._use_tiles(P)
+    Ax = A * x
+    exact = P.T * (Nr * (P * x))
+    assert float((Ax - exact).norm() / exact.norm()) < 1e-12
+    Ay = A * y
+    dxy, dyx = D.dot(y, Ax), D.dot(x, Ay)
+    assert abs(dxy - dyx) <= 1e-11 * abs(dxy)
+    assert D.dot(x, Ax) > 0 and D.dot(y, Ay) > 0
+    lin = A * (2.0 * x + y) - (2.0 * Ax + Ay)
+    assert float(lin.norm() / Ax.norm()) < 1e-13
+    del exact, lin
+    # zero boundary: an impulse on the first sample of block 1 spreads lambda-1 samples
+    # forward inside the block and not at all into block 0
+    bs = nt // nb
+    e = t.zeros(nt, dtype=t.float64, device="cuda")
+    e[bs] = 1.0
+    for Nop in (Nf, Nr):
+        r = Nop * e
+        assert float(r[:bs].abs().max()) == 0.0
+        np.testing.assert_allclose(r[bs:bs + lam].cpu().numpy(), bands[1], rtol=0,
+                                   atol=1e-12 * abs(bands[1][0]))
+        assert float(r[bs + lam:bs + 3 * lam].abs().max()) < 1e-12 * abs(bands[1][0])
