@@ -330,6 +330,384 @@ __global__ __launch_bounds__(kThreads) void k_overlap_save(
 }
 
 // ------------------------------------------------------------------------------------
+// Register-resident variant of the pair kernel for N = 8192 (long bands).
+//
+// The pair kernel above keeps both planes of the complex signal in LDS (135 KB): one
+// workgroup per CU, so a CU alternates between ~12 us of FFT passes and ~17 us of dependent
+// memory round trips (list -> gather, list -> scatter) and nothing overlaps.  Here the signal
+// lives in registers -- 256 threads x 32 complex points -- and LDS is only the exchange
+// buffer between passes, ONE plane at a time (66 KB): two workgroups share a CU and one
+// computes while the other waits on HBM.  Same mathematics as radix_pass / middle_pass with
+// (R1, R2, R3) = (32, 16, 16); Hperm is laid out for that factorisation.
+//
+// Layouts (position a of the N-point signal held by thread t in slot m):
+//   P1: a = t + 256 m                      radix-32 pass over stride 256  (n = N)
+//   P2: a = (16 (m>>4) + (t>>4)) 256 + (t&15) + 16 (m&15)
+//                                          two radix-16 butterflies over stride 16  (n = 256)
+//   P3: a = 32 t + m                       two radix-16 butterflies on contiguous points
+constexpr int kRegT = 256, kRegN = 8192;
+
+template <int L>
+__device__ __forceinline__ int reg_pos(int t, int m)
+{
+    if (L == 1) return t + 256 * m;
+    if (L == 2) return (16 * (m >> 4) + (t >> 4)) * 256 + (t & 15) + 16 * (m & 15);
+    return 32 * t + m;
+}
+
+// padded LDS index of reg_pos<L>(t, m) split into a per-thread base and a compile-time offset
+// (padi(a) = a + (a >> 5) is additive for these layouts), so that the 32 accesses of an
+// exchange are one base register plus immediate offsets
+template <int L>
+__device__ __forceinline__ int reg_base(int t)
+{
+    if (L == 1) return t + (t >> 5);
+    if (L == 2) return (t >> 4) * 264 + (t & 15);
+    return 33 * t;
+}
+template <int L>
+__host__ __device__ constexpr int reg_off(int m)
+{
+    return L == 1 ? 264 * m : (L == 2 ? 4224 * (m >> 4) + 16 * (m & 15) + ((m & 15) >> 1) : m);
+}
+
+// Where slot m of a 32-array sits after in-place butterflies: dft_sub leaves output m of a
+// radix-R block at index brev<R>(m) of that block.  PERM = 0: natural, 32: one radix-32 block,
+// 16: two radix-16 blocks.  The exchanges apply it as a compile-time index, so no value is
+// ever moved between registers.
+template <int PERM>
+__host__ __device__ constexpr int reg_slot(int m)
+{
+    return PERM == 32 ? brev<32>(m) : (PERM == 16 ? 16 * (m >> 4) + brev<16>(m & 15) : m);
+}
+
+template <int FROM, int TO, int PERM>
+__device__ __forceinline__ void reg_exchange(double (&a)[32], double *__restrict__ buf, int t)
+{
+    double *__restrict__ wp = buf + reg_base<FROM>(t);
+    const double *__restrict__ rp = buf + reg_base<TO>(t);
+#pragma unroll
+    for (int m = 0; m < 32; ++m) wp[reg_off<FROM>(m)] = a[reg_slot<PERM>(m)];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 32; ++m) a[m] = rp[reg_off<TO>(m)];
+    __syncthreads();
+}
+
+// dft_regs on the sub-block [OFF, OFF + R) of a 32-array, in place
+template <int R, int OFF>
+__device__ __forceinline__ void dft_sub(double (&re)[32], double (&im)[32])
+{
+#pragma unroll
+    for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const int a = OFF + blk + i, b = a + h;
+                const int tw = i * (32 / (2 * h));
+                const double ar = re[a], ai = im[a], br = re[b], bi = im[b];
+                re[a] = ar + br;
+                im[a] = ai + bi;
+                const double dr = ar - br, di = ai - bi;
+                if (tw == 0) {
+                    re[b] = dr;
+                    im[b] = di;
+                } else if (tw == 8) {
+                    re[b] = di;
+                    im[b] = -dr;
+                } else {
+                    const double c = kCos32[tw], s = kSin32[tw];
+                    re[b] = dr * c + di * s;
+                    im[b] = di * c - dr * s;
+                }
+            }
+        }
+    }
+}
+
+// decimation-in-time counterpart of dft_sub: input m at index brev<R>(m), output natural.
+// Used for the inverse half of the middle pass, so that the spectrum product happens in
+// place on the bit-reversed output of dft_sub and nothing is permuted or copied.
+template <int R, int OFF>
+__device__ __forceinline__ void dit_sub(double (&re)[32], double (&im)[32])
+{
+#pragma unroll
+    for (int h = 1; h <= R / 2; h <<= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const int a = OFF + blk + i, b = a + h;
+                const int tw = i * (32 / (2 * h));          // exponent in units of 2 pi / 32
+                double tr, ti;
+                if (tw == 0) {
+                    tr = re[b];
+                    ti = im[b];
+                } else if (tw == 8) {                        // times -i
+                    tr = im[b];
+                    ti = -re[b];
+                } else {                                     // times (c - i s)
+                    const double c = kCos32[tw], s = kSin32[tw];
+                    tr = re[b] * c + im[b] * s;
+                    ti = im[b] * c - re[b] * s;
+                }
+                const double ar = re[a], ai = im[a];
+                re[a] = ar + tr;
+                im[a] = ai + ti;
+                re[b] = ar - tr;
+                im[b] = ai - ti;
+            }
+        }
+    }
+}
+
+// forward pass on a block: butterfly, then output m (at index brev(m)) times w1^m
+template <int R, int OFF>
+__device__ __forceinline__ void reg_fwd(double (&xr)[32], double (&xi)[32], double2 w1)
+{
+    dft_sub<R, OFF>(xr, xi);
+    double cr = 1.0, ci = 0.0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+        const double nr = cr * w1.x - ci * w1.y;
+        ci = cr * w1.y + ci * w1.x;
+        cr = nr;
+        const int i = OFF + brev<R>(m);
+        const double tr = xr[i] * cr - xi[i] * ci;
+        xi[i] = xr[i] * ci + xi[i] * cr;
+        xr[i] = tr;
+    }
+}
+
+// inverse pass on a block: input m (natural index) times conj(w1^m), then the inverse
+// butterfly (swap . forward . swap); output m ends at index brev(m)
+template <int R, int OFF>
+__device__ __forceinline__ void reg_inv(double (&xr)[32], double (&xi)[32], double2 w1)
+{
+    double cr = 1.0, ci = 0.0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+        const double nr = cr * w1.x - ci * w1.y;
+        ci = cr * w1.y + ci * w1.x;
+        cr = nr;
+        const int i = OFF + m;
+        const double tr = xr[i] * cr + xi[i] * ci;
+        xi[i] = xi[i] * cr - xr[i] * ci;
+        xr[i] = tr;
+    }
+    dft_sub<R, OFF>(xi, xr);
+}
+
+// The pair's two segments are hop = 4096 = 16 * 256 apart (halo 2048 on both sides whatever
+// lambda), so that in layout P1 a thread's 32 points of segment B are its points 16..47 of the
+// 12288-sample union window U: 48 values per thread feed both planes, and the 2 x 4096 results
+// form one contiguous 8192-sample window.  In tile order the window is reached through three
+// address-sorted lists per pair (U[0, 8192), U[8192, 12288), results), each routed through the
+// exchange buffer in chunks, so nothing but the 48 window values stays live in registers.
+constexpr int kRegHop = 4096, kRegHalo = 2048, kRegCh = 8;
+constexpr int kRegL1 = kRegN, kRegL2 = kRegHop, kRegLS = 2 * kRegHop;     // list lengths per pair
+
+template <int LEN, class F>
+__device__ __forceinline__ void reg_list_walk(const uint32_t *__restrict__ lk,
+                                              const uint16_t *__restrict__ lq, int t, F f)
+{
+#pragma unroll 1
+    for (int c0 = 0; c0 < LEN / kRegT; c0 += kRegCh) {
+        uint32_t kk[kRegCh];
+        int qq[kRegCh];
+#pragma unroll
+        for (int u = 0; u < kRegCh; ++u) {
+            const int e = t + (c0 + u) * kRegT;
+            kk[u] = lk[e];
+            qq[u] = (int)lq[e];
+        }
+        f(kk, qq);
+    }
+}
+
+__global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
+    const PairDesc *__restrict__ pairs, int npairs, const double2 *__restrict__ W,
+    const double *__restrict__ Hperm,
+    const uint32_t *__restrict__ l1_k, const uint16_t *__restrict__ l1_q,
+    const uint32_t *__restrict__ l2_k, const uint16_t *__restrict__ l2_q,
+    const uint32_t *__restrict__ ls_k, const uint16_t *__restrict__ ls_q,
+    const double *__restrict__ v, double *__restrict__ out)
+{
+    constexpr int N = kRegN;
+    extern __shared__ double buf[];
+    const int t = threadIdx.x;
+    const int per_xcd = (npairs + 7) / 8;
+    const int pair_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pair_id >= npairs) return;
+    const PairDesc pd = pairs[pair_id];
+    const double *hperm = Hperm + (int64_t)pd.blk * N;
+    const bool has_b = pd.b_len > 0;
+    double *__restrict__ b1 = buf + reg_base<1>(t);
+
+    // ---- load the union window: U[m] = sample (a_start - HALO) + t + 256 m ----
+    double U[48];
+    {
+        reg_list_walk<kRegL1>(l1_k + (int64_t)pair_id * kRegL1, l1_q + (int64_t)pair_id * kRegL1, t,
+                              [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+            double vv[kRegCh];
+#pragma unroll
+            for (int u = 0; u < kRegCh; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < kRegCh; ++u) buf[padi(qq[u])] = vv[u];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) U[m] = b1[reg_off<1>(m)];
+        __syncthreads();
+        if (has_b) {
+            reg_list_walk<kRegL2>(l2_k + (int64_t)pair_id * kRegL2, l2_q + (int64_t)pair_id * kRegL2,
+                                  t, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+                double vv[kRegCh];
+#pragma unroll
+                for (int u = 0; u < kRegCh; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < kRegCh; ++u) buf[padi(qq[u])] = vv[u];
+            });
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) U[32 + m] = b1[reg_off<1>(m)];
+            __syncthreads();
+        }
+    }
+    double zr[32], zi[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        zr[m] = U[m];
+        zi[m] = has_b ? U[m + 16] : 0.0;
+    }
+
+    const double2 w_a = W[t];                       // n = N:   w = exp(-2 pi i j / N),   j = t
+    const double2 w_b = W[32 * (t & 15)];           // n = 256: w = exp(-2 pi i j / 256), j = t & 15
+
+    // ---- forward: radix 32, radix 16, then (radix 16, spectrum, inverse radix 16) ----
+    reg_fwd<32, 0>(zr, zi, w_a);
+    reg_exchange<1, 2, 32>(zr, buf, t);
+    reg_exchange<1, 2, 32>(zi, buf, t);
+    reg_fwd<16, 0>(zr, zi, w_b);
+    reg_fwd<16, 16>(zr, zi, w_b);
+    reg_exchange<2, 3, 16>(zr, buf, t);
+    reg_exchange<2, 3, 16>(zi, buf, t);
+    // middle: radix 16 (output k at index brev(k)), spectrum product in place, inverse radix
+    // 16 as a decimation-in-time network on the bit-reversed data (swap . forward . swap)
+    dft_sub<16, 0>(zr, zi);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double hv = hperm[32 * t + k];
+        zr[brev<16>(k)] *= hv;
+        zi[brev<16>(k)] *= hv;
+    }
+    dit_sub<16, 0>(zi, zr);
+    __builtin_amdgcn_sched_barrier(0);
+    dft_sub<16, 16>(zr, zi);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double hv = hperm[32 * t + 16 + k];
+        zr[16 + brev<16>(k)] *= hv;
+        zi[16 + brev<16>(k)] *= hv;
+    }
+    dit_sub<16, 16>(zi, zr);
+    // ---- inverse: radix 16, radix 32 ----
+    // The twiddle powers are recomputed from an opaque copy of w: otherwise the compiler
+    // keeps the 46 powers of the forward passes alive (spilled) across the whole transform.
+    double2 w_bi = w_b, w_ai = w_a;
+    asm volatile("" : "+v"(w_bi.x), "+v"(w_bi.y), "+v"(w_ai.x), "+v"(w_ai.y));
+    reg_exchange<3, 2, 0>(zr, buf, t);
+    reg_exchange<3, 2, 0>(zi, buf, t);
+    reg_inv<16, 0>(zr, zi, w_bi);
+    reg_inv<16, 16>(zr, zi, w_bi);
+    reg_exchange<2, 1, 16>(zr, buf, t);
+    reg_exchange<2, 1, 16>(zi, buf, t);
+    reg_inv<32, 0>(zr, zi, w_ai);                      // result slot m at index brev<32>(m)
+
+    // ---- store: results of A are slots 8..23 of zr (window positions 2048..6143), of B the
+    //      same slots of zi; together the result window R[0, 8192), R[j] at P1 slot j / 256 ----
+    {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            b1[reg_off<1>(m)] = zr[brev<32>(m + 8)];
+            b1[reg_off<1>(m + 16)] = zi[brev<32>(m + 8)];
+        }
+        __syncthreads();
+        reg_list_walk<kRegLS>(ls_k + (int64_t)pair_id * kRegLS, ls_q + (int64_t)pair_id * kRegLS, t,
+                              [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+#pragma unroll
+            for (int u = 0; u < kRegCh; ++u)
+                if (kk[u] != kInvalidSample) out[kk[u]] = buf[padi(qq[u])];
+        });
+    }
+}
+
+// keys of the three lists of the register-resident kernel, 20480 entries per pair:
+//   [0, 8192)      U[q], q = e              -> list 0, value q
+//   [8192, 12288)  U[q], q = e              -> list 1, value q - 8192
+//   [12288, 20480) results R[j], j = e - 12288 (A: j < 4096, B: j - 4096) -> list 2, value j
+// key = ((3 pair + list) << 32) | address; a stable sort orders every list by address.
+__global__ __launch_bounds__(256) void k_reg_keys(const PairDesc *__restrict__ pairs, int npairs,
+                                                   const uint32_t *__restrict__ idx,
+                                                   uint64_t *__restrict__ keys,
+                                                   uint16_t *__restrict__ vals)
+{
+    constexpr int PER = kRegL1 + kRegL2 + kRegLS;
+    const int64_t total = (int64_t)npairs * PER;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const int64_t p = g / PER;
+        const int e = (int)(g - p * PER);
+        const PairDesc pd = pairs[p];
+        uint32_t k = kInvalidSample;
+        int list, val;
+        if (e < kRegL1 + kRegL2) {
+            list = e < kRegL1 ? 0 : 1;
+            val = e < kRegL1 ? e : e - kRegL1;
+            const int64_t ts = pd.a_start - kRegHalo + e;
+            if (ts >= pd.lo && ts < pd.hi && (list == 0 || pd.b_len > 0)) k = idx[ts];
+        } else {
+            list = 2;
+            val = e - (kRegL1 + kRegL2);
+            const int ja = val, jb = val - kRegHop;
+            if (ja < pd.a_len && ja < kRegHop) k = idx[pd.a_start + ja];
+            else if (jb >= 0 && jb < pd.b_len) k = idx[pd.b_start + jb];
+        }
+        keys[g] = ((uint64_t)(3 * p + list) << 32) | (uint64_t)k;
+        vals[g] = (uint16_t)val;
+    }
+}
+
+// split the sorted (key, value) stream into the three per-pair lists
+__global__ __launch_bounds__(256) void k_reg_unpack(int64_t npairs, const uint64_t *__restrict__ keys,
+                                                     const uint16_t *__restrict__ vals,
+                                                     uint32_t *__restrict__ l1_k, uint16_t *__restrict__ l1_q,
+                                                     uint32_t *__restrict__ l2_k, uint16_t *__restrict__ l2_q,
+                                                     uint32_t *__restrict__ ls_k, uint16_t *__restrict__ ls_q)
+{
+    constexpr int PER = kRegL1 + kRegL2 + kRegLS;
+    const int64_t total = npairs * PER;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const int64_t p = g / PER;
+        const int e = (int)(g - p * PER);
+        const uint32_t k = (uint32_t)(keys[g] & 0xFFFFFFFFull);
+        const uint16_t q = vals[g];
+        if (e < kRegL1) {
+            l1_k[p * kRegL1 + e] = k;
+            l1_q[p * kRegL1 + e] = q;
+        } else if (e < kRegL1 + kRegL2) {
+            l2_k[p * kRegL2 + (e - kRegL1)] = k;
+            l2_q[p * kRegL2 + (e - kRegL1)] = q;
+        } else {
+            ls_k[p * kRegLS + (e - kRegL1 - kRegL2)] = k;
+            ls_q[p * kRegLS + (e - kRegL1 - kRegL2)] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Real-input variant for long bands (halo up to 2048): ONE segment of L = 8192 real samples
 // per workgroup, transformed as M = 4096 complex points z[n] = x[2n] + i x[2n+1].  Its LDS
 // footprint (66 KB) lets TWO workgroups share a CU, so one can compute while the other
@@ -544,6 +922,14 @@ struct FusedOS {
     double2 *d_W = nullptr;
     double *d_Hperm = nullptr;
     size_t lds_bytes = 0;
+    // register-resident pair kernel (N = 8192, two workgroups per CU): spectrum laid out for
+    // the (32, 16, 16) factorisation
+    bool reg_variant = false;
+    int64_t npairs_reg = 0;
+    PairDesc *d_pairs_reg = nullptr;
+    double *d_Hperm_reg = nullptr;
+    uint32_t *d_l1_k = nullptr, *d_l2_k = nullptr, *d_ls_k = nullptr;
+    uint16_t *d_l1_q = nullptr, *d_l2_q = nullptr, *d_ls_q = nullptr;
     // address-sorted gather lists of the tile-order path, built for one tile index at a time
     const void *list_key = nullptr;
     uint32_t *d_lst_k = nullptr;
@@ -560,7 +946,8 @@ void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
     void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm, f->d_segs, f->d_WM, f->d_WL, f->d_Hs,
-                    f->d_lst_k, f->d_lst_q};
+                    f->d_lst_k, f->d_lst_q, f->d_Hperm_reg, f->d_pairs_reg, f->d_l1_k, f->d_l2_k, f->d_ls_k,
+                    f->d_l1_q, f->d_l2_q, f->d_ls_q};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete f;
@@ -585,6 +972,23 @@ static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, do
     k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
         f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx,
         INDIRECT ? f->d_lst_k : nullptr, INDIRECT ? f->d_lst_q : nullptr, d_v, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
+{
+    constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
+    k_overlap_save_reg<<<grid, kRegT, lds, stream>>>(
+        f->d_pairs_reg, (int)f->npairs_reg, f->d_W, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
+        f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -614,6 +1018,7 @@ static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, 
 {
     if (f->real_variant) return launch_real<INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->npairs == 0) return 0;
+    if (INDIRECT && f->d_l1_k) return launch_reg(f, d_v, d_out, stream);
     if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
     return launch<16, 16, 2, INDIRECT>(f, d_idx, d_v, d_out, stream);
@@ -633,7 +1038,56 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
     f->list_key = nullptr;
     const char *e = getenv("CM2_OS_LISTS");
     if (f->real_variant || f->npairs == 0 || (e && atoi(e) == 0)) {
+        if (f->d_l1_k) {                                     // lists of another tile index
+            void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
+                             (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
+            for (void **q : ptrs) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+        }
         f->list_key = (const void *)d_idx;                   // per-sample index mode
+        return 0;
+    }
+    if (f->reg_variant) {
+        void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
+                         (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
+        for (void **q : ptrs) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        constexpr int64_t PER = kRegL1 + kRegL2 + kRegLS;
+        const int64_t total = f->npairs_reg * PER;
+        DevTemp<uint64_t> keys_in, keys_out;
+        DevTemp<uint16_t> vals_in, vals_out;
+        DevTemp<char> d_temp;
+        CM2_HIP(keys_in.alloc(total));
+        CM2_HIP(keys_out.alloc(total));
+        CM2_HIP(vals_in.alloc(total));
+        CM2_HIP(vals_out.alloc(total));
+        k_reg_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs_reg, (int)f->npairs_reg, d_idx, keys_in,
+                                                          vals_in);
+        CM2_LAUNCH_OK();
+        int end_bit = 33;
+        while (((int64_t)1 << (end_bit - 32)) <= 3 * f->npairs_reg && end_bit < 64) ++end_bit;
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   vals_out.p, total, 0, end_bit, stream));
+        CM2_HIP(d_temp.alloc(tb + 16));
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   vals_out.p, total, 0, end_bit, stream));
+        CM2_HIP(hipMalloc(&f->d_l1_k, sizeof(uint32_t) * f->npairs_reg * kRegL1));
+        CM2_HIP(hipMalloc(&f->d_l2_k, sizeof(uint32_t) * f->npairs_reg * kRegL2));
+        CM2_HIP(hipMalloc(&f->d_ls_k, sizeof(uint32_t) * f->npairs_reg * kRegLS));
+        CM2_HIP(hipMalloc(&f->d_l1_q, sizeof(uint16_t) * f->npairs_reg * kRegL1));
+        CM2_HIP(hipMalloc(&f->d_l2_q, sizeof(uint16_t) * f->npairs_reg * kRegL2));
+        CM2_HIP(hipMalloc(&f->d_ls_q, sizeof(uint16_t) * f->npairs_reg * kRegLS));
+        k_reg_unpack<<<grid_for(total), kBlock, 0, stream>>>(f->npairs_reg, keys_out, vals_out, f->d_l1_k,
+                                                            f->d_l1_q, f->d_l2_k, f->d_l2_q,
+                                                            f->d_ls_k, f->d_ls_q);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipStreamSynchronize(stream));
+        f->list_key = (const void *)d_idx;
         return 0;
     }
     const int64_t qm = f->N + f->hop, total = f->npairs * qm;
@@ -726,6 +1180,9 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     }
     f->R1 = 16; f->R2 = 16; f->R3 = f->N / 256;
     f->hop = f->N - 2 * (int64_t)f->halo;
+    // register-resident pair kernel for the tile-order path (fixed geometry: hop 4096, halo
+    // 2048); CM2_FUSED_VARIANT=pair keeps the LDS-resident pair kernel everywhere
+    f->reg_variant = f->N == kRegN && !(variant && strcmp(variant, "pair") == 0);
     f->lds_bytes = sizeof(double) * 2 * (size_t)(f->N + f->N / 32);
     std::vector<PairDesc> pairs;
     for (int64_t b = 0; b < nb; ++b) {
@@ -754,6 +1211,32 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, f->R1,
                                                                f->R2, f->R3, d_bands, f->d_Hperm);
     CM2_LAUNCH_OK();
+    if (f->reg_variant) {
+        std::vector<PairDesc> rp;
+        for (int64_t b = 0; b < nb; ++b) {
+            for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += 2 * kRegHop) {
+                PairDesc pd;
+                pd.lo = off[b]; pd.hi = off[b + 1]; pd.blk = (int32_t)b; pd.pad = 0;
+                pd.a_start = s0;
+                pd.a_len = (off[b + 1] - s0 < kRegHop) ? off[b + 1] - s0 : kRegHop;
+                pd.b_start = s0 + kRegHop;
+                pd.b_len = pd.b_start < off[b + 1]
+                               ? ((off[b + 1] - pd.b_start < kRegHop) ? off[b + 1] - pd.b_start : kRegHop)
+                               : 0;
+                if (pd.b_len == 0) pd.b_start = s0;
+                rp.push_back(pd);
+            }
+        }
+        f->npairs_reg = (int64_t)rp.size();
+        CM2_HIP(hipMalloc(&f->d_pairs_reg, sizeof(PairDesc) * (rp.size() ? rp.size() : 1)));
+        if (!rp.empty())
+            CM2_HIP(hipMemcpy(f->d_pairs_reg, rp.data(), sizeof(PairDesc) * rp.size(),
+                              hipMemcpyHostToDevice));
+        CM2_HIP(hipMalloc(&f->d_Hperm_reg, sizeof(double) * nb * f->N));
+        k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, 32, 16, 16,
+                                                                   d_bands, f->d_Hperm_reg);
+        CM2_LAUNCH_OK();
+    }
     CM2_HIP(hipStreamSynchronize(stream));
     *out = f;
     return 0;

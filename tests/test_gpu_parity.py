@@ -968,22 +968,25 @@ def test_pcg_with_filter_as_noise_operator(cm, oracle):
         assert rel_l2(A * xs, b) < 1e-7
 
 
+@pytest.mark.parametrize("variant", ["pair", "reg"])
 @pytest.mark.parametrize("mode", ["0", "1"])
-@pytest.mark.parametrize("tp,lam", [(2048, 40), (64, 40), (1024, 300), (2048, 1500)])
-def test_overlap_save_on_tile_order_list_modes(cm, oracle, monkeypatch, mode, tp, lam):
-    """The two ways the fused overlap-save kernel reaches the tile-ordered TOD (per-sample
-    index, address-sorted lists per segment pair) give the same result, with flagged samples,
-    ragged blocks whose last pair ends mid-window, and tiles so small (64 pixels) that every
-    sample is its own address run."""
+@pytest.mark.parametrize("tp,lam", [(2048, 40), (64, 40), (1024, 300), (2048, 1500), (512, 2049)])
+def test_overlap_save_on_tile_order_list_modes(cm, oracle, monkeypatch, mode, tp, lam, variant):
+    """The ways the fused overlap-save kernels reach the tile-ordered TOD (per-sample index;
+    address-sorted lists per segment pair with the LDS-resident pair kernel; the three lists of
+    the register-resident kernel, used for the long bands) give the same result, with flagged
+    samples, ragged blocks whose last pair ends mid-window, a block shorter than one window,
+    and tiles so small (64 pixels) that every sample is its own address run."""
     from types import SimpleNamespace
     from cosmomap2_amd.interfaces import linearoperators as L
     monkeypatch.setenv("CM2_OS_LISTS", mode)
-    pol, nt, npix, nblk = 3, 240000, 70000, 3
+    monkeypatch.setenv("CM2_FUSED_VARIANT", variant)
+    pol, nt, npix, nblk = 3, 240000, 70000, 5
     d, pairs, phi, t, diag = make_problem(oracle, 900 + lam, nt, npix, nblk, pol, flag_frac=0.07)
     c, s = np.cos(2 * phi), np.sin(2 * phi)
     P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
     L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
-    sizes = [100000, 60000, 80000]
+    sizes = [100000, 60000, 70000, 7000, 3000]
     kk = np.arange(lam)
     bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
     x = np.random.default_rng(1).standard_normal(pol * npix)
