@@ -212,7 +212,7 @@ def main():
                 28.0 * nt + map_bytes / 2)
             if args.toeplitz == "fused":
                 v_tb = D.empty(T.nvalid)
-                stages["N^-1 on tile order (k_overlap_save, LDS FFT)"] = (ev_time(lambda: call(
+                stages["N^-1 on tile order (k_overlap_save_reg, register+LDS FFT)"] = (ev_time(lambda: call(
                     "cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st()),
                     reps), 16.0 * nt)
                 del v_tb

@@ -505,7 +505,11 @@ __device__ __forceinline__ void reg_inv(double (&xr)[32], double (&xi)[32], doub
 // form one contiguous 8192-sample window.  In tile order the window is reached through three
 // address-sorted lists per pair (U[0, 8192), U[8192, 12288), results), each routed through the
 // exchange buffer in chunks, so nothing but the 48 window values stays live in registers.
-constexpr int kRegHop = 4096, kRegHalo = 2048, kRegCh = 8;
+constexpr int kRegHop = 4096, kRegHalo = 2048;
+#ifndef CM2_REG_CH
+#define CM2_REG_CH 16
+#endif
+constexpr int kRegCh = CM2_REG_CH;
 constexpr int kRegL1 = kRegN, kRegL2 = kRegHop, kRegLS = 2 * kRegHop;     // list lengths per pair
 
 template <int LEN, class F>
