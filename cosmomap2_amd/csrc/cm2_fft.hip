@@ -24,6 +24,16 @@
 // (pack, 2 x [FFT + real pre/post kernel], spectrum multiply, unpack) moves ~7x that.
 // This translation unit is compiled with FMA contraction ON (results are compared with
 // the direct sum at 1e-12, not bit for bit).
+//
+// Kernels in this file:
+//   k_overlap_save<R1,R2,R3,INDIRECT>  the LDS-resident pair kernel described above (N = 512,
+//                                      2048, 8192; time order, or tile order through idx / lists)
+//   k_overlap_save_reg                 register-resident pair kernel for N = 8192 on the tile
+//                                      order: two workgroups per CU (default for long bands)
+//   k_overlap_save_real<INDIRECT>      real-input variant (CM2_FUSED_VARIANT=real), kept for
+//                                      comparison
+// Environment knobs (read when an operator / its lists are built): CM2_FUSED_VARIANT = pair |
+// real, CM2_OS_LISTS = 0 (per-sample index instead of address-sorted lists), CM2_FUSED_FFT_LEN.
 #include "cm2_fft.h"
 
 #include <hipcub/hipcub.hpp>
