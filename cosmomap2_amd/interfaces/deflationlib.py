@@ -145,31 +145,75 @@ def run_krypy_arnoldi(A, x0, M, tol, maxiter=None):
     return Vh, Hh, m
 
 
+_PANEL = 32          # basis vectors per row-major panel of the block Gram-Schmidt
+
+
+class _BasisPanels(object):
+    """The Arnoldi basis kept twice: as a list of contiguous vectors (for the matvec) and as
+    row-major n x 32 panels (for cm2_Zt_apply / cm2_Z_apply, which read 32 basis vectors in
+    one pass).  Unused columns of the last panel are zero."""
+
+    def __init__(self, n):
+        self.n = n
+        self.vecs = []
+        self.panels = []
+
+    def append(self, v):
+        k = len(self.vecs)
+        if k % _PANEL == 0:
+            self.panels.append(D.zeros(self.n * _PANEL).reshape(self.n, _PANEL))
+        self.panels[-1][:, k % _PANEL] = v            # strided copy into the panel
+        self.vecs.append(v)
+
+    def dots(self, w):
+        """[<v_j, w>] for all basis vectors: one kernel per panel, one host copy."""
+        outs = []
+        for pnl in self.panels:
+            o = D.empty(_PANEL)
+            _hip.call("cm2_Zt_apply", self.n, _PANEL, D.ptr(pnl), D.ptr(w), D.ptr(o),
+                      D.ptr(D.reduce_work()), D.stream())
+            outs.append(o)
+        return D.torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def subtract(self, w, coeff_dev):
+        """w -= sum_j coeff_j v_j."""
+        for i, pnl in enumerate(self.panels):
+            corr = D.empty(self.n)
+            _hip.call("cm2_Z_apply", self.n, _PANEL, D.ptr(pnl),
+                      D.ptr(coeff_dev[i * _PANEL:(i + 1) * _PANEL]), D.ptr(corr), D.stream())
+            _hip.call("cm2_axpy", self.n, -1.0, D.ptr(corr), D.ptr(w), D.stream())
+
+
 def _arnoldi_M(A, x0d, M, nmax):
     """Device-resident Arnoldi in the M inner product: returns (list of V vectors in HBM,
-    Hessenberg matrix (nmax+1 x nmax, NumPy), number of completed steps)."""
+    Hessenberg matrix (nmax+1 x nmax, NumPy), number of completed steps).
+
+    Orthogonalisation is block classical Gram-Schmidt applied twice ("twice is enough";
+    map-making spectra are tightly clustered, the new direction is soon tiny and a single
+    pass loses orthogonality): per sweep one pass over the dual basis for all inner products
+    and one over the primal basis for the update, with one host synchronisation, instead of
+    2(k+1) synchronised dot products of a modified Gram-Schmidt loop."""
     n = x0d.numel()
+    Pb, Vb = _BasisPanels(n), None
     if M is None:
         p0 = x0d.clone()
         nrm = _norm(p0)
-        P = [D.scaled(1.0 / nrm, p0)]
-        V = [P[0]]
+        Pb.append(D.scaled(1.0 / nrm, p0))
+        Vb = Pb
     else:
+        Vb = _BasisPanels(n)
         Mv = _apply(M, x0d)
         nrm = math.sqrt(abs(D.dot(x0d, Mv)))
-        P = [D.scaled(1.0 / nrm, x0d)]
-        V = [D.scaled(1.0 / nrm, Mv)]
+        Pb.append(D.scaled(1.0 / nrm, x0d))
+        Vb.append(D.scaled(1.0 / nrm, Mv))
     H = np.zeros((nmax + 1, nmax))
     k_done = 0
     for k in range(nmax):
-        Av = _apply(A, V[k]).clone()
-        # MGS against P with duals V, applied twice ("twice is enough"): map-making spectra are
-        # tightly clustered, the new direction is soon tiny and one pass loses orthogonality
+        Av = _apply(A, Vb.vecs[k]).clone()
         for _sweep in range(2):
-            for j in range(k + 1):
-                alpha = D.dot(V[j], Av)
-                H[j, k] += alpha
-                _hip.call("cm2_axpy", n, -alpha, D.ptr(P[j]), D.ptr(Av), D.stream())
+            h = Vb.dots(Av)                            # duals V: <v_j, Av> = <p_j, Av>_M
+            H[:k + 1, k] += D.to_host(h)[:k + 1]
+            Pb.subtract(Av, h)
         if M is None:
             MAv = Av
             nrm = _norm(Av)
@@ -180,9 +224,10 @@ def _arnoldi_M(A, x0d, M, nmax):
         k_done = k + 1
         if nrm <= 1e-10 * max(abs(H[:k + 1, :k + 1]).max(), 1e-300):   # Krylov space exhausted
             break
-        P.append(D.scaled(1.0 / nrm, Av))
-        V.append(P[-1] if M is None else D.scaled(1.0 / nrm, MAv))
-    return V, H, k_done
+        Pb.append(D.scaled(1.0 / nrm, Av))
+        if M is not None:
+            Vb.append(D.scaled(1.0 / nrm, MAv))
+    return Vb.vecs, H, k_done
 
 
 def ritz_deflation_basis(A, M, x0, r, maxiter):
