@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
+    ap.add_argument("--no-raster", action="store_true",
+                    help="skip the secondary run with a coherent raster-scan pointing")
     ap.add_argument("--no-filters", action="store_true",
                     help="skip the FilterLO / GroundFilterLO timing (SURVEY 8f rows)")
     ap.add_argument("--deflation", type=int, default=32,
@@ -333,8 +335,39 @@ def main():
         filters["ground_ms"] = round(med_ms, 4)
         del Fg, az, pix_f
 
+    # ---- secondary pointing model: coherent raster scan -------------------------
+    # The headline pointing is the reference generator's uniform-random pixels (pairs_gen), the
+    # cache-hostile worst case; a telescope sweeps: every detector block rasters W = 1024 columns
+    # back and forth, 4 samples per pixel, one row per sweep, starting at its own row.
+    raster = None
+    if rank == 0 and world == 1 and lam and not args.no_raster and npix % 1024 == 0:
+        Wc, dwell = 1024, 4
+        Hr = npix // Wc
+        tt = torch.arange(nt, device=dev, dtype=torch.int64)
+        blk, u = tt // bsize, (tt % bsize) // dwell
+        sweep, cc = u // Wc, u % Wc
+        col = torch.where(sweep % 2 == 0, cc, Wc - 1 - cc)
+        row = ((blk * Hr) // nb + sweep) % Hr
+        pix_r = (row * Wc + col).to(torch.int32)
+        del tt, blk, u, sweep, cc, col, row
+        phi_r = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+        ces_r = ProcessTimeSamples(pix_r, npix, pol=pol, phi=phi_r)
+        del phi_r
+        n_r = ces_r.get_new_pixel[0]
+        P_r = SparseLO(n_r, nt, pix_r, pol=pol, angle_processed=ces_r)
+        A_r = P_r.T * N * P_r
+        x_r = torch.rand(pol * n_r, generator=torch.Generator(device=dev).manual_seed(8), device=dev,
+                         dtype=torch.float64)
+        _, med_r = ev_time(lambda: A_r * x_r, reps)
+        raster = {"pointing": "raster: %d columns, %d samples per pixel, one row per sweep" % (Wc, dwell),
+                  "npix": int(n_r), "ms_per_step": round(med_r, 4),
+                  "value": round(nt / (med_r * 1e-3), 1), "unit": "TOD samples/s",
+                  "step_frac_of_hbm_peak": round((72.0 * nt + 48.0 * n_r) / (med_r * 1e-3) / 1e9
+                                                 / HBM_PEAK_GBS, 4)}
+        del A_r, P_r, ces_r, pix_r, x_r
+
     # ---- CPU baseline: the oracle (1 core, reference-unfused) on a bounded sample -----
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as orc
         orc.build()
@@ -369,6 +402,30 @@ def main():
         tcpu = time.perf_counter() - tcpu0
         cpu = {"value": round(ns * repsc / tcpu, 1), "unit": "TOD samples/s", "cores": 1,
                "kind": "port", "sample": sample, "host_cores_available": os.cpu_count()}
+        # the fair host figure (SURVEY 8d ii): all cores, OpenMP pointing loops, FFT Toeplitz
+        if lam:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count()
+            nsa = (min(nt, 20_000_000) // bsize) * bsize or min(nt, bsize)
+            nblk = max(1, nsa // bsize)
+            fast = orc.AllCoresMatvec(pol, npix_c, pix[:nsa].cpu().numpy(),
+                                      ces._d_cos[:nsa].cpu().numpy(), ces._d_sin[:nsa].cpu().numpy(),
+                                      bsize if nsa >= bsize else nsa, bands[:nblk], cores)
+            fast(hx)                                                        # warm-up
+            t0c, repsa = time.perf_counter(), 0
+            while True:
+                fast(hx)
+                repsa += 1
+                if time.perf_counter() - t0c > 8.0:
+                    break
+            ta = time.perf_counter() - t0c
+            cpu_all = {"value": round(nsa * repsa / ta, 1), "unit": "TOD samples/s", "cores": cores,
+                       "kind": "port",
+                       "sample": "%d-sample slice (%d block(s)); OpenMP P / P^T with per-thread maps, "
+                                 "FFT convolution per noise block (scipy.signal.fftconvolve) on a "
+                                 "thread pool" % (nsa, nblk)}
 
     if rank == 0:
         out = {
@@ -386,8 +443,10 @@ def main():
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "stages": stage_report,
             "pcg": pcg,
+            "raster_pointing": raster,
             "filters": filters,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "setup_seconds": round(t_setup, 2),
         }
         print(json.dumps(out))

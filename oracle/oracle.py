@@ -569,3 +569,65 @@ def ground_filter(ground, v):
     binned = inv * gtv
     back = np.where(ok, binned[np.where(ok, ground, 0)], 0.)
     return v - back
+
+
+# --------------------------------------------------------------------------
+# all-cores host baseline of P^T N^-1 P (SURVEY 8d "fair host baseline"): OpenMP pointing
+# loops (cm2_oracle_omp.c) + FFT convolution per noise block on a thread pool.
+# bench.py's cpu_baseline_all_cores leg only.
+# --------------------------------------------------------------------------
+_SO_OMP = os.path.join(_HERE, "_build", "libcm2_oracle_omp.so")
+_SRC_OMP = os.path.join(_HERE, "cm2_oracle_omp.c")
+_lib_omp = None
+
+
+def build_omp(force=False):
+    os.makedirs(os.path.dirname(_SO_OMP), exist_ok=True)
+    if (not force and os.path.exists(_SO_OMP)
+            and os.path.getmtime(_SO_OMP) >= os.path.getmtime(_SRC_OMP)):
+        return _SO_OMP
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-o", _SO_OMP, _SRC_OMP])
+    return _SO_OMP
+
+
+def lib_omp():
+    global _lib_omp
+    if _lib_omp is None:
+        build_omp()
+        _lib_omp = ctypes.CDLL(_SO_OMP)
+    return _lib_omp
+
+
+class AllCoresMatvec(object):
+    """(P^T N^-1 P) x on `threads` host threads for a pol-interleaved map: P and P^T through
+    the OpenMP loops, the banded-Toeplitz blocks (zero boundary) as scipy.signal.fftconvolve
+    'same' with the symmetric 2*lambda-1 kernel, one block per pool thread."""
+
+    def __init__(self, pol, npix, pix, cos, sin, blocksize, bands, threads):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pol, self.npix, self.threads = pol, int(npix), int(threads)
+        self.pix, self.cos, self.sin = _i32(pix), _f64(cos), _f64(sin)
+        self.nt = self.pix.size
+        self.bs = int(blocksize)
+        self.kernels = [np.concatenate([np.asarray(b)[:0:-1], np.asarray(b)]) for b in bands]
+        self.scratch = np.empty(self.threads * pol * self.npix)
+        self.pool = ThreadPoolExecutor(self.threads)
+
+    def __call__(self, x):
+        from scipy.signal import fftconvolve
+        L = lib_omp()
+        x = _f64(x)
+        tod = np.empty(self.nt)
+        L.orc_omp_P_apply(self.pol, ctypes.c_int64(self.nt), self.pix.ctypes.data_as(_I32),
+                          _d(self.cos), _d(self.sin), _d(x), _d(tod), self.threads)
+        out_tod = np.empty(self.nt)
+
+        def one(b):
+            a, e = b * self.bs, min((b + 1) * self.bs, self.nt)
+            out_tod[a:e] = fftconvolve(tod[a:e], self.kernels[b], mode="same")
+        list(self.pool.map(one, range(len(self.kernels))))
+        out = np.empty(self.pol * self.npix)
+        L.orc_omp_Pt_apply(self.pol, ctypes.c_int64(self.nt), ctypes.c_int64(self.npix),
+                           self.pix.ctypes.data_as(_I32), _d(self.cos), _d(self.sin), _d(out_tod),
+                           _d(out), _d(self.scratch), self.threads)
+        return out

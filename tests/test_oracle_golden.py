@@ -210,3 +210,21 @@ def test_ground_filter_oracle():
             np.testing.assert_allclose(y[sel], v[sel] - v[sel].mean(), atol=1e-13)
     np.testing.assert_array_equal(y[g == -1], v[g == -1])
     np.testing.assert_allclose(O.ground_filter(g, y), y, atol=1e-13)
+
+
+def test_all_cores_baseline_equals_serial_oracle(oracle):
+    """bench.py's all-cores host baseline (OpenMP pointing loops + FFT Toeplitz per block)
+    against the serial reference-order oracle."""
+    rng = np.random.default_rng(0)
+    pol, npix, nt, nb, lam = 3, 500, 40000, 4, 33
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    pairs[rng.random(nt) < 0.05] = -1
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    kk = np.arange(lam)
+    bands = [(1 + 0.1 * b) * np.exp(-kk / 8.0) for b in range(nb)]
+    x = rng.standard_normal(pol * npix)
+    ref = oracle.sparse_rmult(pol, npix, pairs, c, s, oracle.blocklo_mult(
+        nt // nb, bands, True, oracle.sparse_mult(pol, pairs, c, s, x)))
+    for threads in (1, 3):
+        y = oracle.AllCoresMatvec(pol, npix, pairs, c, s, nt // nb, bands, threads)(x)
+        assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-13
