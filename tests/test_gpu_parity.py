@@ -1048,3 +1048,50 @@ def test_full_size_properties_c4(cm):
         np.testing.assert_allclose(r[bs:bs + lam].cpu().numpy(), bands[1], rtol=0,
                                    atol=1e-12 * abs(bands[1][0]))
         assert float(r[bs + lam:bs + 3 * lam].abs().max()) < 1e-12 * abs(bands[1][0])
+
+
+def test_config_c1_reference_runnable_case(cm, oracle):
+    """BASELINE configs[0]: nside 16, temperature only, 1e4 samples, N = I, block-diagonal
+    preconditioner -- the case the reference itself runs on a CPU.  Whole solve on the GPU
+    against the oracle's operators driven by the LOCAL scipy.sparse.linalg.cg (the solver the
+    reference calls): same solution, same residual history, same iteration count; with M_BD
+    (the exact inverse of the diagonal A = P^T P) one iteration."""
+    import scipy.sparse.linalg as spla
+    nside, nt, pol, nb = 16, 10000, 1, 10
+    npix = 12 * nside * nside
+    rng = np.random.default_rng(20161202)
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol)
+    CES = cm.U.ProcessTimeSamples(pairs, npix, pol=pol)
+    n = CES.get_new_pixel[0]
+    assert n == ro.new_npix and n < npix                 # ~3 hits per pixel: some never seen
+    np.testing.assert_array_equal(pairs, po)
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol)
+    N = cm.I.BlockLO(nt // nb, [1.0] * nb)               # N = I
+    M = cm.I.BlockDiagonalPreconditionerLO(CES, n, pol)
+    A = P.T * N * P
+    b = P.T * (N * d)
+    A_o = spla.LinearOperator((n, n), dtype=np.float64, matvec=lambda x: oracle.sparse_rmult(
+        pol, n, po, None, None, oracle.sparse_mult(pol, po, None, None, x)))
+    M_o = spla.LinearOperator((n, n), dtype=np.float64,
+                              matvec=lambda x: oracle.bd_precond_mult(pol, ro, x))
+    b_o = oracle.sparse_rmult(pol, n, po, None, None, d)
+    np.testing.assert_array_equal(b, b_o)
+    # without preconditioner: CG needs one iteration per distinct hit count
+    hist_g, hist_o = [], []
+    xg, ig = cm.cg(A, b, rtol=1e-6, callback=lambda x: hist_g.append(np.linalg.norm(b - A * x)))
+    xo, io = spla.cg(A_o, b_o, rtol=1e-6, callback=lambda x: hist_o.append(
+        np.linalg.norm(b_o - A_o.matvec(x))))
+    assert ig == 0 and io == 0 and len(hist_g) == len(hist_o) > 3
+    np.testing.assert_allclose(hist_g, hist_o, rtol=1e-8, atol=1e-12 * np.linalg.norm(b))
+    assert rel_l2(xg, xo) < 1e-10
+    # with M_BD: one iteration, map = hit-weighted mean of the samples per pixel
+    its = []
+    xm, im = cm.cg(A, b, M=M, rtol=1e-6, callback=lambda x: its.append(1))
+    xs, i_s = spla.cg(A_o, b_o, M=M_o, rtol=1e-6)
+    assert im == 0 and i_s == 0 and len(its) == 1
+    assert rel_l2(xm, xs) < 1e-12
+    binned = np.bincount(po[po >= 0], weights=d[po >= 0], minlength=n) / np.bincount(
+        po[po >= 0], minlength=n)
+    assert rel_l2(xm, binned) < 1e-12
