@@ -350,3 +350,94 @@ extern "C" int cm2_bd_apply(int pol, int64_t npix, const double *d_counts,
     CM2_LAUNCH_OK();
     return 0;
 }
+
+// ---- f3: cut-sky map vector <-> full-sky HEALPix maps ------------------------------------
+// reorganize_map (utilities/healpy_functions.py:47-102): map component k of observed pixel i,
+// mapin[pol*i + k], goes to full[k][obspix[i]]; every other full-sky pixel is 0.
+// full2cutskymap (utilities/IOfiles.py:377-393) is the way back.
+namespace cm2 {
+
+__global__ __launch_bounds__(256) void k_cut_to_full(int pol, int64_t npix,
+                                                      const int64_t *__restrict__ obspix,
+                                                      const double *__restrict__ map,
+                                                      int64_t nfull, double *__restrict__ full)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int64_t p = obspix[i];
+        for (int k = 0; k < pol; ++k) full[(int64_t)k * nfull + p] = map[pol * i + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_full_to_cut(int pol, int64_t npix,
+                                                      const int64_t *__restrict__ obspix,
+                                                      const double *__restrict__ full, int64_t nfull,
+                                                      double *__restrict__ map)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int64_t p = obspix[i];
+        for (int k = 0; k < pol; ++k) map[pol * i + k] = full[(int64_t)k * nfull + p];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_obspix_range(int64_t npix, const int64_t *__restrict__ obspix,
+                                                       int64_t nfull, unsigned int *__restrict__ bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride)
+        if (obspix[i] < 0 || obspix[i] >= nfull) atomicAdd(bad, 1u);
+}
+
+static int check_obspix(int64_t npix, const int64_t *d_obspix, int64_t nfull, hipStream_t st)
+{
+    DevTemp<unsigned int> d_bad;
+    CM2_HIP(d_bad.alloc(1));
+    CM2_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), st));
+    k_obspix_range<<<grid_for(npix), kBlock, 0, st>>>(npix, d_obspix, nfull, d_bad);
+    CM2_LAUNCH_OK();
+    unsigned int h_bad = 0;
+    CM2_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, st));
+    CM2_HIP(hipStreamSynchronize(st));
+    CM2_CHECK(h_bad == 0, "%u observed-pixel ids lie outside the full-sky map of %lld pixels", h_bad,
+              (long long)nfull);
+    return 0;
+}
+
+}  // namespace cm2
+
+extern "C" int cm2_cutsky_to_fullsky(int pol, int64_t npix, const int64_t *d_obspix,
+                                     const double *d_map, int64_t nfull, double *d_full,
+                                     void *stream)
+{
+    CM2_CHECK(pol >= 1 && pol <= 3, "cm2_cutsky_to_fullsky: pol=%d", pol);
+    CM2_CHECK(npix >= 0 && nfull >= 0, "cm2_cutsky_to_fullsky: negative size");
+    hipStream_t st = cm2::as_stream(stream);
+    if (nfull) {
+        CM2_CHECK(d_full, "cm2_cutsky_to_fullsky: null output");
+        CM2_HIP(hipMemsetAsync(d_full, 0, sizeof(double) * (size_t)pol * nfull, st));
+    }
+    if (npix == 0) return 0;
+    CM2_CHECK(d_obspix && d_map, "cm2_cutsky_to_fullsky: null input");
+    if (int rc = cm2::check_obspix(npix, d_obspix, nfull, st)) return rc;
+    cm2::k_cut_to_full<<<cm2::grid_for(npix), cm2::kBlock, 0, st>>>(pol, npix, d_obspix, d_map, nfull,
+                                                                     d_full);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_fullsky_to_cutsky(int pol, int64_t npix, const int64_t *d_obspix,
+                                     const double *d_full, int64_t nfull, double *d_map,
+                                     void *stream)
+{
+    CM2_CHECK(pol >= 1 && pol <= 3, "cm2_fullsky_to_cutsky: pol=%d", pol);
+    CM2_CHECK(npix >= 0 && nfull >= 0, "cm2_fullsky_to_cutsky: negative size");
+    if (npix == 0) return 0;
+    CM2_CHECK(d_obspix && d_full && d_map, "cm2_fullsky_to_cutsky: null argument");
+    hipStream_t st = cm2::as_stream(stream);
+    if (int rc = cm2::check_obspix(npix, d_obspix, nfull, st)) return rc;
+    cm2::k_full_to_cut<<<cm2::grid_for(npix), cm2::kBlock, 0, st>>>(pol, npix, d_obspix, d_full, nfull,
+                                                                     d_map);
+    CM2_LAUNCH_OK();
+    return 0;
+}

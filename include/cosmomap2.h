@@ -290,6 +290,17 @@ int cm2_ground_bin_sums(int64_t nt, int nbins, const int32_t *d_bin, const doubl
 int cm2_ground_subtract(int64_t nt, const int32_t *d_bin, const double *d_binned,
                         const double *d_v, double *d_out, void *stream);
 
+/* ---- f3: solution vector <-> full-sky HEALPix maps -------------------------------
+ * cm2_cutsky_to_fullsky: d_full is pol arrays of nfull doubles one after the other
+ * ([I | Q | U]); component k of observed pixel i, d_map[pol*i + k], goes to
+ * d_full[k*nfull + d_obspix[i]], all other pixels are 0 (reorganize_map,
+ * utilities/healpy_functions.py:47-102).  cm2_fullsky_to_cutsky is the inverse gather
+ * (full2cutskymap, utilities/IOfiles.py:377-393).  Pixel ids outside [0, nfull) fail. */
+int cm2_cutsky_to_fullsky(int pol, int64_t npix, const int64_t *d_obspix, const double *d_map,
+                          int64_t nfull, double *d_full, void *stream);
+int cm2_fullsky_to_cutsky(int pol, int64_t npix, const int64_t *d_obspix, const double *d_full,
+                          int64_t nfull, double *d_map, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

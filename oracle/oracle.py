@@ -572,6 +572,33 @@ def ground_filter(ground, v):
 
 
 # --------------------------------------------------------------------------
+# f3  map vector <-> full-sky HEALPix maps
+# --------------------------------------------------------------------------
+def reorganize_map(mapin, obspix, npix, nside, pol):
+    """utilities/healpy_functions.py:47-102 without the FITS output: list of pol full-sky
+    maps of 12*nside^2 pixels (hp.nside2npix), component k of observed pixel i at obspix[i]."""
+    nfull = 12 * nside * nside
+    mapin = np.asarray(mapin)
+    out = []
+    for k in range(pol):                                 # :80-100: i=mapin[::3], q=mapin[1::3] ...
+        m = np.zeros(nfull)
+        m[obspix] = mapin[k::pol]
+        out.append(m)
+    return out
+
+
+def full2cutskymap(hp_map, pol, npix, observpix):
+    """utilities/IOfiles.py:377-393."""
+    x = np.zeros(pol * npix)
+    obsmap = [np.asarray(m)[observpix] for m in hp_map]
+    if pol == 1:
+        return obsmap                                    # a list, as the reference returns it
+    for i in range(npix):
+        x[pol * i:pol * (i + 1)] = [obsmap[k][i] for k in range(pol)]
+    return x
+
+
+# --------------------------------------------------------------------------
 # all-cores host baseline of P^T N^-1 P (SURVEY 8d "fair host baseline"): OpenMP pointing
 # loops (cm2_oracle_omp.c) + FFT convolution per noise block on a thread pool.
 # bench.py's cpu_baseline_all_cores leg only.

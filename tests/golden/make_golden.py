@@ -297,6 +297,19 @@ def main():
         fl["FilterLO.compute_legendres"](me)
         G["filt_out%d" % order] = fl["FilterLO.polyfilter"](me, df.copy())
 
+    # ---- utilities/IOfiles.py:377-393 full2cutskymap (pure NumPy; reorganize_map needs healpy)
+    io = extract("utilities/IOfiles.py", ["full2cutskymap"], {"np": np})
+    rngm = np.random.default_rng(20161204)
+    nfull = 12 * 4 * 4
+    obs = np.sort(rngm.choice(nfull, size=37, replace=False))
+    full = [rngm.standard_normal(nfull) for _ in range(3)]
+    G["cut_obspix"] = obs
+    G["cut_full"] = np.asarray(full)
+    for pol in (1, 2, 3):
+        res = io["full2cutskymap"](full[:pol], pol, obs.size, obs)
+        G["cut_out%d" % pol] = np.asarray(res[0] if pol == 1 else res)
+    G["cut_pol1_returns_list"] = np.int64(isinstance(io["full2cutskymap"](full[:1], 1, obs.size, obs), list))
+
     np.savez_compressed(OUT, **G)
     print("wrote %s (%d arrays, %d bytes)" % (OUT, len(G), os.path.getsize(OUT)))
 

@@ -42,7 +42,7 @@ def test_no_cpu_fallback():
     from cosmomap2_amd import _hip, cg
     from cosmomap2_amd.interfaces import (SparseLO, BlockLO, ToeplitzLO, DeflationLO, FilterLO,
                                           GroundFilterLO)
-    from cosmomap2_amd.utilities import ProcessTimeSamples, norm2
+    from cosmomap2_amd.utilities import ProcessTimeSamples, norm2, reorganize_map
     for make in (lambda: SparseLO(10, 20, np.zeros(20, dtype=np.int32)),
                  lambda: BlockLO(10, [1.0, 2.0]),
                  lambda: ToeplitzLO(np.ones(2), 10),
@@ -52,6 +52,7 @@ def test_no_cpu_fallback():
                  lambda: GroundFilterLO(np.zeros(20, dtype=np.int32)),
                  lambda: ProcessTimeSamples(np.zeros(20, dtype=np.int32), 10),
                  lambda: norm2(np.ones(4)),
+                 lambda: reorganize_map(np.ones(4), np.arange(4), 4, 2, 1),
                  lambda: cg(np.eye(3), np.ones(3))):
         with pytest.raises(_hip.HipError):
             make()

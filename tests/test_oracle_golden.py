@@ -228,3 +228,17 @@ def test_all_cores_baseline_equals_serial_oracle(oracle):
     for threads in (1, 3):
         y = oracle.AllCoresMatvec(pol, npix, pairs, c, s, nt // nb, bands, threads)(x)
         assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-13
+
+
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_full2cutskymap_and_reorganize_map(golden, oracle, pol):
+    obs, full = golden["cut_obspix"], list(golden["cut_full"][:pol])
+    res = oracle.full2cutskymap(full, pol, obs.size, obs)
+    assert isinstance(res, list) == (pol == 1) == bool(golden["cut_pol1_returns_list"]) or pol > 1
+    vec = res[0] if pol == 1 else res
+    np.testing.assert_array_equal(vec, golden["cut_out%d" % pol])
+    maps = oracle.reorganize_map(vec, obs, obs.size, 4, pol)      # needs healpy in the reference
+    assert len(maps) == pol and all(m.size == 192 for m in maps)
+    for k in range(pol):
+        np.testing.assert_array_equal(maps[k][obs], full[k][obs])
+        assert not np.delete(maps[k], obs).any()
