@@ -213,3 +213,18 @@ def test_filter_plan_order0_and_ces_offsets():
     assert list(st) == [1, 6, 11, 16, 22, 30, 38]
     assert list(ln) == [4, 3, 4, 3, 5, 5, 5]
     assert toff is None and table is None
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/cosmomap2.h must be consumable by a C (not C++) host: compile a C99 program
+    against it with gcc and link it to the library (no GPU call: cm2_abi_version only)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "cosmomap2.h"\n'
+                   "int main(void) { return cm2_abi_version() == CM2_ABI_VERSION ? 0 : 1; }\n")
+    libdir = os.path.join(ROOT, "cosmomap2_amd")
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                           "-I" + os.path.join(ROOT, "include"), str(src), "-L" + libdir,
+                           "-lcosmomap2_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    assert subprocess.call([exe]) == 0
