@@ -44,6 +44,7 @@ struct cm2_tiles {
     int32_t *d_item_tile = nullptr; // [nitems]
     int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
     int64_t *d_item_k1 = nullptr;
+    std::vector<int64_t> tile_item0;   // [ntiles+1] first work item of every tile (host)
 };
 
 // ------------------------------------------------------------------ build -------
@@ -318,12 +319,16 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     // work items: every tile bucket cut into slices of <= slice_samples
     std::vector<int32_t> it_tile;
     std::vector<int64_t> it_k0, it_k1;
-    for (int64_t b = 0; b < t->ntiles; ++b)
+    t->tile_item0.assign((size_t)t->ntiles + 1, 0);
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        t->tile_item0[(size_t)b] = (int64_t)it_tile.size();
         for (int64_t k = off[b]; k < off[b + 1]; k += slice_samples) {
             it_tile.push_back((int32_t)b);
             it_k0.push_back(k);
             it_k1.push_back(k + slice_samples < off[b + 1] ? k + slice_samples : off[b + 1]);
         }
+    }
+    t->tile_item0[(size_t)t->ntiles] = (int64_t)it_tile.size();
     t->nitems = (int64_t)it_tile.size();
     const int64_t ni = t->nitems > 0 ? t->nitems : 1;
     CM2_HIP(hipMalloc(&t->d_item_tile, sizeof(int32_t) * ni));
@@ -381,6 +386,31 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
                                                              d_tod_tb, d_out)
     if (t->pol == 1) CM2_PTT(1); else if (t->pol == 2) CM2_PTT(2); else CM2_PTT(3);
 #undef CM2_PTT
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_tb, double *d_out,
+                                        int64_t tile_lo, int64_t tile_hi, void *stream_)
+{
+    CM2_CHECK(t && d_out && (d_tod_tb || t->nvalid == 0), "cm2_Pt_tiles_apply_range: NULL argument");
+    CM2_CHECK(tile_lo >= 0 && tile_lo <= tile_hi && tile_hi <= t->ntiles,
+              "cm2_Pt_tiles_apply_range: tiles [%lld, %lld) outside [0, %lld]", (long long)tile_lo,
+              (long long)tile_hi, (long long)t->ntiles);
+    if (tile_lo == tile_hi) return 0;
+    hipStream_t stream = as_stream(stream_);
+    const int64_t p0 = tile_lo * t->tp;
+    const int64_t p1 = tile_hi * t->tp < t->npix ? tile_hi * t->tp : t->npix;
+    CM2_HIP(hipMemsetAsync(d_out + p0 * t->pol, 0, sizeof(double) * (p1 - p0) * t->pol, stream));
+    const int64_t i0 = t->tile_item0[(size_t)tile_lo], i1 = t->tile_item0[(size_t)tile_hi];
+    if (i1 == i0) return 0;
+    const size_t lds = sizeof(double) * t->tp * t->pol;
+#define CM2_PTR(POL)                                                                           \
+    k_Pt_tiles<POL><<<(int)(i1 - i0), tile_block(), lds, stream>>>(                            \
+        t->tp, t->npix, t->d_item_tile + i0, t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl,    \
+        t->d_cos, t->d_sin, d_tod_tb, d_out)
+    if (t->pol == 1) CM2_PTR(1); else if (t->pol == 2) CM2_PTR(2); else CM2_PTR(3);
+#undef CM2_PTR
     CM2_LAUNCH_OK();
     return 0;
 }

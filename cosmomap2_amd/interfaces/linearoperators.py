@@ -231,7 +231,22 @@ class _TiledNormalLO(_DeviceOp):
         n = P.pol * P.ncols
         super(_TiledNormalLO, self).__init__(n, n, self._mult, symmetric=True)
 
-    def _mult(self, v):
+    def reduced_matvec(self, v, reducer, ngroups=4):
+        """``sum over ranks of (P^T N^-1 P) v`` with the cross-rank reduction of a finished
+        part of the map overlapped with the back-projection of the next part: P^T runs tile
+        group by tile group and ``reducer(view)`` (an asynchronous in-place sum, returning an
+        object with ``wait()``) is started on each group's slice of the output as soon as its
+        kernel is queued.  Returns None when this operator cannot do it (noise operator not
+        on the fused tile path); the caller then reduces the whole vector itself."""
+        if not D.is_dev(v):
+            return None
+        if self._fused_noise is None:
+            self._fused_noise = self.noise.noise_info()["method"] == 3
+        if not self._fused_noise:
+            return None
+        return self._mult(v, reducer=reducer, ngroups=int(ngroups))
+
+    def _mult(self, v, reducer=None, ngroups=1):
         P = self.P
         T = _sparse_tiles(P)
         x = D.f64(v)
@@ -252,8 +267,21 @@ class _TiledNormalLO(_DeviceOp):
             _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
                       D.ptr(v_tb), st)
             out = D.empty(P.pol * P.ncols)
-            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
-            return D.like_input(out, v)
+            if reducer is None:
+                _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+                return D.like_input(out, v)
+            ngroups = max(1, min(ngroups, T.ntiles))
+            works = []
+            for g in range(ngroups):
+                lo, hi = T.ntiles * g // ngroups, T.ntiles * (g + 1) // ngroups
+                _hip.call("cm2_Pt_tiles_apply_range", T.h, D.ptr(v_tb), D.ptr(out), lo, hi, st)
+                a = P.pol * lo * T.tile_pixels
+                b = min(P.pol * hi * T.tile_pixels, out.numel())
+                works.append(reducer(out[a:b]))
+            for w in works:
+                if w is not None:
+                    w.wait()
+            return out
         tod = D.empty(P.nrows)
         _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
         tod2 = self.noise._apply_all(tod)

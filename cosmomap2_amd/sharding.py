@@ -101,7 +101,29 @@ class ShardedLO(lp.LinearOperator):
         super(ShardedLO, self).__init__(n, n, self._mult, symmetric=True,
                                         device_ok=lp.supports_device(local_op))
 
+    def _overlapped(self, x):
+        """Tile-order chain with a fused noise operator: reduce tile groups while the next
+        ones are still being back-projected (CM2_ALLREDUCE_CHUNKS groups, default 4; 0 or 1
+        = one all-reduce after the matvec)."""
+        import os
+        dist = torch.distributed
+        chunks = int(os.environ.get("CM2_ALLREDUCE_CHUNKS", "4"))
+        if chunks <= 1 or not (dist.is_available() and dist.is_initialized()) \
+                or dist.get_world_size(self.group) == 1:
+            return None
+        plan = getattr(self.local_op, "_compiled", None)
+        ops = plan() if plan is not None else [self.local_op]
+        if len(ops) != 1 or not hasattr(ops[0], "reduced_matvec"):
+            return None
+        group = self.group
+        return ops[0].reduced_matvec(
+            x, lambda view: dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True),
+            chunks)
+
     def _mult(self, x):
+        y = self._overlapped(x)
+        if y is not None:
+            return y
         y = self.local_op.matvec(x)
         if isinstance(y, np.ndarray):
             y = np.ascontiguousarray(y)

@@ -96,6 +96,11 @@ int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
 /* d_out = P^T v for a TB-ordered v (d_out is overwritten) */
 int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, double *d_out, void *stream);
+/* P^T restricted to the tiles [tile_lo, tile_hi): overwrites the entries of d_out that belong to
+ * those tiles (pixels tile_lo*tile_pixels .. min(tile_hi*tile_pixels, npix)) and nothing else, so
+ * that a finished part of the map can be reduced across GPUs while the next part is computed. */
+int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_tb, double *d_out,
+                             int64_t tile_lo, int64_t tile_hi, void *stream);
 /* permutations between time order (nt, flagged samples read as / written with 0) and TB order */
 int cm2_tod_time_to_tiles(const cm2_tiles *t, const double *d_time, double *d_tb, void *stream);
 int cm2_tod_tiles_to_time(const cm2_tiles *t, const double *d_tb, double *d_time, void *stream);

@@ -1,0 +1,26 @@
+"""
+Two ranks, TOD sharded at noise-block boundaries, on the one GPU of the test box (gloo
+transport; RCCL needs one GPU per rank): the reduced matvec with the chunked, overlapped
+all-reduce against the single all-reduce and against the same problem on one rank, and a
+PCG solve with the residual norm synchronised across ranks.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_one_gpu():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "_sharded_worker.py")]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "SHARDED-OK" in res.stdout, res.stdout[-2000:]
