@@ -522,24 +522,24 @@ constexpr int kRegHop = 4096, kRegHalo = 2048;
 constexpr int kRegCh = CM2_REG_CH;
 constexpr int kRegL1 = kRegN, kRegL2 = kRegHop, kRegLS = 2 * kRegHop;     // list lengths per pair
 
-template <int LEN, class F>
-__device__ __forceinline__ void reg_list_walk(const uint32_t *__restrict__ lk,
-                                              const uint16_t *__restrict__ lq, int t, F f)
+// walk LEN (address, position) entries, kRegCh per thread at a time: gen(e, k, q) yields entry e
+template <int LEN, class G, class F>
+__device__ __forceinline__ void reg_walk(int t, G gen, F f)
 {
 #pragma unroll 1
     for (int c0 = 0; c0 < LEN / kRegT; c0 += kRegCh) {
         uint32_t kk[kRegCh];
         int qq[kRegCh];
 #pragma unroll
-        for (int u = 0; u < kRegCh; ++u) {
-            const int e = t + (c0 + u) * kRegT;
-            kk[u] = lk[e];
-            qq[u] = (int)lq[e];
-        }
+        for (int u = 0; u < kRegCh; ++u) gen(t + (c0 + u) * kRegT, kk[u], qq[u]);
         f(kk, qq);
     }
 }
 
+// LISTS: the TODs are in the tile-bucketed order and reached through the three address-sorted
+// lists of the pair; otherwise they are in time order and entry e of a walk is simply sample
+// (window start + e) -- the same code path with computed instead of loaded addresses.
+template <bool LISTS>
 __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     const PairDesc *__restrict__ pairs, int npairs, const double2 *__restrict__ W,
     const double *__restrict__ Hperm,
@@ -562,8 +562,19 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     // ---- load the union window: U[m] = sample (a_start - HALO) + t + 256 m ----
     double U[48];
     {
-        reg_list_walk<kRegL1>(l1_k + (int64_t)pair_id * kRegL1, l1_q + (int64_t)pair_id * kRegL1, t,
-                              [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+        const uint32_t *__restrict__ lk1 = LISTS ? l1_k + (int64_t)pair_id * kRegL1 : nullptr;
+        const uint16_t *__restrict__ lq1 = LISTS ? l1_q + (int64_t)pair_id * kRegL1 : nullptr;
+        const int64_t w0 = pd.a_start - kRegHalo;         // time of window position 0
+        reg_walk<kRegL1>(t, [&](int e, uint32_t &k, int &q) {
+            if (LISTS) {
+                k = lk1[e];
+                q = (int)lq1[e];
+            } else {
+                const int64_t ts = w0 + e;
+                k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
+                q = e;
+            }
+        }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
             double vv[kRegCh];
 #pragma unroll
             for (int u = 0; u < kRegCh; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
@@ -575,8 +586,18 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
         for (int m = 0; m < 32; ++m) U[m] = b1[reg_off<1>(m)];
         __syncthreads();
         if (has_b) {
-            reg_list_walk<kRegL2>(l2_k + (int64_t)pair_id * kRegL2, l2_q + (int64_t)pair_id * kRegL2,
-                                  t, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+            const uint32_t *__restrict__ lk2 = LISTS ? l2_k + (int64_t)pair_id * kRegL2 : nullptr;
+            const uint16_t *__restrict__ lq2 = LISTS ? l2_q + (int64_t)pair_id * kRegL2 : nullptr;
+            reg_walk<kRegL2>(t, [&](int e, uint32_t &k, int &q) {
+                if (LISTS) {
+                    k = lk2[e];
+                    q = (int)lq2[e];
+                } else {
+                    const int64_t ts = w0 + kRegL1 + e;
+                    k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
+                    q = e;
+                }
+            }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
                 double vv[kRegCh];
 #pragma unroll
                 for (int u = 0; u < kRegCh; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
@@ -648,8 +669,19 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
             b1[reg_off<1>(m + 16)] = zi[brev<32>(m + 8)];
         }
         __syncthreads();
-        reg_list_walk<kRegLS>(ls_k + (int64_t)pair_id * kRegLS, ls_q + (int64_t)pair_id * kRegLS, t,
-                              [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
+        const uint32_t *__restrict__ lks = LISTS ? ls_k + (int64_t)pair_id * kRegLS : nullptr;
+        const uint16_t *__restrict__ lqs = LISTS ? ls_q + (int64_t)pair_id * kRegLS : nullptr;
+        reg_walk<kRegLS>(t, [&](int e, uint32_t &k, int &q) {
+            if (LISTS) {
+                k = lks[e];
+                q = (int)lqs[e];
+            } else {
+                // result j: segment A for j < 4096, segment B (b_start = a_start + 4096) after
+                const bool ok = e < kRegHop ? e < pd.a_len : e - kRegHop < pd.b_len;
+                k = ok ? (uint32_t)(pd.a_start + e) : kInvalidSample;
+                q = e;
+            }
+        }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
 #pragma unroll
             for (int u = 0; u < kRegCh; ++u)
                 if (kk[u] != kInvalidSample) out[kk[u]] = buf[padi(qq[u])];
@@ -990,17 +1022,19 @@ static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, do
     return 0;
 }
 
+template <bool LISTS>
 static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
     static bool attr_set = false;
     if (!attr_set) {
-        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg,
+        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg<LISTS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    if (f->npairs_reg == 0) return 0;
     const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
-    k_overlap_save_reg<<<grid, kRegT, lds, stream>>>(
+    k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
         f->d_pairs_reg, (int)f->npairs_reg, f->d_W, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
         f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
     CM2_LAUNCH_OK();
@@ -1032,7 +1066,8 @@ static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, 
 {
     if (f->real_variant) return launch_real<INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->npairs == 0) return 0;
-    if (INDIRECT && f->d_l1_k) return launch_reg(f, d_v, d_out, stream);
+    if (INDIRECT && f->d_l1_k) return launch_reg<true>(f, d_v, d_out, stream);
+    if (!INDIRECT && f->reg_variant) return launch_reg<false>(f, d_v, d_out, stream);
     if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
     return launch<16, 16, 2, INDIRECT>(f, d_idx, d_v, d_out, stream);
