@@ -40,7 +40,13 @@ struct cm2_tiles {
     int64_t ntiles = 0, nitems = 0;
     uint32_t *d_tb_dst = nullptr;   // [nt]
     uint16_t *d_pl = nullptr;       // [nvalid]
-    double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]
+    double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]  (full-angle mode)
+    // half-angle mode: ONE double per sample, h = sin / (1 + |cos|) (= tan of half the angle
+    // folded into [-1, 1]) and the sign of cos in bit 15 of d_pl; cos = +-(1 - h^2)/(1 + h^2),
+    // sin = 2h/(1 + h^2) are rebuilt in the kernels (absolute error ~2e-16): 8 bytes less per
+    // sample in each of the two tile kernels
+    bool half = false;
+    double *d_half = nullptr;                    // [nvalid]
     int32_t *d_item_tile = nullptr; // [nitems]
     int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
     int64_t *d_item_k1 = nullptr;
@@ -74,7 +80,22 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict_
     off[b] = lo;
 }
 
-template <int POL>
+// 1 if some (cos, sin) pair is not on the unit circle to rounding: then the half-angle form
+// would change the operator and the full arrays are kept
+__global__ __launch_bounds__(256) void k_unit_circle(int64_t nt, const double *__restrict__ c,
+                                                      const double *__restrict__ s,
+                                                      unsigned int *__restrict__ off_circle)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const double r = c[i] * c[i] + s[i] * s[i] - 1.0;
+        if (!(fabs(r) <= 1e-14)) bad = 1;
+    }
+    if (bad) atomicOr(off_circle, 1u);
+}
+
+template <int POL, bool HALF>
 __global__ __launch_bounds__(256) void k_tile_fill(
     int64_t nt, int64_t nvalid, int tp, const uint32_t *__restrict__ tb_src,
     const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
@@ -86,20 +107,55 @@ __global__ __launch_bounds__(256) void k_tile_fill(
         const uint32_t t = tb_src[k];
         if (k < nvalid) {
             tb_dst[t] = (uint32_t)k;
-            pl[k] = (uint16_t)(pix[t] % tp);
+            uint16_t w = (uint16_t)(pix[t] % tp);
             if (POL > 1) {
-                ctb[k] = c[t];
-                stb[k] = s[t];
+                if (HALF) {
+                    const double cv = c[t], sv = s[t];
+                    if (cv < 0.0) {
+                        w |= 0x8000;
+                        ctb[k] = sv / (1.0 - cv);
+                    } else {
+                        ctb[k] = sv / (1.0 + cv);
+                    }
+                } else {
+                    ctb[k] = c[t];
+                    stb[k] = s[t];
+                }
             }
+            pl[k] = w;
         } else {
             tb_dst[t] = kInvalidSample;      // flagged samples sort behind every tile
         }
     }
 }
 
+// (pixel in tile, cos, sin) of TB sample k in either storage form
+template <int POL, bool HALF>
+__device__ __forceinline__ void tile_sample(const uint16_t *__restrict__ pl,
+                                            const double *__restrict__ c,
+                                            const double *__restrict__ s, int64_t k, int &q,
+                                            double &cc, double &ss)
+{
+    const uint16_t w = pl[k];
+    if (POL == 1) {
+        q = w;
+        cc = ss = 0.0;
+    } else if (HALF) {
+        q = w & 0x7FFF;
+        const double h = c[k], h2 = h * h, inv = 1.0 / (1.0 + h2);
+        cc = (1.0 - h2) * inv;
+        ss = (h + h) * inv;
+        if (w & 0x8000) cc = -cc;
+    } else {
+        q = w;
+        cc = c[k];
+        ss = s[k];
+    }
+}
+
 // ------------------------------------------------------------------ P (TB) ------
 // one workgroup per work item = (tile, contiguous slice of its bucket)
-template <int POL>
+template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_P_tiles(
     int tp, int64_t npix, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
@@ -117,21 +173,23 @@ __global__ __launch_bounds__(1024) void k_P_tiles(
     __syncthreads();
     const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
     for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        const int q = pl[k];
+        int q;
+        double cc, ss;
+        tile_sample<POL, HALF>(pl, c, s, k, q, cc, ss);
         double r = 0.0;
         if (POL == 1) {
             r += tile[q];
         } else if (POL == 2) {
-            r += tile[2 * q] * c[k] + tile[2 * q + 1] * s[k];
+            r += tile[2 * q] * cc + tile[2 * q + 1] * ss;
         } else {
-            r += tile[3 * q] + tile[3 * q + 1] * c[k] + tile[3 * q + 2] * s[k];
+            r += tile[3 * q] + tile[3 * q + 1] * cc + tile[3 * q + 2] * ss;
         }
         d_tb[k] = r;
     }
 }
 
 // ---------------------------------------------------------------- P^T (TB) ------
-template <int POL>
+template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_Pt_tiles(
     int tp, int64_t npix, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
@@ -155,12 +213,8 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t kk = k + u * (int64_t)blockDim.x;
-            q[u] = pl[kk];
             v[u] = v_tb[kk];
-            if (POL > 1) {
-                cc[u] = c[kk];
-                ss[u] = s[kk];
-            }
+            tile_sample<POL, HALF>(pl, c, s, kk, q[u], cc[u], ss[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -177,17 +231,19 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
         }
     }
     for (; k < k1; k += blockDim.x) {
-        const int q = pl[k];
+        int q;
+        double c1, s1;
+        tile_sample<POL, HALF>(pl, c, s, k, q, c1, s1);
         const double v = v_tb[k];
         if (POL == 1) {
             atomicAdd(&tile[q], v);
         } else if (POL == 2) {
-            atomicAdd(&tile[2 * q], v * c[k]);
-            atomicAdd(&tile[2 * q + 1], v * s[k]);
+            atomicAdd(&tile[2 * q], v * c1);
+            atomicAdd(&tile[2 * q + 1], v * s1);
         } else {
             atomicAdd(&tile[3 * q], v);
-            atomicAdd(&tile[3 * q + 1], v * c[k]);
-            atomicAdd(&tile[3 * q + 2], v * s[k]);
+            atomicAdd(&tile[3 * q + 1], v * c1);
+            atomicAdd(&tile[3 * q + 2], v * s1);
         }
     }
     __syncthreads();
@@ -246,8 +302,8 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t);
 extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
-    void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_item_tile, t->d_item_k0,
-                    t->d_item_k1};
+    void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
+                    t->d_item_k0, t->d_item_k1};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete t;
@@ -304,15 +360,38 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     const int64_t nv = t->nvalid > 0 ? t->nvalid : 1;
     CM2_HIP(hipMalloc(&t->d_tb_dst, sizeof(uint32_t) * nt));
     CM2_HIP(hipMalloc(&t->d_pl, sizeof(uint16_t) * nv));
-    if (pol > 1) {
-        CM2_HIP(hipMalloc(&t->d_cos, sizeof(double) * nv));
-        CM2_HIP(hipMalloc(&t->d_sin, sizeof(double) * nv));
+    // half-angle storage (one double per sample instead of cos and sin) when every pair lies
+    // on the unit circle; CM2_TILE_ANGLES=full keeps both arrays
+    t->half = false;
+    if (pol > 1 && nt > 0 && tile_pixels <= 0x8000) {
+        const char *e = getenv("CM2_TILE_ANGLES");
+        if (!(e && strcmp(e, "full") == 0)) {
+            DevTemp<unsigned int> d_off_circle;
+            CM2_HIP(d_off_circle.alloc(1));
+            CM2_HIP(hipMemsetAsync(d_off_circle, 0, sizeof(unsigned int), stream));
+            k_unit_circle<<<grid_for(nt), kBlock, 0, stream>>>(nt, d_cos, d_sin, d_off_circle);
+            CM2_LAUNCH_OK();
+            unsigned int h_off = 0;
+            CM2_HIP(hipMemcpyAsync(&h_off, d_off_circle, sizeof(h_off), hipMemcpyDeviceToHost, stream));
+            CM2_HIP(hipStreamSynchronize(stream));
+            t->half = (h_off == 0);
+        }
     }
-#define CM2_TF(POL)                                                                            \
-    k_tile_fill<POL><<<grid_for(nt), kBlock, 0, stream>>>(nt, t->nvalid, tile_pixels, tb_src,  \
-                                                          d_pix, d_cos, d_sin, t->d_tb_dst,    \
-                                                          t->d_pl, t->d_cos, t->d_sin)
-    if (pol == 1) CM2_TF(1); else if (pol == 2) CM2_TF(2); else CM2_TF(3);
+    if (pol > 1) {
+        if (t->half) {
+            CM2_HIP(hipMalloc(&t->d_half, sizeof(double) * nv));
+        } else {
+            CM2_HIP(hipMalloc(&t->d_cos, sizeof(double) * nv));
+            CM2_HIP(hipMalloc(&t->d_sin, sizeof(double) * nv));
+        }
+    }
+#define CM2_TF(POL, HALF)                                                                      \
+    k_tile_fill<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                               \
+        nt, t->nvalid, tile_pixels, tb_src, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,         \
+        HALF ? t->d_half : t->d_cos, t->d_sin)
+    if (pol == 1) CM2_TF(1, false);
+    else if (pol == 2) { if (t->half) CM2_TF(2, true); else CM2_TF(2, false); }
+    else { if (t->half) CM2_TF(3, true); else CM2_TF(3, false); }
 #undef CM2_TF
     CM2_LAUNCH_OK();
 
@@ -349,7 +428,7 @@ extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
 {
     CM2_CHECK(t && h_info, "cm2_tiles_info: NULL argument");
     h_info[0] = t->nt; h_info[1] = t->nvalid; h_info[2] = t->tp;
-    h_info[3] = t->ntiles; h_info[4] = t->nitems;
+    h_info[3] = t->ntiles; h_info[4] = t->nitems; h_info[5] = t->half ? 1 : 0;
     return 0;
 }
 
@@ -360,12 +439,13 @@ extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *
     if (t->nitems == 0) return 0;
     hipStream_t stream = as_stream(stream_);
     const size_t lds = sizeof(double) * t->tp * t->pol;
-#define CM2_PT(POL)                                                                            \
-    k_P_tiles<POL><<<(int)t->nitems, tile_block(), lds, stream>>>(t->tp, t->npix, t->d_item_tile,    \
-                                                            t->d_item_k0, t->d_item_k1,        \
-                                                            t->d_pl, t->d_cos, t->d_sin, d_x,  \
-                                                            d_tod_tb)
-    if (t->pol == 1) CM2_PT(1); else if (t->pol == 2) CM2_PT(2); else CM2_PT(3);
+#define CM2_PT(POL, HALF)                                                                      \
+    k_P_tiles<POL, HALF><<<(int)t->nitems, tile_block(), lds, stream>>>(                       \
+        t->tp, t->npix, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
+        HALF ? t->d_half : t->d_cos, t->d_sin, d_x, d_tod_tb)
+    if (t->pol == 1) CM2_PT(1, false);
+    else if (t->pol == 2) { if (t->half) CM2_PT(2, true); else CM2_PT(2, false); }
+    else { if (t->half) CM2_PT(3, true); else CM2_PT(3, false); }
 #undef CM2_PT
     CM2_LAUNCH_OK();
     return 0;
@@ -379,12 +459,13 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
     CM2_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * t->npix * t->pol, stream));
     if (t->nitems == 0) return 0;
     const size_t lds = sizeof(double) * t->tp * t->pol;
-#define CM2_PTT(POL)                                                                           \
-    k_Pt_tiles<POL><<<(int)t->nitems, tile_block(), lds, stream>>>(t->tp, t->npix, t->d_item_tile,   \
-                                                             t->d_item_k0, t->d_item_k1,       \
-                                                             t->d_pl, t->d_cos, t->d_sin,      \
-                                                             d_tod_tb, d_out)
-    if (t->pol == 1) CM2_PTT(1); else if (t->pol == 2) CM2_PTT(2); else CM2_PTT(3);
+#define CM2_PTT(POL, HALF)                                                                     \
+    k_Pt_tiles<POL, HALF><<<(int)t->nitems, tile_block(), lds, stream>>>(                      \
+        t->tp, t->npix, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
+        HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
+    if (t->pol == 1) CM2_PTT(1, false);
+    else if (t->pol == 2) { if (t->half) CM2_PTT(2, true); else CM2_PTT(2, false); }
+    else { if (t->half) CM2_PTT(3, true); else CM2_PTT(3, false); }
 #undef CM2_PTT
     CM2_LAUNCH_OK();
     return 0;
@@ -405,11 +486,13 @@ extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_
     const int64_t i0 = t->tile_item0[(size_t)tile_lo], i1 = t->tile_item0[(size_t)tile_hi];
     if (i1 == i0) return 0;
     const size_t lds = sizeof(double) * t->tp * t->pol;
-#define CM2_PTR(POL)                                                                           \
-    k_Pt_tiles<POL><<<(int)(i1 - i0), tile_block(), lds, stream>>>(                            \
+#define CM2_PTR(POL, HALF)                                                                     \
+    k_Pt_tiles<POL, HALF><<<(int)(i1 - i0), tile_block(), lds, stream>>>(                      \
         t->tp, t->npix, t->d_item_tile + i0, t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl,    \
-        t->d_cos, t->d_sin, d_tod_tb, d_out)
-    if (t->pol == 1) CM2_PTR(1); else if (t->pol == 2) CM2_PTR(2); else CM2_PTR(3);
+        HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
+    if (t->pol == 1) CM2_PTR(1, false);
+    else if (t->pol == 2) { if (t->half) CM2_PTR(2, true); else CM2_PTR(2, false); }
+    else { if (t->half) CM2_PTR(3, true); else CM2_PTR(3, false); }
 #undef CM2_PTR
     CM2_LAUNCH_OK();
     return 0;

@@ -184,9 +184,10 @@ class _TileHandle(object):
 
     def __init__(self, handle):
         self.h = handle
-        info = (ctypes.c_int64 * 5)()
+        info = (ctypes.c_int64 * 6)()
         _hip.call("cm2_tiles_info", handle, info)
-        self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info]
+        self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info[:5]]
+        self.half_angle = bool(info[5])
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -90,7 +90,10 @@ int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
                      const double *d_sin, int64_t nt, int64_t npix, int pol, int tile_pixels,
                      int64_t slice_samples, void *stream);
 int cm2_tiles_destroy(cm2_tiles *t);
-/* h_info[0..4] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items */
+/* h_info[0..5] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
+ * 1 if the plan stores one half-angle value per sample instead of cos and sin (done when every
+ * (cos, sin) pair is on the unit circle to 1e-14; the kernels rebuild cos = +-(1-h^2)/(1+h^2),
+ * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample) */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* d_tod_tb[k] = (P x) for the k-th sample in TB order */
 int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);

@@ -100,19 +100,33 @@ def test_pointing_bitexact(cm, oracle, pol, nt, npix):
     assert info["nvalid"] == int((pairs >= 0).sum()) and info["nslices"] == (npix + 63) // 64
 
 
+@pytest.mark.parametrize("angles", ["half", "full"])
 @pytest.mark.parametrize("pol", [1, 2, 3])
 @pytest.mark.parametrize("nt,npix,tp", [(300000, 5000, 2048), (50000, 100, 64), (400000, 70000, 1024)])
-def test_tiled_pointing(cm, oracle, pol, nt, npix, tp):
-    """Tile-bucketed order: gather bit-exact, permutations exact, LDS-atomic scatter to
-    rounding, and the tiled P^T N P equal to the exact three stages to 1e-13."""
+def test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles):
+    """Tile-bucketed order: permutations exact, LDS-atomic scatter to rounding, the tiled
+    P^T N P equal to the exact three stages to 1e-13.  The gather is bit-exact when the tile
+    plan keeps cos and sin ("full"); in the default half-angle storage (one double per sample,
+    cos and sin rebuilt from tan of the half angle) it differs by an ulp or two of the map
+    values."""
     from types import SimpleNamespace
     from cosmomap2_amd import _hip, device as D
     from cosmomap2_amd.interfaces import linearoperators as L
+    monkeypatch.setenv("CM2_TILE_ANGLES", angles)
     d, pairs, phi, t, diag = make_problem(oracle, 300 + pol, nt, npix, 4, pol, flag_frac=0.1)
     c, s = np.cos(2 * phi), np.sin(2 * phi)
+    # angles where the half-angle form is most delicate: cos = +-1, 0 and sin = +-1, tiny sin
+    c[:8] = [1.0, -1.0, 0.0, 0.0, np.cos(1e-9), -np.cos(1e-9), np.cos(np.pi - 1e-7), 6.123233995736766e-17]
+    s[:8] = [0.0, 0.0, 1.0, -1.0, np.sin(1e-9), np.sin(1e-9), np.sin(np.pi - 1e-7), 1.0]
     P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
     T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
     assert T.nvalid == int((pairs >= 0).sum()) and T.ntiles == (npix + tp - 1) // tp
+    assert T.half_angle == (angles == "half" and pol > 1)
+    if pol > 1:
+        # weights that are not a (cos, sin) pair: the plan must keep both arrays
+        P2 = cm.I.SparseLO(npix, nt, pairs, pol=pol,
+                           angle_processed=SimpleNamespace(cos=0.5 * c, sin=s))
+        assert not L._sparse_tiles(P2, tile_pixels=tp, slice_samples=4096).half_angle
     rng = np.random.default_rng(9)
     x = rng.standard_normal(pol * npix)
     v = rng.standard_normal(nt)
@@ -121,7 +135,12 @@ def test_tiled_pointing(cm, oracle, pol, nt, npix, tp):
     d_tb, tod, out = D.empty(T.nvalid), D.empty(nt), D.empty(pol * npix)
     _hip.call("cm2_P_tiles_apply", T.h, D.ptr(xd), D.ptr(d_tb), st)
     _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
-    np.testing.assert_array_equal(tod.cpu().numpy(), oracle.sparse_mult(pol, pairs, c, s, x))
+    gather_ref = oracle.sparse_mult(pol, pairs, c, s, x)
+    if angles == "full" or pol == 1:
+        np.testing.assert_array_equal(tod.cpu().numpy(), gather_ref)
+    else:
+        np.testing.assert_allclose(tod.cpu().numpy(), gather_ref, rtol=0,
+                                   atol=1e-15 * np.abs(x).max())
     v_tb = D.empty(T.nvalid)
     _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(vd), D.ptr(v_tb), st)
     back = D.empty(nt)
