@@ -28,12 +28,13 @@ def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
     bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(here, tag + "_bench_c4.json"), "w"), indent=1)
-    ks = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
+    ks = newest(os.path.join(src, "kt", "**", "*_kernel_stats.csv"))
     shutil.copy(ks, os.path.join(here, tag + "_rocprofv3_kernel_stats_c4.csv"))
     rows = list(csv.DictReader(open(ks)))
 
     def counters(kind):
-        f = glob.glob(os.path.join(src, kind, "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = newest(os.path.join(src, kind, "**", "*_counter_collection.csv"))
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -65,9 +66,9 @@ def main(src, tag):
 
     md = ["# rocprofv3 summary %s -- `python3 bench.py` (%s)" % (tag, bench["config"]["workload"]), "",
           "Commands (MI355X box, after `cd /tmp && export TMPDIR=/tmp`):", "",
-          "    rocprofv3 --kernel-trace --stats -d out/kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-pcg",
-          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg",
-          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg",
+          "    rocprofv3 --kernel-trace --stats -d out/kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-pcg --no-filters --no-raster",
+          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg --no-filters --no-raster",
+          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg --no-filters --no-raster",
           "", "Full kernel table: `%s_rocprofv3_kernel_stats_c4.csv`; machine-readable: `%s_pmc_c4.json`." % (tag, tag),
           "", "| kernel | calls | avg ms (rocprofv3) | 2*FETCH_SIZE GB | WRITE_SIZE GB | HBM traffic GB | algorithmic GB | GB/s algorithmic |",
           "|---|---|---|---|---|---|---|---|"]
@@ -81,6 +82,10 @@ def main(src, tag):
            + "; ".join("%s %.3f ms" % (k, v["ms"]) for k, v in bench["stages"].items()) + ".",
            "Step: %.3f ms = %.3g samples/s = %.1f %% of the 8 TB/s HBM peak on 72 B/sample + 48 B/pixel."
            % (bench["ms_per_step"], bench["value"], 100 * bench["step_frac_of_hbm_peak"])]
+    md += ["", "Algorithmic bytes are SURVEY 8(d)'s (P and P^T: pixel 4 + cos 8 + sin 8 + TOD 8 = 28 B per "
+           "sample).  The tile plan stores a 2-byte pixel-in-tile index and, by default, one half-angle "
+           "value instead of cos and sin: P and P^T are designed to move 18 B per sample, which is why "
+           "their measured traffic is below the algorithmic figure."]
     open(os.path.join(here, tag + "_pmc_c4.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[10:]))
 
