@@ -209,6 +209,8 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
                 tile_pixels //= 2
         if slice_samples is None:
             slice_samples = max(4096, min(65536, P.nrows // 4096))
+            if os.environ.get("CM2_TILE_SLICE"):
+                slice_samples = int(os.environ["CM2_TILE_SLICE"])
         h = ctypes.c_void_p()
         _hip.call("cm2_tiles_create", ctypes.byref(h), D.ptr(P._d_pix), D.ptr(P._d_cos),
                   D.ptr(P._d_sin), P.nrows, P.ncols, int(P.pol), int(tile_pixels),
