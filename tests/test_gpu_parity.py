@@ -1193,3 +1193,41 @@ def test_reference_api_surface(cm, oracle):
     x1, info1 = spla.cg(A, b, M=M, rtol=1e-8)
     x2, info2 = spla.cg(A, b, M=M2, rtol=1e-8)
     assert info1 == 0 and info2 == 0 and rel_l2(x2, x1) < 1e-6
+
+
+def test_throughput_path_equals_exact_path_end_to_end(cm):
+    """The whole solve on the throughput path (tile order, half-angle storage, LDS atomics,
+    register-resident FFT) against the exact path (time order, fixed-order P^T, direct band
+    sum = the oracle's arithmetic): same PCG iteration count, maps equal far below the
+    north_star's 1e-6."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    t = cm.torch
+    nside, nt, nb, pol, lam = 64, 4_000_000, 40, 3, 700
+    npix = 12 * nside * nside
+    g = t.Generator(device="cuda").manual_seed(3)
+    pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
+    pix[t.rand(nt, generator=g, device="cuda") < 0.02] = -1
+    phi = 0.9 + (2 * np.pi * 2.5 / 200.0) * t.arange(nt, device="cuda", dtype=t.float64)
+    d = t.rand(nt, generator=g, device="cuda", dtype=t.float64)
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.02 * b) * np.where(kk == 0, 1.0, 0.25 * np.exp(-kk / 200.0)) for b in range(nb)]
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol)
+    sols = {}
+    for mode, method in (("exact", 1), ("tiled", 3)):
+        L.set_pointing_mode(mode)
+        try:
+            N = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=method)
+            A = P.T * N * P
+            b = P.T * (N * d)
+            its = []
+            x, info = cm.cg(A, b, M=M, rtol=1e-9, maxiter=300, callback=lambda v: its.append(1))
+            assert info == 0
+            sols[mode] = (x, len(its))
+        finally:
+            L.set_pointing_mode("auto")
+    (xe, ie), (xt, it) = sols["exact"], sols["tiled"]
+    assert abs(ie - it) <= 1, (ie, it)
+    assert float((xt - xe).norm() / xe.norm()) < 1e-8
