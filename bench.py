@@ -326,7 +326,12 @@ def main():
             mean_ms, med_ms = ev_time(lambda: F * d, reps)
             filters["poly%d_ms" % order] = round(med_ms, 4)
             filters["poly%d_GBps" % order] = round(20.0 * nt / (med_ms * 1e-3) / 1e9, 1)
-            del F
+            # the production operator A = P^T F P (tile-order P / P^T around the filter)
+            P_f = SparseLO(npix_c, nt, pix_f, pol=pol, angle_processed=ces)
+            A_f = P_f.T * F * P_f
+            _, med_a = ev_time(lambda: A_f * x, reps)
+            filters["PtFP_poly%d_ms" % order] = round(med_a, 4)
+            del F, A_f, P_f
         az = ((torch.arange(nt, device=dev, dtype=torch.int64) % (2 * (sub + gap))) - (sub + gap)
               ).abs().to(torch.int32)             # triangle-wave azimuth -> sub+gap+1 ground bins
         Fg = GroundFilterLO(az)

@@ -244,7 +244,8 @@ class _TiledNormalLO(_DeviceOp):
         if not D.is_dev(v):
             return None
         if self._fused_noise is None:
-            self._fused_noise = self.noise.noise_info()["method"] == 3
+            info = getattr(self.noise, "noise_info", None)
+            self._fused_noise = info is not None and info()["method"] == 3
         if not self._fused_noise:
             return None
         return self._mult(v, reducer=reducer, ngroups=int(ngroups))
@@ -264,7 +265,8 @@ class _TiledNormalLO(_DeviceOp):
         d_tb, v_tb = self._work
         _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)
         if self._fused_noise is None:
-            self._fused_noise = self.noise.noise_info()["method"] == 3
+            info = getattr(self.noise, "noise_info", None)
+            self._fused_noise = info is not None and info()["method"] == 3
         if self._fused_noise:
             # overlap-save kernel reads and writes the tile order directly
             _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
@@ -340,6 +342,15 @@ def _fuse_chain(chain):
                 continue
             if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], BlockLO) \
                     and chain[i + 1].isoffdiag and _use_tiles(P):
+                out.append(_TiledNormalLO(P, chain[i + 1]))
+                i += 3
+                changed = True
+                continue
+            if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], (FilterLO, GroundFilterLO)) \
+                    and _use_tiles(P):
+                # A = P^T F P, the production operator: tile-order P / P^T around the
+                # time-order filter (two streaming permutations instead of the exact-order
+                # gather and fixed-order scatter)
                 out.append(_TiledNormalLO(P, chain[i + 1]))
                 i += 3
                 changed = True
@@ -932,6 +943,10 @@ class FilterLO(_DeviceOp):
         """Offset removal per chunk (:129-168), whatever ``poly_order`` is."""
         return self._apply(0, d)
 
+    def _apply_all(self, d):
+        """The operator's own matvec on a device vector (used by the tile-order chain)."""
+        return self._apply(self.poly_order, d)
+
     def polyfilter(self, d):
         """Legendre filtering up to ``poly_order`` (:170-204)."""
         if self.poly_order == 0:
@@ -977,6 +992,8 @@ class GroundFilterLO(_DeviceOp):
         _hip.call("cm2_ground_subtract", self.n, D.ptr(self._G._d_pix), D.ptr(binned), D.ptr(x),
                   D.ptr(out), D.stream())
         return D.like_input(out, v)
+
+    _apply_all = mult
 
     def __init__(self, ground):
         g = ground.detach().cpu().numpy() if D.is_tensor(ground) else np.asarray(ground)

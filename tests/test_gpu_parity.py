@@ -1231,3 +1231,40 @@ def test_throughput_path_equals_exact_path_end_to_end(cm):
     (xe, ie), (xt, it) = sols["exact"], sols["tiled"]
     assert abs(ie - it) <= 1, (ie, it)
     assert float((xt - xe).norm() / xe.norm()) < 1e-8
+
+
+def test_filter_chain_on_tile_order(cm):
+    """A = P^T F P (and the ground filter likewise) above 2^20 samples runs on the tile order
+    around the time-order filter; it must equal the exact-order chain to rounding."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    t = cm.torch
+    nside, ns, nb, pol = 32, 150000, 10, 3
+    nt = ns * nb
+    npix = 12 * nside * nside
+    g = t.Generator(device="cuda").manual_seed(5)
+    pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
+    pix[t.rand(nt, generator=g, device="cuda") < 0.04] = -1
+    phi = 0.2 + (2 * np.pi * 2.5 / 200.0) * t.arange(nt, device="cuda", dtype=t.float64)
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    starts = np.arange(0, ns - 1500 + 1, 1540)
+    sizes = np.full(starts.size, 1500)
+    x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
+    az = ((t.arange(nt, device="cuda") % 3080) - 1540).abs().to(t.int32)
+    ops = [cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=0),
+           cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=2),
+           cm.I.GroundFilterLO(az)]
+    for F in ops:
+        res = {}
+        for mode in ("exact", "tiled"):
+            L.set_pointing_mode(mode)
+            try:
+                A = P.T * F * P
+                res[mode] = A * x
+                plan = A._compiled()
+                assert (len(plan) == 1 and isinstance(plan[0], L._TiledNormalLO)) == (mode == "tiled")
+            finally:
+                L.set_pointing_mode("auto")
+        err = float((res["tiled"] - res["exact"]).norm() / res["exact"].norm())
+        assert err < 1e-12, (type(F).__name__, err)
