@@ -74,6 +74,7 @@ PROTOTYPES = {
     "cm2_filter_destroy": [_vp],
     "cm2_filter_info": [_vp, _vp],
     "cm2_filter_apply": [_vp, _vp, _vp, _vp],
+    "cm2_filter_apply_tiles": [_vp, _vp, _vp, _vp, _vp, _vp],
     "cm2_cutsky_to_fullsky": [_int, _i64, _vp, _vp, _i64, _vp, _vp],
     "cm2_fullsky_to_cutsky": [_int, _i64, _vp, _vp, _i64, _vp, _vp],
     "cm2_ground_bin_sums": [_i64, _int, _vp, _vp, _vp, _vp],

@@ -8,6 +8,8 @@
 // per sample.  The Legendre tables are shared by all chunks of one length and stay in L2.
 #include "cm2_common.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <vector>
 
 namespace cm2 {
@@ -328,6 +330,124 @@ __global__ __launch_bounds__(256) void k_filter_poly(int64_t nseg, const int64_t
     }
 }
 
+// ---- the same filters on the tile-bucketed TOD order of cm2_tiles.hip ------------------
+// A window is a stretch of <= 8192 consecutive time samples holding whole chunks.  One
+// workgroup gathers its window through an address-sorted list (k = position in the tile
+// order, q = offset in the window; the window's samples of one pixel tile are one contiguous
+// run), filters the chunks in LDS -- one wavefront per chunk, same arithmetic as above -- and
+// scatters the window back through the list entries it kept in registers: 6 (list) + 8 + 8
+// bytes per sample.  Flagged samples have no slot in the tile order: they are simply absent.
+constexpr int kWinLen = 8192, kWinT = 256, kWinPer = kWinLen / kWinT;
+
+struct FilterWin {
+    int64_t t0;            // time of window offset 0
+    int32_t span, s0, s1;  // samples in the window, chunks [s0, s1)
+    int32_t pad;
+};
+
+template <bool MEAN>
+struct LdsChunk {
+    const double *d;
+    const uint8_t *ok;
+    int64_t a, n;
+    int lane;
+    template <class F>
+    __device__ __forceinline__ void each(F f) const
+    {
+        for (int64_t j = lane; j < n; j += kWave) f(j, d[a + j], ok[a + j] != 0);
+    }
+};
+
+template <int K>          // K = 0: mean removal, K >= 2: Legendre order K - 1
+__global__ __launch_bounds__(kWinT, 2) void k_filter_windows(
+    const FilterWin *__restrict__ wins, int nwin, const int64_t *__restrict__ start,
+    const int64_t *__restrict__ len, const uint8_t *__restrict__ kind,
+    const int64_t *__restrict__ toff, const double *__restrict__ table, const void *__restrict__ coef_,
+    const uint32_t *__restrict__ lst_k, const uint16_t *__restrict__ lst_q,
+    const double *__restrict__ in, double *__restrict__ out)
+{
+    extern __shared__ double win_lds[];
+    double *data = win_lds;
+    uint8_t *ok = reinterpret_cast<uint8_t *>(win_lds + kWinLen);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per_xcd = (nwin + 7) / 8;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= nwin) return;
+    const FilterWin w = wins[wid];
+    for (int i = t; i < kWinLen / 8; i += kWinT) reinterpret_cast<uint64_t *>(ok)[i] = 0;
+    uint32_t kk[kWinPer];
+    uint16_t qq[kWinPer];
+    const int64_t base = (int64_t)wid * kWinLen;
+#pragma unroll
+    for (int u = 0; u < kWinPer; ++u) {
+        kk[u] = lst_k[base + t + u * kWinT];
+        qq[u] = lst_q[base + t + u * kWinT];
+    }
+    double vv[kWinPer];
+#pragma unroll
+    for (int u = 0; u < kWinPer; ++u) vv[u] = (kk[u] != kInvalidSample) ? in[kk[u]] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kWinPer; ++u)
+        if (kk[u] != kInvalidSample) {
+            data[qq[u]] = vv[u];
+            ok[qq[u]] = 1;
+        }
+    __syncthreads();
+    for (int s = w.s0 + wave; s < w.s1; s += kWinT / 64) {
+        const int64_t a = start[s] - w.t0, n = len[s];
+        const int64_t prev = (s == w.s0) ? 0 : start[s - 1] + len[s - 1] - w.t0;
+        zero_range(data, prev, a, lane);                       // gap in front of the chunk
+        if (s == w.s1 - 1) zero_range(data, a + n, w.span, lane);
+        if constexpr (K == 0) {
+            LdsChunk<true> ch{data, ok, a, n, lane};
+            mean_body(ch, a, a + n, lane, data);
+        } else {
+            const int kd = kind[s];
+            if (kd == 0) {
+                zero_range(data, a, a + n, lane);
+            } else {
+                const OrthoCoef<K> *coef = static_cast<const OrthoCoef<K> *>(coef_);
+                OrthoCoef<K> cf;
+                if (kd == 2) cf = coef[s];
+                LdsChunk<false> ch{data, ok, a, n, lane};
+                poly_body<K>(ch, kd, a, table + toff[s], cf, data);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kWinPer; ++u)
+        if (kk[u] != kInvalidSample) out[kk[u]] = data[qq[u]];
+}
+
+// keys of the window lists: (window << 32) | position in the tile order, value = offset in the
+// window; slots past the window's span and flagged samples get an invalid address
+__global__ __launch_bounds__(256) void k_win_keys(const FilterWin *__restrict__ wins, int64_t nwin,
+                                                   const uint32_t *__restrict__ idx,
+                                                   uint64_t *__restrict__ keys,
+                                                   uint16_t *__restrict__ vals)
+{
+    const int64_t total = nwin * kWinLen;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const int64_t wi = g / kWinLen;
+        const int q = (int)(g - wi * kWinLen);
+        const FilterWin w = wins[wi];
+        const uint32_t k = q < w.span ? idx[w.t0 + q] : kInvalidSample;
+        keys[g] = ((uint64_t)wi << 32) | (uint64_t)k;
+        vals[g] = (uint16_t)q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_win_unpack(int64_t total, const uint64_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ lst_k)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
+        lst_k[g] = (uint32_t)(keys[g] & 0xFFFFFFFFull);
+}
+
 __global__ __launch_bounds__(256) void k_ground_subtract(int64_t nt, const int32_t *__restrict__ bin,
                                                           const double *__restrict__ binned,
                                                           const double *__restrict__ v,
@@ -380,12 +500,21 @@ struct cm2_filter {
     double *d_table = nullptr;
     void *d_coef = nullptr;              // OrthoCoef<order+1>[nseg]
     int64_t nkind[3] = {0, 0, 0};
+    std::vector<int64_t> h_start, h_len; // host copies of the chunk table (window planning)
+    // tile-order plan, built for one tile index at a time
+    const void *win_key = nullptr;
+    bool win_ok = false, win_memset = false;
+    int64_t nwin = 0;
+    FilterWin *d_wins = nullptr;
+    uint32_t *d_win_k = nullptr;
+    uint16_t *d_win_q = nullptr;
 };
 
 extern "C" void cm2_filter_destroy(cm2_filter *f)
 {
     if (!f) return;
-    void *bufs[] = {f->d_start, f->d_len, f->d_prev_end, f->d_toff, f->d_kind, f->d_table, f->d_coef};
+    void *bufs[] = {f->d_start, f->d_len, f->d_prev_end, f->d_toff, f->d_kind, f->d_table, f->d_coef,
+                    f->d_wins, f->d_win_k, f->d_win_q};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete f;
@@ -459,6 +588,8 @@ int filter_fill(cm2_filter *f, int64_t nt, int64_t nseg, const int64_t *h_start,
     f->order = order;
     f->covered = covered;
     f->d_pix = d_pix;
+    f->h_start.assign(h_start, h_start + nseg);
+    f->h_len.assign(h_len, h_len + nseg);
     if (upload(&f->d_start, h_start, (size_t)nseg, st)) return 1;
     if (upload(&f->d_len, h_len, (size_t)nseg, st)) return 1;
     if (upload(&f->d_prev_end, prev_end.data(), (size_t)nseg, st)) return 1;
@@ -548,6 +679,129 @@ extern "C" int cm2_filter_apply(const cm2_filter *f, const double *d_in, double 
     }
     CM2_LAUNCH_OK();
     return 0;
+}
+
+extern "C" const uint32_t *cm2_tiles_index(const cm2_tiles *t);     // cm2_tiles.hip
+extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t);
+
+namespace {
+
+int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, hipStream_t st)
+{
+    void **old[] = {(void **)&f->d_wins, (void **)&f->d_win_k, (void **)&f->d_win_q};
+    for (void **q : old) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    f->win_key = (const void *)d_idx;
+    f->win_ok = false;
+    f->win_memset = false;
+    f->nwin = 0;
+    std::vector<FilterWin> wins;
+    const int64_t nseg = f->nseg;
+    const auto &S = f->h_start;
+    const auto &L = f->h_len;
+    if (nseg == 0 || S[0] > 0) f->win_memset = true;
+    for (int64_t s0 = 0; s0 < nseg;) {
+        const int64_t t0 = S[(size_t)s0];
+        int64_t s1 = s0;
+        while (s1 < nseg && S[(size_t)s1] + L[(size_t)s1] - t0 <= kWinLen && s1 - s0 < (1 << 20)) ++s1;
+        if (s1 == s0) return 0;                       // a chunk longer than a window: not tileable
+        int64_t t1 = S[(size_t)s1 - 1] + L[(size_t)s1 - 1];
+        const int64_t next = s1 < nseg ? S[(size_t)s1] : f->nt;
+        if (next - t0 <= kWinLen) t1 = next;          // the trailing gap rides along (zeroed in LDS)
+        else f->win_memset = true;                    // samples between windows: zeroed by a memset
+        FilterWin w;
+        w.t0 = t0;
+        w.span = (int32_t)(t1 - t0);
+        w.s0 = (int32_t)s0;
+        w.s1 = (int32_t)s1;
+        w.pad = 0;
+        wins.push_back(w);
+        s0 = s1;
+    }
+    f->nwin = (int64_t)wins.size();
+    f->win_ok = true;
+    if (f->nwin == 0) return 0;
+    CM2_CHECK(f->nseg < ((int64_t)1 << 31) && f->nwin < ((int64_t)1 << 31), "too many chunks");
+    CM2_HIP(hipMalloc(&f->d_wins, sizeof(FilterWin) * wins.size()));
+    CM2_HIP(hipMemcpyAsync(f->d_wins, wins.data(), sizeof(FilterWin) * wins.size(),
+                           hipMemcpyHostToDevice, st));
+    const int64_t total = f->nwin * kWinLen;
+    DevTemp<uint64_t> keys_in, keys_out;
+    DevTemp<uint16_t> vals_in;
+    DevTemp<char> d_temp;
+    CM2_HIP(keys_in.alloc(total));
+    CM2_HIP(keys_out.alloc(total));
+    CM2_HIP(vals_in.alloc(total));
+    CM2_HIP(hipMalloc(&f->d_win_k, sizeof(uint32_t) * total));
+    CM2_HIP(hipMalloc(&f->d_win_q, sizeof(uint16_t) * total));
+    k_win_keys<<<grid_for(total), kBlock, 0, st>>>(f->d_wins, f->nwin, d_idx, keys_in, vals_in);
+    CM2_LAUNCH_OK();
+    int end_bit = 33;
+    while (((int64_t)1 << (end_bit - 32)) <= f->nwin && end_bit < 64) ++end_bit;
+    size_t tb = 0;
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               f->d_win_q, total, 0, end_bit, st));
+    CM2_HIP(d_temp.alloc(tb + 16));
+    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                               f->d_win_q, total, 0, end_bit, st));
+    k_win_unpack<<<grid_for(total), kBlock, 0, st>>>(total, keys_out, f->d_win_k);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <int K>
+int launch_windows(const cm2_filter *f, const double *d_in, double *d_out, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(double) * kWinLen + kWinLen;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM2_HIP(hipFuncSetAttribute((const void *)k_filter_windows<K>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (int)(((f->nwin + 7) / 8) * 8);
+    k_filter_windows<K><<<grid, kWinT, lds, st>>>(f->d_wins, (int)f->nwin, f->d_start, f->d_len,
+                                                  f->d_kind, f->d_toff, f->d_table, f->d_coef,
+                                                  f->d_win_k, f->d_win_q, d_in, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cm2_filter_apply_tiles(cm2_filter *f, const cm2_tiles *tiles, const double *d_in_tb,
+                                      double *d_out_tb, int *h_done, void *stream)
+{
+    CM2_CHECK(f && tiles && h_done, "cm2_filter_apply_tiles: null argument");
+    *h_done = 0;
+    CM2_CHECK(cm2_tiles_nt(tiles) == f->nt, "filter has %lld samples, tile plan %lld",
+              (long long)f->nt, (long long)cm2_tiles_nt(tiles));
+    hipStream_t st = as_stream(stream);
+    const uint32_t *d_idx = cm2_tiles_index(tiles);
+    if (f->win_key != (const void *)d_idx)
+        if (int rc = filter_windows_build(f, d_idx, st)) return rc;
+    if (!f->win_ok) return 0;                         // caller falls back to the time order
+    int64_t tinfo[6];
+    if (int rc = cm2_tiles_info(tiles, tinfo)) return rc;
+    const int64_t nvalid = tinfo[1];
+    CM2_CHECK(nvalid == 0 || (d_in_tb && d_out_tb && d_in_tb != d_out_tb),
+              "cm2_filter_apply_tiles: null or aliased vectors");
+    if (f->win_memset && nvalid) CM2_HIP(hipMemsetAsync(d_out_tb, 0, sizeof(double) * nvalid, st));
+    *h_done = 1;
+    if (f->nwin == 0) return 0;
+    switch (f->order == 0 ? 0 : f->order + 1) {
+        case 0: return launch_windows<0>(f, d_in_tb, d_out_tb, st);
+        case 2: return launch_windows<2>(f, d_in_tb, d_out_tb, st);
+        case 3: return launch_windows<3>(f, d_in_tb, d_out_tb, st);
+        case 4: return launch_windows<4>(f, d_in_tb, d_out_tb, st);
+        case 5: return launch_windows<5>(f, d_in_tb, d_out_tb, st);
+        case 6: return launch_windows<6>(f, d_in_tb, d_out_tb, st);
+        case 7: return launch_windows<7>(f, d_in_tb, d_out_tb, st);
+        default: return launch_windows<8>(f, d_in_tb, d_out_tb, st);
+    }
 }
 
 extern "C" int cm2_ground_subtract(int64_t nt, const int32_t *d_bin, const double *d_binned,

@@ -287,6 +287,12 @@ class _TiledNormalLO(_DeviceOp):
                 if w is not None:
                     w.wait()
             return out
+        tiled_apply = getattr(self.noise, "_apply_tiles", None)
+        if tiled_apply is not None and tiled_apply(T, d_tb, v_tb):
+            # the time-domain operator ran on the tile order itself (sub-scan filters)
+            out = D.empty(P.pol * P.ncols)
+            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+            return D.like_input(out, v)
         tod = D.empty(P.nrows)
         _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
         tod2 = self.noise._apply_all(tod)
@@ -946,6 +952,14 @@ class FilterLO(_DeviceOp):
     def _apply_all(self, d):
         """The operator's own matvec on a device vector (used by the tile-order chain)."""
         return self._apply(self.poly_order, d)
+
+    def _apply_tiles(self, T, d_in_tb, d_out_tb):
+        """Filter a TOD held in the tile-bucketed order ``T``; False if the chunks do not fit
+        the windowed kernel (the caller then goes through the time order)."""
+        done = ctypes.c_int(0)
+        _hip.call("cm2_filter_apply_tiles", self._plan_for(self.poly_order).h, T.h, D.ptr(d_in_tb),
+                  D.ptr(d_out_tb), ctypes.byref(done), D.stream())
+        return bool(done.value)
 
     def polyfilter(self, d):
         """Legendre filtering up to ``poly_order`` (:170-204)."""

@@ -286,6 +286,14 @@ int cm2_filter_info(const cm2_filter *f, int64_t *info);
 /* d_out = F d_in (nt doubles each; d_out must not alias d_in) */
 int cm2_filter_apply(const cm2_filter *f, const double *d_in, double *d_out, void *stream);
 
+/* The same filter with input and output in the tile-bucketed order of `tiles` (flagged samples
+ * have no slot there).  The time stream is cut into windows of <= 8192 samples holding whole
+ * chunks; each window is gathered through an address-sorted list, filtered in LDS and
+ * scattered back.  *h_done = 0 (and nothing is written) when a chunk is longer than a window:
+ * the caller then applies cm2_filter_apply on the time order.  d_out_tb != d_in_tb. */
+int cm2_filter_apply_tiles(cm2_filter *f, const cm2_tiles *tiles, const double *d_in_tb,
+                           double *d_out_tb, int *h_done, void *stream);
+
 /* ---- f2: ground-template filter  (GroundFilterLO, :24-61) --------------------
  * d_out[t] = d_v[t] - binned[d_bin[t]]   (d_out[t] = d_v[t] where d_bin[t] < 0),
  * the last step of v - G (G^T G)^-1 G^T v once binned = (G^T G)^-1 G^T v has

@@ -1252,8 +1252,15 @@ def test_filter_chain_on_tile_order(cm):
     sizes = np.full(starts.size, 1500)
     x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
     az = ((t.arange(nt, device="cuda") % 3080) - 1540).abs().to(t.int32)
+    tiny_starts = np.arange(0, ns - 100, 100)
     ops = [cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=0),
            cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix, poly_order=2),
+           # chunks longer than the 8192-sample window: the chain goes through the time order
+           cm.I.FilterLO(nt, [np.array([9000, 20000]), np.array([100, 30000])], ns, nb, pix, poly_order=1),
+           # two short chunks per detector pair, long stretches outside any chunk (-> 0)
+           cm.I.FilterLO(nt, [np.array([700, 900]), np.array([5000, 120000])], ns, nb, pix, poly_order=3),
+           # 1500 chunks of 90 samples per pair
+           cm.I.FilterLO(nt, [np.full(tiny_starts.size, 90), tiny_starts], ns, nb, pix, poly_order=1),
            cm.I.GroundFilterLO(az)]
     for F in ops:
         res = {}
