@@ -338,6 +338,10 @@ def main():
         mean_ms, med_ms = ev_time(lambda: Fg * d, reps)
         filters["ground_bins"] = Fg.nbins
         filters["ground_ms"] = round(med_ms, 4)
+        A_g = P.T * Fg * P
+        _, med_g = ev_time(lambda: A_g * x, reps)
+        filters["PtGP_ms"] = round(med_g, 4)
+        del A_g
         del Fg, az, pix_f
 
     # ---- secondary pointing model: coherent raster scan -------------------------

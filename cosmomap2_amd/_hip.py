@@ -33,6 +33,7 @@ PROTOTYPES = {
     "cm2_tiles_info": [_vp, ctypes.POINTER(_i64)],
     "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],
+    "cm2_i32_time_to_tiles": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply_range": [_vp, _vp, _vp, _i64, _i64, _vp],
     "cm2_tod_time_to_tiles": [_vp, _vp, _vp, _vp],
     "cm2_tod_tiles_to_time": [_vp, _vp, _vp, _vp],

@@ -498,6 +498,29 @@ extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_
     return 0;
 }
 
+__global__ __launch_bounds__(256) void k_i32_time_to_tiles(int64_t nt,
+                                                            const uint32_t *__restrict__ tb_dst,
+                                                            const int32_t *__restrict__ in,
+                                                            int32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride) {
+        const uint32_t k = tb_dst[t];
+        if (k != kInvalidSample) out[k] = in[t];
+    }
+}
+
+extern "C" int cm2_i32_time_to_tiles(const cm2_tiles *t, const int32_t *d_time, int32_t *d_tb,
+                                     void *stream_)
+{
+    CM2_CHECK(t && (t->nt == 0 || (d_time && d_tb)), "cm2_i32_time_to_tiles: NULL argument");
+    if (t->nt == 0) return 0;
+    k_i32_time_to_tiles<<<grid_for(t->nt), kBlock, 0, as_stream(stream_)>>>(t->nt, t->d_tb_dst, d_time,
+                                                                          d_tb);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
 static inline void perm_geometry(int64_t nt, int &blocks, int64_t &chunk)
 {
     // one 1024-thread workgroup per CU-slot, each with a contiguous time range

@@ -1009,6 +1009,28 @@ class GroundFilterLO(_DeviceOp):
 
     _apply_all = mult
 
+    def _apply_tiles(self, T, d_in_tb, d_out_tb):
+        """The same filter on a TOD held in the tile-bucketed order ``T``: binning and
+        subtraction do not care about the order of the samples, only the bin labels have to
+        be carried over once.  Flagged-pixel samples are absent there; they hold 0 in the
+        chain P^T (.) P, so the bin sums are the same."""
+        if self.nbins > self.LDS_BINS or T.nt != self.n:
+            return False
+        cache = getattr(self, "_bin_tb", None)
+        if cache is None or cache[0] is not T:
+            lab = D.empty(max(T.nvalid, 1), torch.int32)
+            _hip.call("cm2_i32_time_to_tiles", T.h, D.ptr(self._G._d_pix), D.ptr(lab), D.stream())
+            cache = self._bin_tb = (T, lab)
+        lab = cache[1]
+        st = D.stream()
+        sums = D.empty(self.nbins)
+        _hip.call("cm2_ground_bin_sums", T.nvalid, self.nbins, D.ptr(lab), D.ptr(d_in_tb),
+                  D.ptr(sums), st)
+        binned = self._invGtG.mult(sums)
+        _hip.call("cm2_ground_subtract", T.nvalid, D.ptr(lab), D.ptr(binned), D.ptr(d_in_tb),
+                  D.ptr(d_out_tb), st)
+        return True
+
     def __init__(self, ground):
         g = ground.detach().cpu().numpy() if D.is_tensor(ground) else np.asarray(ground)
         self.nbins = int(g.max()) + 1

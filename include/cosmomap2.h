@@ -99,6 +99,8 @@ int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
 /* d_out = P^T v for a TB-ordered v (d_out is overwritten) */
 int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, double *d_out, void *stream);
+/* integer per-sample labels (e.g. ground bins) from time order to TB order; set-up use */
+int cm2_i32_time_to_tiles(const cm2_tiles *t, const int32_t *d_time, int32_t *d_tb, void *stream);
 /* P^T restricted to the tiles [tile_lo, tile_hi): overwrites the entries of d_out that belong to
  * those tiles (pixels tile_lo*tile_pixels .. min(tile_hi*tile_pixels, npix)) and nothing else, so
  * that a finished part of the map can be reduced across GPUs while the next part is computed. */
