@@ -353,7 +353,7 @@ def _fuse_chain(chain):
                 changed = True
                 continue
             if i + 2 < n and chain[i + 2] is P and isinstance(chain[i + 1], (FilterLO, GroundFilterLO)) \
-                    and _use_tiles(P):
+                    and _use_tiles(P) and chain[i + 1]._tile_compatible(P):
                 # A = P^T F P, the production operator: tile-order P / P^T around the
                 # time-order filter (two streaming permutations instead of the exact-order
                 # gather and fixed-order scatter)
@@ -953,6 +953,16 @@ class FilterLO(_DeviceOp):
         """The operator's own matvec on a device vector (used by the tile-order chain)."""
         return self._apply(self.poly_order, d)
 
+    def _tile_compatible(self, P):
+        """The tile order has no slot for the samples ``P`` flags; the filter may run there only
+        if it flags exactly the same samples (the reference passes ``P.pairs``)."""
+        cache = self.__dict__.setdefault("_flag_match", {})
+        if id(P) not in cache:
+            a, b = self._d_pix, P._d_pix
+            cache[id(P)] = a.numel() == b.numel() and (
+                a.data_ptr() == b.data_ptr() or bool(torch.equal(a < 0, b < 0)))
+        return cache[id(P)]
+
     def _apply_tiles(self, T, d_in_tb, d_out_tb):
         """Filter a TOD held in the tile-bucketed order ``T``; False if the chunks do not fit
         the windowed kernel (the caller then goes through the time order)."""
@@ -1008,6 +1018,9 @@ class GroundFilterLO(_DeviceOp):
         return D.like_input(out, v)
 
     _apply_all = mult
+
+    def _tile_compatible(self, P):
+        return self.n == P.nrows
 
     def _apply_tiles(self, T, d_in_tb, d_out_tb):
         """The same filter on a TOD held in the tile-bucketed order ``T``: binning and

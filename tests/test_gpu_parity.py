@@ -1275,3 +1275,16 @@ def test_filter_chain_on_tile_order(cm):
                 L.set_pointing_mode("auto")
         err = float((res["tiled"] - res["exact"]).norm() / res["exact"].norm())
         assert err < 1e-12, (type(F).__name__, err)
+    # a filter whose flags differ from the pointing's stays on the time order (same numbers)
+    pix2 = pix.clone()
+    pix2[::1000] = -1
+    F2 = cm.I.FilterLO(nt, [sizes, starts], ns, nb, pix2, poly_order=1)
+    L.set_pointing_mode("tiled")
+    try:
+        A2 = P.T * F2 * P
+        y2 = A2 * x
+        assert not any(isinstance(op, L._TiledNormalLO) for op in A2._compiled())
+    finally:
+        L.set_pointing_mode("auto")
+    ref2 = P.T * (F2 * (P * x))
+    assert float((y2 - ref2).norm() / ref2.norm()) < 1e-13
