@@ -239,14 +239,9 @@ class _TiledNormalLO(_DeviceOp):
         part of the map overlapped with the back-projection of the next part: P^T runs tile
         group by tile group and ``reducer(view)`` (an asynchronous in-place sum, returning an
         object with ``wait()``) is started on each group's slice of the output as soon as its
-        kernel is queued.  Returns None when this operator cannot do it (noise operator not
-        on the fused tile path); the caller then reduces the whole vector itself."""
+        kernel is queued.  Returns None for a host vector (the caller then reduces the whole
+        result itself)."""
         if not D.is_dev(v):
-            return None
-        if self._fused_noise is None:
-            info = getattr(self.noise, "noise_info", None)
-            self._fused_noise = info is not None and info()["method"] == 3
-        if not self._fused_noise:
             return None
         return self._mult(v, reducer=reducer, ngroups=int(ngroups))
 
@@ -267,39 +262,36 @@ class _TiledNormalLO(_DeviceOp):
         if self._fused_noise is None:
             info = getattr(self.noise, "noise_info", None)
             self._fused_noise = info is not None and info()["method"] == 3
+        tiled_apply = getattr(self.noise, "_apply_tiles", None)
         if self._fused_noise:
             # overlap-save kernel reads and writes the tile order directly
             _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
                       D.ptr(v_tb), st)
-            out = D.empty(P.pol * P.ncols)
-            if reducer is None:
-                _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
-                return D.like_input(out, v)
-            ngroups = max(1, min(ngroups, T.ntiles))
-            works = []
-            for g in range(ngroups):
-                lo, hi = T.ntiles * g // ngroups, T.ntiles * (g + 1) // ngroups
-                _hip.call("cm2_Pt_tiles_apply_range", T.h, D.ptr(v_tb), D.ptr(out), lo, hi, st)
-                a = P.pol * lo * T.tile_pixels
-                b = min(P.pol * hi * T.tile_pixels, out.numel())
-                works.append(reducer(out[a:b]))
-            for w in works:
-                if w is not None:
-                    w.wait()
-            return out
-        tiled_apply = getattr(self.noise, "_apply_tiles", None)
-        if tiled_apply is not None and tiled_apply(T, d_tb, v_tb):
-            # the time-domain operator ran on the tile order itself (sub-scan filters)
-            out = D.empty(P.pol * P.ncols)
-            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
-            return D.like_input(out, v)
-        tod = D.empty(P.nrows)
-        _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
-        tod2 = self.noise._apply_all(tod)
-        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st)
+            src = v_tb
+        elif tiled_apply is not None and tiled_apply(T, d_tb, v_tb):
+            src = v_tb              # the time-domain operator ran on the tile order itself
+        else:
+            tod = D.empty(P.nrows)
+            _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st)
+            tod2 = self.noise._apply_all(tod)
+            _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st)
+            src = d_tb
         out = D.empty(P.pol * P.ncols)
-        _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st)
-        return D.like_input(out, v)
+        if reducer is None:
+            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(src), D.ptr(out), st)
+            return D.like_input(out, v)
+        ngroups = max(1, min(ngroups, T.ntiles))
+        works = []
+        for g in range(ngroups):
+            lo, hi = T.ntiles * g // ngroups, T.ntiles * (g + 1) // ngroups
+            _hip.call("cm2_Pt_tiles_apply_range", T.h, D.ptr(src), D.ptr(out), lo, hi, st)
+            a = P.pol * lo * T.tile_pixels
+            b = min(P.pol * hi * T.tile_pixels, out.numel())
+            works.append(reducer(out[a:b]))
+        for w in works:
+            if w is not None:
+                w.wait()
+        return out
 
 
 #: "exact": P^T is always the fixed-order pixel-major reduction (bit-reproducible, equal to
