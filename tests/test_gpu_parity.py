@@ -725,6 +725,10 @@ def test_two_level_preconditioner_invariants(cm, pol):
         Az[:, i] = A * Z[:, i]
     E = cm.I.CoarseLO(Z, Az, r)
     Zd = cm.I.DeflationLO(Z)
+    # tests/test_deflation_operator.py:33-53: independent columns, Zd and Zd.H against dense Z
+    assert np.linalg.matrix_rank(Z) == r and la.det(cm.U.dgemm(Z, Z.T)) != 0
+    assert np.allclose(Zd * np.ones(r), Z.dot(np.ones(r)))
+    assert np.allclose(Zd.H * x0, Z.T.dot(x0))
     I = cm.I.lp.IdentityOperator(pol * npix)
     R = I - A * Zd * E * Zd.T
     M2 = M * R + Zd * E * Zd.T
