@@ -51,6 +51,12 @@ struct cm2_tiles {
     int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
     int64_t *d_item_k1 = nullptr;
     std::vector<int64_t> tile_item0;   // [ntiles+1] first work item of every tile (host)
+    // address-sorted lists of the windowed permutations (built on first use): for every window
+    // of kPermWin consecutive time samples, its samples' TB positions in ascending order and
+    // their offsets in the window
+    uint32_t *d_perm_k = nullptr;
+    uint16_t *d_perm_q = nullptr;
+    int64_t nperm_win = 0;
 };
 
 // ------------------------------------------------------------------ build -------
@@ -282,6 +288,77 @@ __global__ __launch_bounds__(1024) void k_tiles_to_time(int64_t nt, int64_t chun
     }
 }
 
+// Windowed forms of the two permutations.  A per-sample scatter / gather between the orders
+// moves 8-byte fragments (a window's samples of one tile are ~20 contiguous entries) and the
+// caches write lines back before they are complete: 3.2 GB of HBM writes for 0.8 GB of
+// payload.  Here a workgroup owns kPermWin consecutive time samples, reaches their TB
+// positions through a list sorted by address (one contiguous run per tile) and stages the
+// window in LDS, so that both sides of the copy are streams: 6 + 8 + 8 bytes per sample.
+constexpr int kPermWin = 8192, kPermT = 256, kPermPer = kPermWin / kPermT;
+
+template <bool TO_TIME>
+__global__ __launch_bounds__(kPermT) void k_perm_windows(int64_t nt, int64_t nwin,
+                                                          const uint32_t *__restrict__ lst_k,
+                                                          const uint16_t *__restrict__ lst_q,
+                                                          const double *__restrict__ in,
+                                                          double *__restrict__ out)
+{
+    __shared__ double win[kPermWin];
+    const int per_xcd = (int)((nwin + 7) / 8);
+    const int64_t w = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (w >= nwin) return;
+    const int64_t t0 = w * kPermWin, base = w * kPermWin;
+    const int span = (int)((nt - t0 < kPermWin) ? nt - t0 : kPermWin);
+    const int t = threadIdx.x;
+    uint32_t kk[kPermPer];
+    uint16_t qq[kPermPer];
+#pragma unroll
+    for (int u = 0; u < kPermPer; ++u) {
+        kk[u] = lst_k[base + t + u * kPermT];
+        qq[u] = lst_q[base + t + u * kPermT];
+    }
+    if (TO_TIME) {
+        double vv[kPermPer];
+#pragma unroll
+        for (int u = 0; u < kPermPer; ++u) vv[u] = (kk[u] != kInvalidSample) ? in[kk[u]] : 0.0;
+        for (int j = t; j < span; j += kPermT) win[j] = 0.0;      // flagged samples read as 0
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kPermPer; ++u)
+            if (kk[u] != kInvalidSample) win[qq[u]] = vv[u];
+        __syncthreads();
+        for (int j = t; j < span; j += kPermT) out[t0 + j] = win[j];
+    } else {
+        for (int j = t; j < span; j += kPermT) win[j] = in[t0 + j];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kPermPer; ++u)
+            if (kk[u] != kInvalidSample) out[kk[u]] = win[qq[u]];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_perm_keys(int64_t nt, int64_t nwin,
+                                                    const uint32_t *__restrict__ tb_dst,
+                                                    uint64_t *__restrict__ keys,
+                                                    uint16_t *__restrict__ vals)
+{
+    const int64_t total = nwin * kPermWin;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t k = g < nt ? tb_dst[g] : kInvalidSample;
+        keys[g] = ((uint64_t)(g / kPermWin) << 32) | (uint64_t)k;
+        vals[g] = (uint16_t)(g % kPermWin);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_perm_unpack(int64_t total, const uint64_t *__restrict__ keys,
+                                                      uint32_t *__restrict__ lst_k)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
+        lst_k[g] = (uint32_t)(keys[g] & 0xFFFFFFFFull);
+}
+
 // workgroup size of the two tile kernels (CM2_TILE_BLOCK = 256 / 512 / 1024 to experiment)
 static int tile_block()
 {
@@ -303,7 +380,7 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
     void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
-                    t->d_item_k0, t->d_item_k1};
+                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete t;
@@ -531,10 +608,67 @@ static inline void perm_geometry(int64_t nt, int &blocks, int64_t &chunk)
     if (blocks < 1) blocks = 1;
 }
 
+// lists of the windowed permutations (CM2_PERM_WINDOWS=0 keeps the per-sample kernels)
+static int perm_lists(const cm2_tiles *tc, hipStream_t st, bool *use)
+{
+    cm2_tiles *t = const_cast<cm2_tiles *>(tc);         // lazily built cache
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char *e = getenv("CM2_PERM_WINDOWS");
+        enabled = e ? atoi(e) : 1;
+    }
+    *use = false;
+    if (!enabled || t->nt < kPermWin) return 0;
+    if (!t->d_perm_k) {
+        const int64_t nwin = (t->nt + kPermWin - 1) / kPermWin, total = nwin * kPermWin;
+        DevTemp<uint64_t> keys_in, keys_out;
+        DevTemp<uint16_t> vals_in;
+        DevTemp<char> d_temp;
+        CM2_HIP(keys_in.alloc(total));
+        CM2_HIP(keys_out.alloc(total));
+        CM2_HIP(vals_in.alloc(total));
+        uint32_t *lk = nullptr;
+        uint16_t *lq = nullptr;
+        CM2_HIP(hipMalloc(&lk, sizeof(uint32_t) * total));
+        DevTemp<uint32_t> guard_k;
+        guard_k.p = lk;
+        CM2_HIP(hipMalloc(&lq, sizeof(uint16_t) * total));
+        DevTemp<uint16_t> guard_q;
+        guard_q.p = lq;
+        k_perm_keys<<<grid_for(total), kBlock, 0, st>>>(t->nt, nwin, t->d_tb_dst, keys_in, vals_in);
+        CM2_LAUNCH_OK();
+        int end_bit = 33;
+        while (((int64_t)1 << (end_bit - 32)) <= nwin && end_bit < 64) ++end_bit;
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p, lq,
+                                                   total, 0, end_bit, st));
+        CM2_HIP(d_temp.alloc(tb + 16));
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p, lq,
+                                                   total, 0, end_bit, st));
+        k_perm_unpack<<<grid_for(total), kBlock, 0, st>>>(total, keys_out, lk);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipStreamSynchronize(st));
+        t->d_perm_k = guard_k.keep();
+        t->d_perm_q = guard_q.keep();
+        t->nperm_win = nwin;
+    }
+    *use = true;
+    return 0;
+}
+
 extern "C" int cm2_tod_time_to_tiles(const cm2_tiles *t, const double *d_time, double *d_tb,
                                      void *stream_)
 {
     CM2_CHECK(t && d_time && d_tb, "cm2_tod_time_to_tiles: NULL argument");
+    bool windows = false;
+    if (int rc = perm_lists(t, as_stream(stream_), &windows)) return rc;
+    if (windows) {
+        const int grid = (int)(((t->nperm_win + 7) / 8) * 8);
+        k_perm_windows<false><<<grid, kPermT, 0, as_stream(stream_)>>>(t->nt, t->nperm_win, t->d_perm_k,
+                                                                      t->d_perm_q, d_time, d_tb);
+        CM2_LAUNCH_OK();
+        return 0;
+    }
     int blocks;
     int64_t chunk;
     perm_geometry(t->nt, blocks, chunk);
@@ -547,6 +681,15 @@ extern "C" int cm2_tod_tiles_to_time(const cm2_tiles *t, const double *d_tb, dou
                                      void *stream_)
 {
     CM2_CHECK(t && d_time && d_tb, "cm2_tod_tiles_to_time: NULL argument");
+    bool windows = false;
+    if (int rc = perm_lists(t, as_stream(stream_), &windows)) return rc;
+    if (windows) {
+        const int grid = (int)(((t->nperm_win + 7) / 8) * 8);
+        k_perm_windows<true><<<grid, kPermT, 0, as_stream(stream_)>>>(t->nt, t->nperm_win, t->d_perm_k,
+                                                                     t->d_perm_q, d_tb, d_time);
+        CM2_LAUNCH_OK();
+        return 0;
+    }
     int blocks;
     int64_t chunk;
     perm_geometry(t->nt, blocks, chunk);
