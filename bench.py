@@ -331,6 +331,19 @@ def main():
             A_f = P_f.T * F * P_f
             _, med_a = ev_time(lambda: A_f * x, reps)
             filters["PtFP_poly%d_ms" % order] = round(med_a, 4)
+            if order == 0 and not args.no_pcg:
+                # PCG on the production system P^T F P x = P^T F d with M_BD
+                b_f = P_f.T * (F * d)
+                cosmomap2_amd.cg(A_f, b_f, M=Mbd, rtol=1e-6, maxiter=1)
+                torch.cuda.synchronize()
+                its_f = []
+                t_f = time.perf_counter()
+                x_f, info_f = cosmomap2_amd.cg(A_f, b_f, M=Mbd, rtol=1e-6, maxiter=500,
+                                               callback=lambda xk: its_f.append(1))
+                torch.cuda.synchronize()
+                filters["PtFP_poly0_pcg"] = {"rtol": 1e-6, "iters": len(its_f), "info": int(info_f),
+                                             "seconds": round(time.perf_counter() - t_f, 4)}
+                del b_f, x_f
             del F, A_f, P_f
         az = ((torch.arange(nt, device=dev, dtype=torch.int64) % (2 * (sub + gap))) - (sub + gap)
               ).abs().to(torch.int32)             # triangle-wave azimuth -> sub+gap+1 ground bins
