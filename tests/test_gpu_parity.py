@@ -1292,3 +1292,34 @@ def test_filter_chain_on_tile_order(cm):
         L.set_pointing_mode("auto")
     ref2 = P.T * (F2 * (P * x))
     assert float((y2 - ref2).norm() / ref2.norm()) < 1e-13
+
+
+@pytest.mark.parametrize("nt,npix,pol", [(5000, 300, 3), (900, 40, 2), (8191, 100, 1), (8193, 100, 3)])
+def test_small_problems_forced_onto_the_tile_path(cm, nt, npix, pol):
+    """Sizes around and below one 8192-sample window, every kind of operator between P^T and
+    P (fused and direct Toeplitz, sub-scan filter, ground filter): tile path == exact path."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(nt)
+    pix = rng.integers(0, npix, nt).astype(np.int32)
+    pix[rng.random(nt) < 0.05] = -1
+    phi = rng.random(nt)
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    x = rng.standard_normal(pol * n)
+    lam = 30
+    bands = [np.where(np.arange(lam) == 0, 1.0, 0.1 * np.exp(-np.arange(lam) / 5.0))]
+    ops = [cm.I.BlockLO(nt, bands, offdiag=True, method=3),
+           cm.I.BlockLO(nt, bands, offdiag=True, method=1),
+           cm.I.FilterLO(nt, [np.array([nt // 3, nt // 3]), np.array([5, nt // 2])], nt, 1, pix,
+                         poly_order=1),
+           cm.I.GroundFilterLO(rng.integers(-1, 20, nt))]
+    for op in ops:
+        res = {}
+        for mode in ("exact", "tiled"):
+            L.set_pointing_mode(mode)
+            try:
+                res[mode] = (P.T * op * P) * x
+            finally:
+                L.set_pointing_mode("auto")
+        assert rel_l2(res["tiled"], res["exact"]) < 1e-13, type(op).__name__
