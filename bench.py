@@ -18,7 +18,6 @@ uniform-random pixel per sample, HWP angle ramp, d ~ U[0,1)):
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

@@ -8,8 +8,6 @@ runs on the GPU (cm2_cutsky_to_fullsky / cm2_fullsky_to_cutsky).
 healpy is not a dependency: ``nside2npix`` is ``12 * nside**2`` (HEALPix definition) and
 writing FITS files (the ``fname`` arguments, ``hp.write_map``) is not provided.
 """
-import numpy as np
-
 from .. import _hip
 from .. import device as D
 

@@ -19,7 +19,7 @@ def main():
     from cosmomap2_amd.interfaces import SparseLO, BlockLO, BlockDiagonalPreconditionerLO
     from cosmomap2_amd.interfaces import linearoperators as L
     from cosmomap2_amd.utilities import ProcessTimeSamples
-    from cosmomap2_amd.sharding import ShardedLO, make_sync, shard_blocks
+    from cosmomap2_amd.sharding import ShardedLO, make_sync
 
     pol, npix, nb, bs, lam = 3, 30000, 24, 100000, 600
     nt = nb * bs
