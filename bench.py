@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--config", default=os.environ.get("CM2_BENCH_CONFIG", "c4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--lam", type=int, default=0, help="override the Toeplitz band length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
     ap.add_argument("--no-raster", action="store_true",
@@ -119,6 +120,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.nt:
         cfg["nt"] = args.nt
+    if args.lam and cfg["lam"]:
+        cfg["lam"] = args.lam
+        cfg["label"] += " [lambda=%d]" % args.lam
     pol = 3
     npix = 12 * cfg["nside"] ** 2
     nb = cfg["nb"]

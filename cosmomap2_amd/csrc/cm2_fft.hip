@@ -970,10 +970,11 @@ struct FusedOS {
     size_t lds_bytes = 0;
     // register-resident pair kernel (N = 8192, two workgroups per CU): spectrum laid out for
     // the (32, 16, 16) factorisation
-    bool reg_variant = false;
+    bool reg_variant = false, reg_time_order = false;
     int64_t npairs_reg = 0;
     PairDesc *d_pairs_reg = nullptr;
     double *d_Hperm_reg = nullptr;
+    double2 *d_W_reg = nullptr;          // exp(-2 pi i t / 8192): f->d_W belongs to f->N
     uint32_t *d_l1_k = nullptr, *d_l2_k = nullptr, *d_ls_k = nullptr;
     uint16_t *d_l1_q = nullptr, *d_l2_q = nullptr, *d_ls_q = nullptr;
     // address-sorted gather lists of the tile-order path, built for one tile index at a time
@@ -992,7 +993,7 @@ void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
     void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm, f->d_segs, f->d_WM, f->d_WL, f->d_Hs,
-                    f->d_lst_k, f->d_lst_q, f->d_Hperm_reg, f->d_pairs_reg, f->d_l1_k, f->d_l2_k, f->d_ls_k,
+                    f->d_lst_k, f->d_lst_q, f->d_Hperm_reg, f->d_W_reg, f->d_pairs_reg, f->d_l1_k, f->d_l2_k, f->d_ls_k,
                     f->d_l1_q, f->d_l2_q, f->d_ls_q};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1035,7 +1036,7 @@ static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStr
     if (f->npairs_reg == 0) return 0;
     const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
     k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
-        f->d_pairs_reg, (int)f->npairs_reg, f->d_W, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
+        f->d_pairs_reg, (int)f->npairs_reg, f->d_W_reg, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
         f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
     CM2_LAUNCH_OK();
     return 0;
@@ -1067,7 +1068,7 @@ static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, 
     if (f->real_variant) return launch_real<INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->npairs == 0) return 0;
     if (INDIRECT && f->d_l1_k) return launch_reg<true>(f, d_v, d_out, stream);
-    if (!INDIRECT && f->reg_variant) return launch_reg<false>(f, d_v, d_out, stream);
+    if (!INDIRECT && f->reg_variant && f->reg_time_order) return launch_reg<false>(f, d_v, d_out, stream);
     if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
     return launch<16, 16, 2, INDIRECT>(f, d_idx, d_v, d_out, stream);
@@ -1231,7 +1232,12 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     f->hop = f->N - 2 * (int64_t)f->halo;
     // register-resident pair kernel for the tile-order path (fixed geometry: hop 4096, halo
     // 2048); CM2_FUSED_VARIANT=pair keeps the LDS-resident pair kernel everywhere
-    f->reg_variant = f->N == kRegN && !(variant && strcmp(variant, "pair") == 0);
+    // (it serves every band the fused path supports: on the tile order the short-FFT pair
+    // kernels gather windows of a few hundred samples, one or two per pixel tile, and take
+    // 1.3 - 3.2 ms at 1e8 samples where this kernel takes 0.9 ms whatever lambda is)
+    f->reg_variant = !(variant && strcmp(variant, "pair") == 0);
+    const char *reg_time = getenv("CM2_REG_TIME_ORDER");     // time order: long bands only,
+    f->reg_time_order = f->N == kRegN || (reg_time && atoi(reg_time) != 0);   // unless asked
     f->lds_bytes = sizeof(double) * 2 * (size_t)(f->N + f->N / 32);
     std::vector<PairDesc> pairs;
     for (int64_t b = 0; b < nb; ++b) {
@@ -1281,9 +1287,12 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
         if (!rp.empty())
             CM2_HIP(hipMemcpy(f->d_pairs_reg, rp.data(), sizeof(PairDesc) * rp.size(),
                               hipMemcpyHostToDevice));
-        CM2_HIP(hipMalloc(&f->d_Hperm_reg, sizeof(double) * nb * f->N));
-        k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, 32, 16, 16,
-                                                                   d_bands, f->d_Hperm_reg);
+        CM2_HIP(hipMalloc(&f->d_Hperm_reg, sizeof(double) * nb * kRegN));
+        k_spectrum_perm<<<grid_for(nb * kRegN), kBlock, 0, stream>>>((int)nb, lambda, kRegN, 32, 16, 16,
+                                                                    d_bands, f->d_Hperm_reg);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipMalloc(&f->d_W_reg, sizeof(double2) * kRegN));
+        k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W_reg);
         CM2_LAUNCH_OK();
     }
     CM2_HIP(hipStreamSynchronize(stream));

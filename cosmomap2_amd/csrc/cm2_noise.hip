@@ -28,6 +28,12 @@
 
 using namespace cm2;
 
+// one work item of the tiled direct Toeplitz kernel
+struct DirTile {
+    int64_t start;      // first output sample
+    int32_t len, blk;
+};
+
 struct cm2_noise {
     int64_t nt = 0, nb = 0, lambda = 0;
     int method = 0;
@@ -46,7 +52,12 @@ struct cm2_noise {
     rocfft_execution_info info = nullptr;
     void *d_fftwork = nullptr;
     size_t fftwork_bytes = 0;
-    cm2::FusedOS *fused = nullptr;   // method CM2_TOEPLITZ_FUSED
+    cm2::FusedOS *fused = nullptr;   // method CM2_TOEPLITZ_FUSED; for AUTO -> DIRECT / FFT operators
+                                     // built on first application on a tile order
+    DirTile *d_dirtiles = nullptr;   // work list of the tiled direct kernel
+    int64_t ndirtiles = 0;
+    bool auto_method = false;        // the caller left the choice to the library
+    std::vector<int64_t> h_off;      // block offsets (host)
 };
 
 #define CM2_FFT(call)                                                                  \
@@ -106,6 +117,50 @@ __global__ __launch_bounds__(256) void k_toeplitz_direct(int64_t nt, int nb, boo
             if (k - i >= lo) acc += a[i] * v[k - i];
         }
         out[k] = acc;
+    }
+}
+
+// LDS-tiled form of the same sum.  A workgroup owns kDirTile consecutive outputs of one block,
+// stages them with a halo of lambda-1 samples on both sides (zeros outside the block: adding
+// a_i * 0 leaves every partial sum unchanged, so the boundary tests of the loop above are not
+// needed) and each thread forms kDirPer outputs, 256 apart, with the reference's term order.
+// 2(lambda-1) LDS reads per output instead of as many cache accesses.
+constexpr int kDirTile = 2048, kDirT = 256, kDirPer = kDirTile / kDirT;
+
+__global__ __launch_bounds__(kDirT) void k_toeplitz_direct_tiled(const DirTile *__restrict__ tiles,
+                                                                  int64_t lambda,
+                                                                  const int64_t *__restrict__ off,
+                                                                  const double *__restrict__ bands,
+                                                                  const double *__restrict__ v,
+                                                                  double *__restrict__ out)
+{
+    extern __shared__ double dir_lds[];                 // kDirTile + 2 (lambda - 1) doubles
+    const DirTile tl = tiles[blockIdx.x];
+    const int64_t lo = off[tl.blk], hi = off[tl.blk + 1];
+    const int halo = (int)(lambda - 1), span = kDirTile + 2 * halo;
+    const int64_t w0 = tl.start - halo;
+    for (int j = threadIdx.x; j < span; j += kDirT) {
+        const int64_t ts = w0 + j;
+        dir_lds[j] = (ts >= lo && ts < hi && j < tl.len + 2 * halo) ? v[ts] : 0.0;
+    }
+    __syncthreads();
+    const double *a = bands + (int64_t)tl.blk * lambda;
+    const double *c = dir_lds + halo + threadIdx.x;     // c[256 u] = v at this thread's output u
+    double acc[kDirPer];
+#pragma unroll
+    for (int u = 0; u < kDirPer; ++u) acc[u] = a[0] * c[kDirT * u];
+    for (int i = 1; i < (int)lambda; ++i) {
+        const double ai = a[i];
+#pragma unroll
+        for (int u = 0; u < kDirPer; ++u) {
+            acc[u] += ai * c[kDirT * u + i];
+            acc[u] += ai * c[kDirT * u - i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kDirPer; ++u) {
+        const int j = threadIdx.x + kDirT * u;
+        if (j < tl.len) out[tl.start + j] = acc[u];
     }
 }
 
@@ -202,7 +257,8 @@ extern "C" int cm2_noise_destroy(cm2_noise *n)
     if (n->fwd) rocfft_plan_destroy(n->fwd);
     if (n->inv) rocfft_plan_destroy(n->inv);
     if (n->info) rocfft_execution_info_destroy(n->info);
-    void *ptrs[] = {n->d_off, n->d_t, n->d_seg, n->d_seg_blk, n->d_X, n->d_F, n->d_H, n->d_fftwork};
+    void *ptrs[] = {n->d_off, n->d_t, n->d_seg, n->d_seg_blk, n->d_X, n->d_F, n->d_H, n->d_fftwork,
+                    n->d_dirtiles};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete n;
@@ -253,6 +309,8 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
     std::vector<int64_t> off;
     if (int rc = noise_common(n, h_sizes, nblocks, off)) { cm2_noise_destroy(n); return rc; }
     n->lambda = lambda;
+    n->h_off = off;
+    n->auto_method = (method == CM2_TOEPLITZ_AUTO);
     if (method == CM2_TOEPLITZ_AUTO)
         method = (lambda <= 32) ? CM2_TOEPLITZ_DIRECT
                                 : (cm2::fused_os_supported(lambda) ? CM2_TOEPLITZ_FUSED
@@ -339,6 +397,8 @@ extern "C" int cm2_noise_info(const cm2_noise *n, int64_t *h_info)
     CM2_CHECK(n && h_info, "cm2_noise_info: NULL argument");
     h_info[0] = n->nt; h_info[1] = n->nb; h_info[2] = n->lambda;
     h_info[3] = n->method; h_info[4] = n->L;
+    h_info[5] = (n->lambda > 0 && (n->method == CM2_TOEPLITZ_FUSED ||
+                                    (n->auto_method && cm2::fused_os_supported(n->lambda)))) ? 1 : 0;
     return 0;
 }
 
@@ -364,8 +424,36 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
         return 0;
     }
     if (n->method == CM2_TOEPLITZ_DIRECT) {
-        k_toeplitz_direct<<<grid_for(n->nt), kBlock, 0, stream>>>(
-            n->nt, (int)n->nb, n->equal_sizes, n->bsize, n->lambda, n->d_off, n->d_t, d_v, d_out);
+        const size_t lds = sizeof(double) * (size_t)(kDirTile + 2 * (n->lambda - 1));
+        if (lds > 150 * 1024 || n->nt == 0) {           // very long bands: the plain loop
+            k_toeplitz_direct<<<grid_for(n->nt), kBlock, 0, stream>>>(
+                n->nt, (int)n->nb, n->equal_sizes, n->bsize, n->lambda, n->d_off, n->d_t, d_v, d_out);
+            CM2_LAUNCH_OK();
+            return 0;
+        }
+        if (!n->d_dirtiles) {
+            std::vector<DirTile> tl;
+            for (int64_t b = 0; b < n->nb; ++b)
+                for (int64_t s0 = n->h_off[(size_t)b]; s0 < n->h_off[(size_t)b + 1]; s0 += kDirTile) {
+                    DirTile d;
+                    d.start = s0;
+                    d.len = (int32_t)(n->h_off[(size_t)b + 1] - s0 < kDirTile ? n->h_off[(size_t)b + 1] - s0
+                                                                              : kDirTile);
+                    d.blk = (int32_t)b;
+                    tl.push_back(d);
+                }
+            n->ndirtiles = (int64_t)tl.size();
+            CM2_HIP(hipMalloc(&n->d_dirtiles, sizeof(DirTile) * (tl.size() ? tl.size() : 1)));
+            if (!tl.empty())
+                CM2_HIP(hipMemcpy(n->d_dirtiles, tl.data(), sizeof(DirTile) * tl.size(),
+                                  hipMemcpyHostToDevice));
+            if (lds > 64 * 1024)
+                CM2_HIP(hipFuncSetAttribute((const void *)k_toeplitz_direct_tiled,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (n->ndirtiles)
+            k_toeplitz_direct_tiled<<<(unsigned)n->ndirtiles, kDirT, lds, stream>>>(
+                n->d_dirtiles, n->lambda, n->d_off, n->d_t, d_v, d_out);
         CM2_LAUNCH_OK();
         return 0;
     }
@@ -413,8 +501,15 @@ extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const
 {
     CM2_CHECK(n && tiles && d_in_tb && d_out_tb, "cm2_noise_apply_tiles: NULL argument");
     CM2_CHECK(d_in_tb != d_out_tb, "cm2_noise_apply_tiles: in-place application is not supported");
-    CM2_CHECK(n->method == CM2_TOEPLITZ_FUSED && n->fused,
-              "cm2_noise_apply_tiles needs a Toeplitz operator built with CM2_TOEPLITZ_FUSED");
+    if (!n->fused && n->auto_method && n->lambda > 0 && cm2::fused_os_supported(n->lambda)) {
+        // the method was left to the library and resolved to the direct sum (short band) for
+        // the time order; on a tile order the fused overlap-save kernel is the fast one
+        if (int rc = cm2::fused_os_create(&n->fused, n->d_t, n->lambda, n->h_off, as_stream(stream_)))
+            return rc;
+    }
+    CM2_CHECK(n->fused && (n->method == CM2_TOEPLITZ_FUSED || n->auto_method),
+              "cm2_noise_apply_tiles needs a Toeplitz operator built with CM2_TOEPLITZ_FUSED "
+              "or CM2_TOEPLITZ_AUTO");
     CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
               (long long)n->nt, (long long)cm2_tiles_nt(tiles));
     return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), d_in_tb, d_out_tb,

@@ -261,7 +261,7 @@ class _TiledNormalLO(_DeviceOp):
         _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)
         if self._fused_noise is None:
             info = getattr(self.noise, "noise_info", None)
-            self._fused_noise = info is not None and info()["method"] == 3
+            self._fused_noise = info is not None and info()["tiles_ok"]
         tiled_apply = getattr(self.noise, "_apply_tiles", None)
         if self._fused_noise:
             # overlap-save kernel reads and writes the tile order directly
@@ -506,9 +506,10 @@ class BlockLO(blk.BlockDiagonalLinearOperator):
         return self._diag_dev
 
     def noise_info(self):
-        info = (ctypes.c_int64 * 5)()
+        info = (ctypes.c_int64 * 6)()
         _hip.call("cm2_noise_info", self._noise.h, info)
-        return dict(nt=info[0], nblocks=info[1], lam=info[2], method=info[3], fft_len=info[4])
+        return dict(nt=info[0], nblocks=info[1], lam=info[2], method=info[3], fft_len=info[4],
+                    tiles_ok=bool(info[5]))
 
     def _apply_all(self, v):
         return _noise_apply(self._noise, self._nt, v)

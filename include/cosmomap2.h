@@ -141,7 +141,10 @@ int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_
                           double *d_out_tb, void *stream);
 /* per-sample diagonal of a constant-diagonal noise operator (BlockLO.diag). */
 int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
-/* h_info[0..4] = nt, nblocks, lambda (0 for diag), method used, FFT length */
+/* h_info[0..5] = nt, nblocks, lambda (0 for diag), method used, FFT length, 1 if
+ * cm2_noise_apply_tiles is available (CM2_TOEPLITZ_FUSED, or CM2_TOEPLITZ_AUTO with lambda <= 2049:
+ * an AUTO operator that applies the direct sum on the time order still runs the fused
+ * overlap-save kernel on a tile order) */
 int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
 
 /* ------------------------------------------------------------------------- *

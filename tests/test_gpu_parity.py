@@ -1323,3 +1323,35 @@ def test_small_problems_forced_onto_the_tile_path(cm, nt, npix, pol):
             finally:
                 L.set_pointing_mode("auto")
         assert rel_l2(res["tiled"], res["exact"]) < 1e-13, type(op).__name__
+
+
+@pytest.mark.parametrize("lam", [2, 33, 200])
+def test_default_method_noise_on_tile_order(cm, lam):
+    """BlockLO(..., offdiag=True) with the method left to the library: the direct sum (short
+    band) or the fused kernel on the time order, the fused overlap-save kernel on the tile
+    order whatever the band length; the product P^T N P must agree on the two paths."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    t = cm.torch
+    nside, nt, nb, pol = 32, 1_200_000, 8, 3
+    npix = 12 * nside * nside
+    g = t.Generator(device="cuda").manual_seed(lam)
+    pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
+    phi = 0.3 + 0.0785 * t.arange(nt, device="cuda", dtype=t.float64)
+    ces = cm.U.ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
+    kk = np.arange(lam)
+    bands = [np.where(kk == 0, 1.0, 0.2 * np.exp(-kk / 10.0)) for _ in range(nb)]
+    N = cm.I.BlockLO(nt // nb, bands, offdiag=True)                  # method = AUTO
+    info = N.noise_info()
+    assert info["method"] == (1 if lam <= 32 else 3) and info["tiles_ok"]
+    x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
+    res = {}
+    for mode in ("exact", "tiled"):
+        L.set_pointing_mode(mode)
+        try:
+            A = P.T * N * P
+            res[mode] = A * x
+        finally:
+            L.set_pointing_mode("auto")
+    assert float((res["tiled"] - res["exact"]).norm() / res["exact"].norm()) < 1e-12
