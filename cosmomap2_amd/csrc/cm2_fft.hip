@@ -1236,8 +1236,10 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     // kernels gather windows of a few hundred samples, one or two per pixel tile, and take
     // 1.3 - 3.2 ms at 1e8 samples where this kernel takes 0.9 ms whatever lambda is)
     f->reg_variant = !(variant && strcmp(variant, "pair") == 0);
-    const char *reg_time = getenv("CM2_REG_TIME_ORDER");     // time order: long bands only,
-    f->reg_time_order = f->N == kRegN || (reg_time && atoi(reg_time) != 0);   // unless asked
+    // the time order as well (1e8 samples, lambda 32 / 128 / 512: 0.80 ms against 1.24 / 2.06 /
+    // 0.90 ms of the short-FFT pair kernels); CM2_REG_TIME_ORDER=0 keeps those for N < 8192
+    const char *reg_time = getenv("CM2_REG_TIME_ORDER");
+    f->reg_time_order = f->N == kRegN || !(reg_time && atoi(reg_time) == 0);
     f->lds_bytes = sizeof(double) * 2 * (size_t)(f->N + f->N / 32);
     std::vector<PairDesc> pairs;
     for (int64_t b = 0; b < nb; ++b) {
