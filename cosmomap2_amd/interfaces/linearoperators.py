@@ -202,7 +202,7 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
     """Tile-bucketed plan of a SparseLO, built on first use (sort by pixel tile)."""
     if getattr(P, "_tiles", None) is None:
         if tile_pixels is None:
-            tile_pixels = {1: 8192, 2: 4096, 3: 2048}[P.pol]       # <= 64 KB of LDS per tile
+            tile_pixels = {1: 4096, 2: 2048, 3: 2048}[P.pol]       # 32 / 32 / 48 KB of LDS per tile
             if os.environ.get("CM2_TILE_PIXELS"):
                 tile_pixels = int(os.environ["CM2_TILE_PIXELS"])
             while tile_pixels > 64 and tile_pixels // 2 >= P.ncols:
