@@ -1265,7 +1265,9 @@ def test_filter_chain_on_tile_order(cm):
            cm.I.FilterLO(nt, [np.array([700, 900]), np.array([5000, 120000])], ns, nb, pix, poly_order=3),
            # 1500 chunks of 90 samples per pair
            cm.I.FilterLO(nt, [np.full(tiny_starts.size, 90), tiny_starts], ns, nb, pix, poly_order=1),
-           cm.I.GroundFilterLO(az)]
+           cm.I.GroundFilterLO(az),
+           # more bins than the LDS histogram holds: binning through the pixel-major P^T
+           cm.I.GroundFilterLO(t.randint(0, 9000, (nt,), generator=g, device="cuda", dtype=t.int32))]
     for F in ops:
         res = {}
         for mode in ("exact", "tiled"):
