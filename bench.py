@@ -2,12 +2,18 @@
 """
 bench.py -- TOD samples/s through one P^T N^-1 P matvec (BASELINE.json metric) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
+                    [--scaling weak|strong]
 
 A "step" is one application of A = P^T N^-1 P to a map-domain vector with all inputs
-already resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each
-rank owns a block-aligned TOD shard of the same size (weak scaling), a step is the local
-matvec followed by the RCCL all-reduce of the map.  Rank 0 prints ONE JSON line.
+already resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; a step is
+the local matvec of the rank's block-aligned TOD shard followed by the RCCL all-reduce of the
+map.  --scaling weak (default): every rank owns a shard of the configuration's per-GPU size
+(C4: 1e8 samples per GPU); --scaling strong: the configuration's TOTAL is cut into N shards
+(C4: 1e8 samples over N ranks; C5: 1e9 over 8).  With N > 1 the JSON line carries the other
+mode's point too ("other_scaling_point"), the backend and world size torch.distributed
+reports, and the exposed all-reduce time (step minus the local matvec).  Rank 0 prints ONE
+JSON line.
 
 Workloads (BASELINE.json configs; synthetic inputs after utilities_functions.py:99-212:
 uniform-random pixel per sample, HWP angle ramp, d ~ U[0,1)):
@@ -15,10 +21,17 @@ uniform-random pixel per sample, HWP angle ramp, d ~ U[0,1)):
   c3  nside 128 IQU, 1e8 samples, banded-Toeplitz N, lambda 2048 -> P, overlap-save FFT, P^T
   c4  nside 256 IQU, 1e8 samples/GPU, Toeplitz lambda 2048       -> the configuration the
       north_star target (>= 40 % HBM roofline) is quoted on; DEFAULT.
+  c5  one GPU's share of C5: nside 512 IQU, 1.25e8 samples (8 detector blocks of 15 625 000)
+
+Byte accounting per stage: "bytes_survey" is SURVEY.md 8(d)'s algorithmic figure (P 28, N^-1 16,
+P^T 28 B/sample + map traffic) -- the figure `roofline.achieved` is computed from;
+"bytes_designed" is what the kernel is built to move (half-angle storage, address lists, window
+overlap), which is what to compare the PMC traffic with.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,13 +43,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 CONFIGS = {
-    "c2": dict(nside=128, nt=10_000_000, nb=100, lam=0, label="C2 nside128 IQU 1e7 diag-N"),
-    "c3": dict(nside=128, nt=100_000_000, nb=100, lam=2048,
+    "c2": dict(nside=128, nt=10_000_000, nb=100, lam=0, total=10_000_000, total_nb=100,
+               label="C2 nside128 IQU 1e7 diag-N"),
+    "c3": dict(nside=128, nt=100_000_000, nb=100, lam=2048, total=100_000_000, total_nb=100,
                label="C3 nside128 IQU 1e8 Toeplitz(2048)"),
-    "c4": dict(nside=256, nt=100_000_000, nb=100, lam=2048,
+    "c4": dict(nside=256, nt=100_000_000, nb=100, lam=2048, total=100_000_000, total_nb=100,
                label="C4 nside256 IQU 1e8/GPU Toeplitz(2048)"),
     # one GPU's share of C5 (1e9 samples, 64 detector blocks over 8 GPUs): 8 blocks of 15 625 000
-    "c5": dict(nside=512, nt=125_000_000, nb=8, lam=2048,
+    "c5": dict(nside=512, nt=125_000_000, nb=8, lam=2048, total=1_000_000_000, total_nb=64,
                label="C5 share: nside512 IQU 1.25e8/GPU, 8 detector blocks, Toeplitz(2048)"),
 }
 
@@ -62,6 +76,14 @@ def toeplitz_band(lam, rng, fknee=0.02, alpha=1.5):
     return a * (1.0 + 0.1 * rng.random())
 
 
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("CM2_BENCH_CONFIG", "c4"),
                     choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--lam", type=int, default=0, help="override the Toeplitz band length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -77,6 +100,8 @@ def main():
                     help="skip the secondary run with a coherent raster-scan pointing")
     ap.add_argument("--no-filters", action="store_true",
                     help="skip the FilterLO / GroundFilterLO timing (SURVEY 8f rows)")
+    ap.add_argument("--no-other-point", action="store_true",
+                    help="N > 1: skip the other scaling mode's point")
     ap.add_argument("--deflation", type=int, default=32,
                     help="rank of the deflation space of the two-level PCG run (0 = skip)")
     ap.add_argument("--arnoldi-steps", type=int, default=96)
@@ -114,76 +139,142 @@ def main():
     from cosmomap2_amd import device as D
     from cosmomap2_amd import _hip
     from cosmomap2_amd.interfaces import SparseLO, BlockLO, BlockDiagonalPreconditionerLO
+    from cosmomap2_amd.interfaces import linearoperators as L
     from cosmomap2_amd.utilities import ProcessTimeSamples
-    from cosmomap2_amd.sharding import ShardedLO, make_sync
+    from cosmomap2_amd.sharding import ShardedLO, make_sync, shard_blocks
 
     cfg = dict(CONFIGS[args.config])
     if args.nt:
         cfg["nt"] = args.nt
+        cfg["total"] = args.nt
+        cfg["total_nb"] = cfg["nb"]
     if args.lam and cfg["lam"]:
         cfg["lam"] = args.lam
         cfg["label"] += " [lambda=%d]" % args.lam
     pol = 3
     npix = 12 * cfg["nside"] ** 2
-    nb = cfg["nb"]
-    nt = (cfg["nt"] // nb) * nb
-    bsize = nt // nb
     lam = cfg["lam"]
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    # ---- synthetic shard, generated in HBM (seed differs per rank) -------------------
-    t_setup = time.time()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(20161202 + 1000 * rank)
-    rng = np.random.default_rng(20161202 + 1000 * rank)
-    pix = torch.randint(0, npix, (nt,), generator=gen, device=dev, dtype=torch.int32)
-    theta0 = float(rng.uniform(0, np.pi))
-    phi = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
-    d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
-    if lam:
-        bands = [toeplitz_band(lam, rng) for _ in range(nb)]
-        N = BlockLO(bsize, bands, offdiag=True, method=(3 if args.toeplitz == "fused" else 2))
-        nlabel = "N^-1 (k_overlap_save, LDS FFT)" if args.toeplitz == "fused" else "N^-1 (overlap-save rocFFT)"
-        w = None
-    else:
-        N = BlockLO(bsize, list(rng.random(nb) + 0.5), offdiag=False)
-        w = N._device_diag()
-    allred = None
-    if world > 1:
-        allred = lambda t: dist.all_reduce(t)
-    ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi, w=w, allreduce=allred)
-    del phi
-    npix_c = ces.get_new_pixel[0]
-    P = SparseLO(npix_c, nt, pix, pol=pol, angle_processed=ces)
-    Mbd = BlockDiagonalPreconditionerLO(ces, npix_c, pol=pol)
-    A_local = P.T * N * P
-    A = ShardedLO(A_local) if world > 1 else A_local
-    n = pol * npix_c
-    x = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(7), device=dev,
-                   dtype=torch.float64)
-    torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
+    def sync():
+        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- a rank's shard in one scaling mode, generated in HBM (seed differs per rank) -------
+    def shard_geometry(scaling):
+        """(samples, noise blocks) of this rank's shard."""
+        if scaling == "weak" or world == 1:
+            nb = cfg["nb"]
+            return (cfg["nt"] // nb) * nb, nb
+        tnb = cfg["total_nb"]
+        bsz = cfg["total"] // tnb
+        b0, b1, s0, s1 = shard_blocks([bsz] * tnb, world, rank)
+        return s1 - s0, b1 - b0
+
+    def build_shard(scaling):
+        nt, nb = shard_geometry(scaling)
+        bsize = nt // nb
+        tm = {}
+        t0 = time.time()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(20161202 + 1000 * rank)
+        rng = np.random.default_rng(20161202 + 1000 * rank)
+        pix = torch.randint(0, npix, (nt,), generator=gen, device=dev, dtype=torch.int32)
+        theta0 = float(rng.uniform(0, np.pi))
+        phi = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+        d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
+        sync()
+        tm["generate_inputs"] = time.time() - t0
+        t0 = time.time()
+        if lam:
+            bands = [toeplitz_band(lam, rng) for _ in range(nb)]
+            N = BlockLO(bsize, bands, offdiag=True, method=(3 if args.toeplitz == "fused" else 2))
+            w = None
+        else:
+            bands = None
+            N = BlockLO(bsize, list(rng.random(nb) + 0.5), offdiag=False)
+            w = N._device_diag()
+        sync()
+        tm["noise_operator"] = time.time() - t0
+        t0 = time.time()
+        allred = (lambda t: dist.all_reduce(t)) if world > 1 else None
+        ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi, w=w, allreduce=allred)
+        del phi
+        sync()
+        tm["weights_mask_compaction"] = time.time() - t0
+        npix_c = ces.get_new_pixel[0]
+        t0 = time.time()
+        P = SparseLO(npix_c, nt, pix, pol=pol, angle_processed=ces)
+        Mbd = BlockDiagonalPreconditionerLO(ces, npix_c, pol=pol)
+        sync()
+        tm["pixel_major_plan_and_M_BD"] = time.time() - t0
+        A_local = P.T * N * P
+        A = ShardedLO(A_local) if world > 1 else A_local
+        n = pol * npix_c
+        x = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(7), device=dev,
+                       dtype=torch.float64)
+        if lam and L._use_tiles(P):
+            t0 = time.time()
+            L._sparse_tiles(P)
+            sync()
+            tm["tile_plan"] = time.time() - t0
+            t0 = time.time()
+            A_local * x            # first application: FFT address lists, fixed-order P^T lists
+            sync()
+            tm["first_matvec_fft_lists_and_PT_lists"] = time.time() - t0
+        return dict(nt=nt, nb=nb, bsize=bsize, pix=pix, d=d, bands=bands, N=N, w=w, ces=ces,
+                    npix_c=npix_c, P=P, Mbd=Mbd, A_local=A_local, A=A, n=n, x=x, rng=rng,
+                    gen=gen, theta0=theta0, setup=tm)
+
+    def timed(A, x, steps, warmup):
+        for _ in range(warmup):
+            y = A * x
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = A * x
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        del y
+        return elapsed
+
+    t_setup = time.time()
+    S = build_shard(args.scaling)
+    sync()
+    t_setup = time.time() - t_setup
+    S_setup = S["setup"]
+    nt, nb, bsize, npix_c, n = S["nt"], S["nb"], S["bsize"], S["npix_c"], S["n"]
+    P, N, A, A_local, Mbd, x, d, pix, ces = (S[k] for k in ("P", "N", "A", "A_local", "Mbd", "x",
+                                                               "d", "pix", "ces"))
+    bands, w, gen, theta0 = S["bands"], S["w"], S["gen"], S["theta0"]
+
     # ---- timed region: W warmup + exactly K steps ------------------------------------
-    for _ in range(args.warmup):
-        y = A * x
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = A * x
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = timed(A, x, args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * nt / (elapsed / args.steps)
+    nt_all = nt
+    if world > 1:
+        tot = torch.tensor([float(nt)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        nt_all = int(tot.item())
+    value = nt_all / (elapsed / args.steps)
+
+    # exposed all-reduce: the same K steps of the local matvec alone
+    dist_info = None
+    if world > 1:
+        el_local = timed(A_local, x, args.steps, args.warmup)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "local_matvec_ms": round(1e3 * el_local / args.steps, 4),
+                     "exposed_allreduce_ms": round(ms_per_step - 1e3 * el_local / args.steps, 4),
+                     "allreduce_bytes": 8 * n,
+                     "allreduce_chunks": int(os.environ.get("CM2_ALLREDUCE_CHUNKS", "4"))}
 
     # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
     def ev_time(fn, reps):
@@ -200,59 +291,73 @@ def main():
         return float(np.mean(ts)), float(ts[len(ts) // 2])
 
     reps = max(5, min(args.steps, 20))
-    stages = {}
+    stages = {}          # name -> ((mean ms, median ms), bytes_survey, bytes_designed)
     map_bytes = 48.0 * npix_c
+    tile_info = None
     if lam:
-        from cosmomap2_amd.interfaces import linearoperators as L
         tod = P * x
         tod2 = N * tod
         if L._use_tiles(P):
             T = L._sparse_tiles(P)
+            nv = T.nvalid
+            ang = 8.0 if T.half_angle else 16.0          # half-angle double, or cos and sin
             st = D.stream
             d_tb = D.empty(T.nvalid)
             out = D.empty(n)
             call = _hip.call
+            tile_info = {"tile_pixels": T.tile_pixels, "tiles": T.ntiles,
+                         "half_angle_storage": T.half_angle,
+                         "pt_order": "fixed (time order per pixel, no atomics)" if T.pt_fixed
+                         else "atomic"}
             stages["P tiles (k_P_tiles)"] = (ev_time(lambda: call(
                 "cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()), reps),
-                28.0 * nt + map_bytes / 2)
+                28.0 * nt + map_bytes / 2, (2.0 + ang + 8.0) * nv + map_bytes / 2)
             if args.toeplitz == "fused":
                 v_tb = D.empty(T.nvalid)
+                os_designed = float(N.noise_info().get("tile_bytes_per_sample", 35.0)) * nv
                 stages["N^-1 on tile order (k_overlap_save_reg, register+LDS FFT)"] = (ev_time(lambda: call(
                     "cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st()),
-                    reps), 16.0 * nt)
+                    reps), 16.0 * nt, os_designed)
                 del v_tb
             else:
                 stages["tiles->time (k_tiles_to_time)"] = (ev_time(lambda: call(
-                    "cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st()), reps), 16.0 * nt)
-                stages[nlabel] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
+                    "cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), st()), reps),
+                    16.0 * nt, 22.0 * nt)
+                stages["N^-1 (overlap-save rocFFT)"] = (ev_time(lambda: N * tod, reps), 16.0 * nt,
+                                                        None)
                 stages["time->tiles (k_time_to_tiles)"] = (ev_time(lambda: call(
                     "cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st()), reps),
-                    16.0 * nt)
-            stages["P^T tiles (k_Pt_tiles)"] = (ev_time(lambda: call(
+                    16.0 * nt, 22.0 * nt)
+            pt_name = "P^T tiles (k_Pt_tiles_fixed)" if T.pt_fixed else "P^T tiles (k_Pt_tiles)"
+            pt_designed = ((8.0 + 4.0 + ang) if T.pt_fixed else (8.0 + 2.0 + ang)) * nv + map_bytes / 2
+            stages[pt_name] = (ev_time(lambda: call(
                 "cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st()), reps),
-                28.0 * nt + map_bytes / 2)
+                28.0 * nt + map_bytes / 2, pt_designed)
             del d_tb, out
         else:
-            stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2)
-            stages[nlabel] = (ev_time(lambda: N * tod, reps), 16.0 * nt)
+            stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2,
+                                      28.0 * nt + map_bytes / 2)
+            stages["N^-1"] = (ev_time(lambda: N * tod, reps), 16.0 * nt, 24.0 * nt)
             stages["P^T (k_Pt_sell)"] = (ev_time(lambda: P.T * tod2, reps),
-                                         28.0 * nt + map_bytes / 2)
+                                         28.0 * nt + map_bytes / 2, 32.0 * nt + map_bytes / 2)
         step_bytes = 72.0 * nt + map_bytes
         del tod, tod2
     else:
         stages["P^T diag(w) P fused (k_PtNP_sell)"] = (ev_time(lambda: A_local * x, reps),
-                                                       28.0 * nt + map_bytes)
+                                                       28.0 * nt + map_bytes, 24.0 * nt + map_bytes)
         step_bytes = 28.0 * nt + map_bytes
     dom = max(stages, key=lambda k: stages[k][0][0])
-    (dom_mean, dom_med), dom_bytes = stages[dom]
+    (dom_mean, dom_med), dom_bytes, dom_designed = stages[dom]
     achieved = dom_bytes / (dom_mean * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes": dom_bytes,
+                "traffic": None, "traffic_measured_in_run": False,
+                "algorithmic_bytes": dom_bytes, "designed_bytes": dom_designed,
                 "avg_launch_ms": round(dom_mean, 4)}
-    # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE need
-    # rocprofv3 passes of their own, so they are taken from the committed summary of this very
-    # command -- profiles/make_summary.py -- and only when the workload is the same)
+    # HBM traffic of the dominant kernel from the PMC counters.  FETCH_SIZE / WRITE_SIZE need
+    # rocprofv3 passes of their own, so the figure is NOT measured in this run: it is copied from
+    # the newest committed summary of this command (profiles/make_summary.py), only when workload
+    # and size are the same, and labelled with that profile's file and commit.
     try:
         pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_c4.json"))
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
@@ -261,11 +366,20 @@ def main():
                 if kname in dom and rec.get("hbm_traffic_bytes"):
                     roofline["traffic"] = rec["hbm_traffic_bytes"]
                     roofline["traffic_source"] = "profiles/" + pmcs[-1]
+                    roofline["traffic_source_commit"] = pmc.get("commit")
     except Exception:
         pass
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
-    stage_report = {k: {"ms": round(v[0][0], 4), "GB/s": round(v[1] / (v[0][0] * 1e-3) / 1e9, 1)}
-                    for k, v in stages.items()}
+    stage_report = {}
+    for k, v in stages.items():
+        ms = v[0][0]
+        rec = {"ms": round(ms, 4), "bytes_survey": v[1],
+               "GB/s_survey": round(v[1] / (ms * 1e-3) / 1e9, 1)}
+        if v[2] is not None:
+            rec["bytes_designed"] = v[2]
+            rec["GB/s_designed"] = round(v[2] / (ms * 1e-3) / 1e9, 1)
+            rec["frac_of_hbm_peak_designed"] = round(v[2] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        stage_report[k] = rec
 
     # ---- PCG iterations to 1e-6 (outside the timed region) ----------------------------
     pcg = None
@@ -281,21 +395,29 @@ def main():
                                     callback=lambda xk: its.append(1), sync=make_sync())
         torch.cuda.synchronize()
         pcg = {"rtol": 1e-6, "iters": len(its), "info": int(info),
-               "seconds": round(time.perf_counter() - tp, 3), "preconditioner": "block-diagonal"}
+               "seconds": round(time.perf_counter() - tp, 3), "preconditioner": "block-diagonal",
+               "true_relative_residual": float(torch.linalg.vector_norm(b - A * xs)
+                                               / torch.linalg.vector_norm(b))}
         if lam and args.deflation > 0:
             # two-level preconditioner with an Arnoldi/Ritz deflation space (BASELINE config C4)
             from cosmomap2_amd.interfaces import (DeflationLO, CoarseLO, TwoLevelPreconditionerLO,
-                                                  ritz_deflation_basis)
+                                                  ritz_deflation_basis, apply_to_columns)
+            from cosmomap2_amd.utilities import write_ritz_eigenvectors, read_ritz_eigenvectors
             r = args.deflation
             tz = time.perf_counter()
             Z, theta = ritz_deflation_basis(A, Mbd, b, r, args.arnoldi_steps)
-            AZ = torch.empty_like(Z)
-            for j in range(r):
-                AZ[:, j] = A * Z[:, j].contiguous()
+            torch.cuda.synchronize()
+            t_ritz = time.perf_counter() - tz
+            ta = time.perf_counter()
+            AZ = apply_to_columns(A, Z)
+            torch.cuda.synchronize()
+            t_az = time.perf_counter() - ta
+            te = time.perf_counter()
             Zd, AZd = DeflationLO(Z), DeflationLO(AZ)
             E = CoarseLO(Z, AZ, r, apply='eig')
             M2 = TwoLevelPreconditionerLO(Mbd, Zd, AZd, E)
             torch.cuda.synchronize()
+            t_e = time.perf_counter() - te
             t_build = time.perf_counter() - tz
             cosmomap2_amd.cg(A, b, M=M2, rtol=1e-6, maxiter=1, sync=make_sync())   # warm-up
             torch.cuda.synchronize()
@@ -306,12 +428,69 @@ def main():
             torch.cuda.synchronize()
             t_pcg2 = time.perf_counter() - tp
             rel = float(torch.linalg.vector_norm(xs2 - xs) / torch.linalg.vector_norm(xs))
-            pcg["two_level"] = {"rank": r, "arnoldi_steps": args.arnoldi_steps,
-                                "iters": len(its2), "info": int(info2),
-                                "seconds": round(t_pcg2, 4),
-                                "build_seconds": round(t_build, 3),
-                                "smallest_ritz": float(theta[0]), "largest_kept_ritz": float(theta[-1]),
-                                "rel_l2_vs_block_diagonal_solution": rel}
+            # one application of M2: Z^T r, the r x r solve, fused tail over Z and AZ
+            rr = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(9), device=dev,
+                            dtype=torch.float64)
+            m2_mean, m2_med = ev_time(lambda: M2 * rr, reps)
+            work = D.reduce_work()
+            y32 = D.empty(r)
+            zt_mean, _ = ev_time(lambda: _hip.call("cm2_Zt_apply", n, r, D.ptr(Z), D.ptr(rr),
+                                                   D.ptr(y32), D.ptr(work), D.stream()), reps)
+            zy = D.empty(n)
+            z_mean, _ = ev_time(lambda: _hip.call("cm2_Z_apply", n, r, D.ptr(Z), D.ptr(y32),
+                                                  D.ptr(zy), D.stream()), reps)
+            gw = D.empty(int(_hip.load().cm2_gemm_tn_work_doubles(r, r)))
+            dE = D.empty(r * r)
+            g_mean, _ = ev_time(lambda: _hip.call("cm2_gemm_tn", n, r, r, D.ptr(Z), D.ptr(AZ),
+                                                  D.ptr(dE), D.ptr(gw), D.stream()), reps)
+            zbytes = 8.0 * n * r
+            m2_bytes = 3 * zbytes + 8.0 * 3 * n + 56.0 * npix_c
+            two = {"rank": r, "arnoldi_steps": args.arnoldi_steps,
+                   "iters": len(its2), "info": int(info2),
+                   "seconds": round(t_pcg2, 4),
+                   "build_seconds": round(t_build, 3),
+                   "build_split_seconds": {"arnoldi_and_ritz_vectors": round(t_ritz, 3),
+                                           "AZ_columns": round(t_az, 3),
+                                           "coarse_matrix_and_operators": round(t_e, 3)},
+                   "smallest_ritz": float(theta[0]), "largest_kept_ritz": float(theta[-1]),
+                   "rel_l2_vs_block_diagonal_solution": rel,
+                   "M2_apply": {"ms": round(m2_mean, 4), "bytes": m2_bytes,
+                                "GB/s": round(m2_bytes / (m2_mean * 1e-3) / 1e9, 1),
+                                "frac_of_hbm_peak": round(m2_bytes / (m2_mean * 1e-3) / 1e9
+                                                          / HBM_PEAK_GBS, 4)},
+                   "kernels": {
+                       "Z^T r (cm2_Zt_apply)": {
+                           "ms": round(zt_mean, 4),
+                           "GB/s": round((zbytes + 8.0 * n) / (zt_mean * 1e-3) / 1e9, 1)},
+                       "Z y (cm2_Z_apply)": {
+                           "ms": round(z_mean, 4),
+                           "GB/s": round((zbytes + 8.0 * n) / (z_mean * 1e-3) / 1e9, 1)},
+                       "E = Z^T AZ (cm2_gemm_tn, fp64 MFMA)": {
+                           "ms": round(g_mean, 4),
+                           "GB/s": round(2 * zbytes / (g_mean * 1e-3) / 1e9, 1),
+                           "TFLOP/s": round(2.0 * n * r * r / (g_mean * 1e-3) / 1e12, 2)}}}
+            # Ritz-vector checkpoint: what a second run pays instead of the build
+            if rank == 0:
+                import tempfile
+                with tempfile.TemporaryDirectory() as tmp:
+                    fn = os.path.join(tmp, "ritz_c4")
+                    tw = time.perf_counter()
+                    write_ritz_eigenvectors(Z, fn, eigvals=theta)
+                    t_w = time.perf_counter() - tw
+                    tr = time.perf_counter()
+                    Zr, thr = read_ritz_eigenvectors(fn, eigvals=True, device=True)
+                    AZr = apply_to_columns(A_local, Zr)
+                    CoarseLO(Zr, AZr, r, apply='eig')
+                    torch.cuda.synchronize()
+                    t_r = time.perf_counter() - tr
+                    two["checkpoint"] = {"write_seconds": round(t_w, 3),
+                                         "build_seconds_from_checkpoint": round(t_r, 3),
+                                         "bit_identical_Z": bool(torch.equal(Zr, Z)),
+                                         "note": "local operator only" if world > 1 else None}
+                    del Zr, AZr
+            pcg["two_level"] = two
+            del Z, AZ, Zd, AZd, E, M2, xs2, rr, zy, gw
+        del b, xs
 
     # ---- 8(f) rows: sub-scan and ground filters on the same TOD (rank 0, untimed extras) ----
     filters = None
@@ -391,6 +570,26 @@ def main():
                                                  / HBM_PEAK_GBS, 4)}
         del A_r, P_r, ces_r, pix_r, x_r
 
+    fft_len = N.noise_info()["fft_len"] if lam else 0
+
+    # ---- the other scaling mode's point (N > 1) --------------------------------------------
+    other = None
+    if world > 1 and not args.no_other_point:
+        other_mode = "strong" if args.scaling == "weak" else "weak"
+        del A, A_local, P, N, Mbd, ces, x, d, pix, S
+        torch.cuda.empty_cache()
+        S2 = build_shard(other_mode)
+        el2 = timed(S2["A"], S2["x"], args.steps, args.warmup)
+        el2_local = timed(S2["A_local"], S2["x"], args.steps, args.warmup)
+        tot = torch.tensor([float(S2["nt"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        other = {"scaling": other_mode, "nt_this_rank": S2["nt"], "nt_all_ranks": int(tot.item()),
+                 "ms_per_step": round(1e3 * el2 / args.steps, 4),
+                 "value": float(tot.item()) / (el2 / args.steps), "unit": "TOD samples/s",
+                 "local_matvec_ms": round(1e3 * el2_local / args.steps, 4),
+                 "exposed_allreduce_ms": round(1e3 * (el2 - el2_local) / args.steps, 4)}
+        del S2
+
     # ---- CPU baseline: the oracle (1 core, reference-unfused) on a bounded sample -----
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -457,22 +656,27 @@ def main():
             "metric": "TOD samples/s through P^T N^-1 P",
             "value": value, "unit": "TOD samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["label"], "nside": cfg["nside"], "pol": pol,
-                       "nt_per_gpu": nt, "npix": int(npix_c), "noise": ("toeplitz" if lam else "diag"),
-                       "lambda": lam, "blocks_per_gpu": nb,
-                       "fft_len": (N.noise_info()["fft_len"] if lam else 0),
+                       "nt_per_gpu": nt, "nt_all_gpus": nt_all, "npix": int(npix_c),
+                       "noise": ("toeplitz" if lam else "diag"),
+                       "lambda": lam, "blocks_per_gpu": nb, "fft_len": fft_len,
+                       "tile_plan": tile_info,
                        "parallelism": "tod-shard x%d + map all-reduce" % world},
             "roofline": roofline,
             "step_algorithmic_GBps": round(step_gbs, 1),
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "stages": stage_report,
+            "distributed": dist_info,
+            "other_scaling_point": other,
             "pcg": pcg,
             "raster_pointing": raster,
             "filters": filters,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "setup_seconds": round(t_setup, 2),
+            "setup_split_seconds": {k: round(v, 3) for k, v in S_setup.items()},
+            "commit": git_head(),
         }
         print(json.dumps(out))
     if world > 1:

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "cm2_tiles_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _vp],
     "cm2_tiles_destroy": [_vp],
     "cm2_tiles_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_tiles_set_pt_order": [_vp, _int],
     "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_i32_time_to_tiles": [_vp, _vp, _vp, _vp],
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "cm2_gemm_tn": [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "cm2_small_matvec": [_int, _vp, _vp, _vp, _vp],
     "cm2_gemm_atbt": [_i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "cm2_transpose": [_i64, _i64, _vp, _vp, _vp],
     "cm2_cos_sin_2phi": [_i64, _vp, _vp, _vp, _vp],
     "cm2_m2_finish": [_int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp, _vp],

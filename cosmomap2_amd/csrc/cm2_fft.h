@@ -14,9 +14,10 @@ bool fused_os_supported(int64_t lambda);
 int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
                     const std::vector<int64_t> &off, hipStream_t stream);
 int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream);
-// same, with input and output TODs addressed through d_idx[t] (tile-bucketed order)
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
-                           hipStream_t stream);
+// same, with input and output TODs addressed through d_idx[t] (tile-bucketed order of the tile
+// plan `plan_id`; the address lists are rebuilt when the plan changes)
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, const double *d_v,
+                           double *d_out, hipStream_t stream);
 int64_t fused_os_length(const FusedOS *f);
 void fused_os_destroy(FusedOS *f);
 

@@ -978,7 +978,7 @@ struct FusedOS {
     uint32_t *d_l1_k = nullptr, *d_l2_k = nullptr, *d_ls_k = nullptr;
     uint16_t *d_l1_q = nullptr, *d_l2_q = nullptr, *d_ls_q = nullptr;
     // address-sorted gather lists of the tile-order path, built for one tile index at a time
-    const void *list_key = nullptr;
+    uint64_t list_plan = 0;              // id of the tile plan the lists were built for
     uint32_t *d_lst_k = nullptr;
     uint16_t *d_lst_q = nullptr;
     // real-input variant (one segment of 8192 reals per workgroup, two workgroups per CU)
@@ -1008,13 +1008,10 @@ template <int R1, int R2, int R3, bool INDIRECT>
 static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
                   hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save<R1, R2, R3, INDIRECT>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)f->lds_bytes));
-        attr_set = true;
-    }
+    // per launch: the attribute is per device, and setting it is cheap
+    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save<R1, R2, R3, INDIRECT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)f->lds_bytes));
     const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
         f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx,
@@ -1027,12 +1024,9 @@ template <bool LISTS>
 static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg<LISTS>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // per launch: the attribute is per device, and setting it is cheap
+    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg<LISTS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (f->npairs_reg == 0) return 0;
     const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
     k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
@@ -1047,12 +1041,9 @@ static int launch_real(const FusedOS *f, const uint32_t *d_idx, const double *d_
                        hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * 2 * (size_t)(kRealM + kRealM / 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_real<INDIRECT>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // per launch: the attribute is per device, and setting it is cheap
+    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_real<INDIRECT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (f->nsegs == 0) return 0;
     const int grid = (int)(((f->nsegs + 7) / 8) * 8);
     k_overlap_save_real<INDIRECT><<<grid, kRealT, lds, stream>>>(
@@ -1079,13 +1070,13 @@ int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream
     return dispatch<false>(f, nullptr, d_v, d_out, stream);
 }
 
-static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
+static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipStream_t stream)
 {
     if (f->d_lst_k) (void)hipFree(f->d_lst_k);
     if (f->d_lst_q) (void)hipFree(f->d_lst_q);
     f->d_lst_k = nullptr;
     f->d_lst_q = nullptr;
-    f->list_key = nullptr;
+    f->list_plan = 0;
     const char *e = getenv("CM2_OS_LISTS");
     if (f->real_variant || f->npairs == 0 || (e && atoi(e) == 0)) {
         if (f->d_l1_k) {                                     // lists of another tile index
@@ -1096,7 +1087,7 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
                 *q = nullptr;
             }
         }
-        f->list_key = (const void *)d_idx;                   // per-sample index mode
+        f->list_plan = plan_id;                              // per-sample index mode
         return 0;
     }
     if (f->reg_variant) {
@@ -1137,7 +1128,7 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
                                                             f->d_ls_k, f->d_ls_q);
         CM2_LAUNCH_OK();
         CM2_HIP(hipStreamSynchronize(stream));
-        f->list_key = (const void *)d_idx;
+        f->list_plan = plan_id;
         return 0;
     }
     const int64_t qm = f->N + f->hop, total = f->npairs * qm;
@@ -1163,15 +1154,17 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, hipStream_t stream)
     k_list_unpack<<<grid_for(total), kBlock, 0, stream>>>(total, keys_out, f->d_lst_k);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    f->list_key = (const void *)d_idx;
+    f->list_plan = plan_id;
     return 0;
 }
 
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
-                           hipStream_t stream)
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, const double *d_v,
+                           double *d_out, hipStream_t stream)
 {
-    if (f->list_key != (const void *)d_idx)
-        if (int rc = build_lists(f, d_idx, stream)) return rc;
+    // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
+    // again to a later plan of the same size)
+    if (f->list_plan != plan_id)
+        if (int rc = build_lists(f, d_idx, plan_id, stream)) return rc;
     return dispatch<true>(f, d_idx, d_v, d_out, stream);
 }
 
@@ -1182,6 +1175,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
               (long long)lambda);
     FusedOS *f = new FusedOS();
+    struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};   // early returns
     f->halo = (int)(lambda - 1);
     int64_t forced = 0;
     if (const char *e = getenv("CM2_FUSED_FFT_LEN")) forced = atoll(e);
@@ -1225,6 +1219,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
                                                                              f->d_Hs);
         CM2_LAUNCH_OK();
         CM2_HIP(hipStreamSynchronize(stream));
+        guard.f = nullptr;
         *out = f;
         return 0;
     }
@@ -1298,6 +1293,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
         CM2_LAUNCH_OK();
     }
     CM2_HIP(hipStreamSynchronize(stream));
+    guard.f = nullptr;
     *out = f;
     return 0;
 }

@@ -502,7 +502,7 @@ struct cm2_filter {
     int64_t nkind[3] = {0, 0, 0};
     std::vector<int64_t> h_start, h_len; // host copies of the chunk table (window planning)
     // tile-order plan, built for one tile index at a time
-    const void *win_key = nullptr;
+    uint64_t win_plan = 0;            // id of the tile plan the window lists were built for
     bool win_ok = false, win_memset = false;
     int64_t nwin = 0;
     FilterWin *d_wins = nullptr;
@@ -683,17 +683,19 @@ extern "C" int cm2_filter_apply(const cm2_filter *f, const double *d_in, double 
 
 extern "C" const uint32_t *cm2_tiles_index(const cm2_tiles *t);     // cm2_tiles.hip
 extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t);
+extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t);
+extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t);
 
 namespace {
 
-int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, hipStream_t st)
+int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, uint64_t plan_id, hipStream_t st)
 {
     void **old[] = {(void **)&f->d_wins, (void **)&f->d_win_k, (void **)&f->d_win_q};
     for (void **q : old) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
-    f->win_key = (const void *)d_idx;
+    f->win_plan = 0;                                  // set once the lists are complete
     f->win_ok = false;
     f->win_memset = false;
     f->nwin = 0;
@@ -706,7 +708,10 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, hipStream_t st)
         const int64_t t0 = S[(size_t)s0];
         int64_t s1 = s0;
         while (s1 < nseg && S[(size_t)s1] + L[(size_t)s1] - t0 <= kWinLen && s1 - s0 < (1 << 20)) ++s1;
-        if (s1 == s0) return 0;                       // a chunk longer than a window: not tileable
+        if (s1 == s0) {                               // a chunk longer than a window: not tileable
+            f->win_plan = plan_id;
+            return 0;
+        }
         int64_t t1 = S[(size_t)s1 - 1] + L[(size_t)s1 - 1];
         const int64_t next = s1 < nseg ? S[(size_t)s1] : f->nt;
         if (next - t0 <= kWinLen) t1 = next;          // the trailing gap rides along (zeroed in LDS)
@@ -722,7 +727,10 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, hipStream_t st)
     }
     f->nwin = (int64_t)wins.size();
     f->win_ok = true;
-    if (f->nwin == 0) return 0;
+    if (f->nwin == 0) {
+        f->win_plan = plan_id;
+        return 0;
+    }
     CM2_CHECK(f->nseg < ((int64_t)1 << 31) && f->nwin < ((int64_t)1 << 31), "too many chunks");
     CM2_HIP(hipMalloc(&f->d_wins, sizeof(FilterWin) * wins.size()));
     CM2_HIP(hipMemcpyAsync(f->d_wins, wins.data(), sizeof(FilterWin) * wins.size(),
@@ -749,6 +757,7 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, hipStream_t st)
     k_win_unpack<<<grid_for(total), kBlock, 0, st>>>(total, keys_out, f->d_win_k);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(st));
+    f->win_plan = plan_id;
     return 0;
 }
 
@@ -756,12 +765,9 @@ template <int K>
 int launch_windows(const cm2_filter *f, const double *d_in, double *d_out, hipStream_t st)
 {
     constexpr size_t lds = sizeof(double) * kWinLen + kWinLen;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CM2_HIP(hipFuncSetAttribute((const void *)k_filter_windows<K>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // per launch: the attribute is per device, and setting it is cheap
+    CM2_HIP(hipFuncSetAttribute((const void *)k_filter_windows<K>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (int)(((f->nwin + 7) / 8) * 8);
     k_filter_windows<K><<<grid, kWinT, lds, st>>>(f->d_wins, (int)f->nwin, f->d_start, f->d_len,
                                                   f->d_kind, f->d_toff, f->d_table, f->d_coef,
@@ -781,12 +787,13 @@ extern "C" int cm2_filter_apply_tiles(cm2_filter *f, const cm2_tiles *tiles, con
               (long long)f->nt, (long long)cm2_tiles_nt(tiles));
     hipStream_t st = as_stream(stream);
     const uint32_t *d_idx = cm2_tiles_index(tiles);
-    if (f->win_key != (const void *)d_idx)
-        if (int rc = filter_windows_build(f, d_idx, st)) return rc;
+    // the lists belong to ONE tile plan: keyed on its id, not on a device address that a later
+    // plan could be given again by the allocator
+    const uint64_t plan_id = cm2_tiles_plan_id(tiles);
+    if (f->win_plan != plan_id)
+        if (int rc = filter_windows_build(f, d_idx, plan_id, st)) return rc;
     if (!f->win_ok) return 0;                         // caller falls back to the time order
-    int64_t tinfo[6];
-    if (int rc = cm2_tiles_info(tiles, tinfo)) return rc;
-    const int64_t nvalid = tinfo[1];
+    const int64_t nvalid = cm2_tiles_nvalid(tiles);
     CM2_CHECK(nvalid == 0 || (d_in_tb && d_out_tb && d_in_tb != d_out_tb),
               "cm2_filter_apply_tiles: null or aliased vectors");
     if (f->win_memset && nvalid) CM2_HIP(hipMemsetAsync(d_out_tb, 0, sizeof(double) * nvalid, st));

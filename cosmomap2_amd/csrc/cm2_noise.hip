@@ -495,6 +495,7 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
 struct cm2_tiles;
 extern "C" const uint32_t *cm2_tiles_index(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t);
+extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t);
 
 extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
                                      double *d_out_tb, void *stream_)
@@ -512,6 +513,6 @@ extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const
               "or CM2_TOEPLITZ_AUTO");
     CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
               (long long)n->nt, (long long)cm2_tiles_nt(tiles));
-    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), d_in_tb, d_out_tb,
-                                       as_stream(stream_));
+    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), cm2_tiles_plan_id(tiles),
+                                       d_in_tb, d_out_tb, as_stream(stream_));
 }

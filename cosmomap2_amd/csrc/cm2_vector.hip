@@ -521,6 +521,47 @@ extern "C" int cm2_gemm_atbt(int64_t m, int64_t n, int64_t k, const double *d_A,
     return 0;
 }
 
+// ------------------------------------------- out[c][r] = in[r][c]  (layout change) ---
+// Moves a set of map vectors between "one contiguous vector per column" (what the matvec
+// wants) and the row-major n x r panels the deflation kernels stream (rows x cols in, cols x
+// rows out).  32 x 32 tiles through LDS (33-double pitch), both sides coalesced.
+__global__ __launch_bounds__(256) void k_transpose(int64_t rows, int64_t cols,
+                                                    const double *__restrict__ in,
+                                                    double *__restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int64_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int64_t tid = blockIdx.x; tid < tiles_c * tiles_r; tid += gridDim.x) {
+        const int64_t r0 = (tid / tiles_c) * 32, c0 = (tid % tiles_c) * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + ty + 8 * j, c = c0 + tx;
+            if (r < rows && c < cols) tile[ty + 8 * j][tx] = in[r * cols + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + 8 * j];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int cm2_transpose(int64_t rows, int64_t cols, const double *d_in, double *d_out,
+                             void *stream_)
+{
+    CM2_CHECK(rows >= 0 && cols >= 0, "cm2_transpose: negative size");
+    if (rows == 0 || cols == 0) return 0;
+    CM2_CHECK(d_in && d_out && d_in != d_out, "cm2_transpose: NULL or aliased argument");
+    const int64_t tiles = ((rows + 31) / 32) * ((cols + 31) / 32);
+    const int grid = (int)(tiles < kNumCU * 16 ? tiles : kNumCU * 16);
+    k_transpose<<<grid, kBlock, 0, as_stream(stream_)>>>(rows, cols, d_in, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
 // cos(2 phi), sin(2 phi) of the HWP / polarisation angle (process_ces.py:493-494)
 __global__ __launch_bounds__(256) void k_trig2(int64_t n, const double *__restrict__ phi,
                                                 double *__restrict__ c, double *__restrict__ s)

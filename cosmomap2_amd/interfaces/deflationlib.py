@@ -21,11 +21,34 @@ from ..solvers import _apply
 from ..utilities.linear_algebra_funcs import dgemm
 
 __all__ = ["arnoldi", "build_hess", "build_Z", "run_krypy_arnoldi", "find_ritz_eigenvalues",
-           "ritz_deflation_basis"]
+           "ritz_deflation_basis", "apply_to_columns"]
 
 
 def _norm(v):
     return math.sqrt(D.dot(v, v))
+
+
+def _transpose(mat):
+    """Row-major (rows x cols) tensor in HBM -> its (cols x rows) transpose, by the tiled kernel."""
+    rows, cols = int(mat.shape[0]), int(mat.shape[1])
+    out = D.empty(rows * cols).reshape(cols, rows)
+    _hip.call("cm2_transpose", rows, cols, D.ptr(mat), D.ptr(out), D.stream())
+    return out
+
+
+def apply_to_columns(A, Z):
+    """``A Z`` for a row-major (n x r) matrix in HBM, as the reference builds ``AZ``
+    (src/test_M2_precond_onto_real_data.py:98-101: ``Az[:, i] = A * Z[:, i]``): the panel is
+    transposed once into r contiguous map vectors, ``A`` is applied to each, and the results
+    are transposed back -- two tiled layout kernels instead of 2 r strided column copies."""
+    D.require_gpu()
+    Zd = D.f64(Z)
+    Zt = _transpose(Zd)                                   # r x n: row j = column j of Z
+    r = int(Zt.shape[0])
+    AZt = D.empty(Zt.numel()).reshape(Zt.shape)
+    for j in range(r):
+        AZt[j].copy_(_apply(A, Zt[j]))
+    return _transpose(AZt)
 
 
 def arnoldi(A, b, x0=None, tol=1e-5, maxiter=1000, inner_m=30):
@@ -248,14 +271,13 @@ def ritz_deflation_basis(A, M, x0, r, maxiter):
     Hm = H[:m, :m]
     theta, U = np.linalg.eigh(0.5 * (Hm + Hm.T))
     sel = np.argsort(theta)[:r]
-    Vmat = D.torch.stack(V[:m], dim=1).contiguous()            # n x m, row-major
-    Z = D.empty(n * r).reshape(n, r)
+    # Z = V U_sel: the m basis vectors as a row-major n x m panel, one pass per Ritz vector
+    Vmat = _transpose(D.torch.stack(V[:m], dim=0))             # n x m, row-major
+    Zt = D.empty(r * n).reshape(r, n)
     for jcol, e in enumerate(sel):
-        col = D.empty(n)
         _hip.call("cm2_Z_apply", n, m, D.ptr(Vmat), D.ptr(D.f64(np.ascontiguousarray(U[:, e]))),
-                  D.ptr(col), D.stream())
-        Z[:, jcol] = col
-    return Z, theta[sel]
+                  D.ptr(Zt[jcol]), D.stream())
+    return _transpose(Zt), theta[sel]
 
 
 def find_ritz_eigenvalues(h, v, threshold=1.e-2, eigenvalues=False, filename=None):
@@ -264,11 +286,9 @@ def find_ritz_eigenvalues(h, v, threshold=1.e-2, eigenvalues=False, filename=Non
     ordered by Ritz residual norm) and the selection of the reference
     (deflationlib.py:204-219): ``r`` = number of Ritz values below ``threshold``; returns
     ``(z[:, :r], r)`` or, with ``eigenvalues=True``, ``(z[:, sel], r, eig[sel])``.
-    ``filename`` (HDF5 dump of the Ritz vectors) is outside the scope of this package.
-    PARITY UNPINNED (krypy absent).
+    With ``filename`` ALL Ritz vectors and values are saved first (deflationlib.py:215-216 ->
+    utilities/IOfiles.py:214-238).  PARITY UNPINNED (krypy absent).
     """
-    if filename is not None:
-        raise NotImplementedError("writing Ritz vectors to HDF5 is outside the hot path")
     h = np.asarray(h)
     n = h.shape[1]
     Hn = h[:n, :n]
@@ -281,6 +301,9 @@ def find_ritz_eigenvalues(h, v, threshold=1.e-2, eigenvalues=False, filename=Non
     sel = theta < threshold
     r = int(sel.sum())
     print("Found   %d Ritz eigenvalues smaller than %.1g " % (r, threshold))
+    if filename is not None:
+        from ..utilities.IOfiles import write_ritz_eigenvectors_to_hdf5
+        write_ritz_eigenvectors_to_hdf5(z, filename, eigvals=theta)
     if eigenvalues:
         return z[:, sel], r, theta[sel]
     return z[:, :r], r

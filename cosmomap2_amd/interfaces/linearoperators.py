@@ -14,6 +14,7 @@ at construction; later host-side mutation is not seen.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import scipy.linalg as sla
@@ -184,10 +185,17 @@ class _TileHandle(object):
 
     def __init__(self, handle):
         self.h = handle
-        info = (ctypes.c_int64 * 6)()
+        info = (ctypes.c_int64 * 8)()
         _hip.call("cm2_tiles_info", handle, info)
         self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info[:5]]
         self.half_angle = bool(info[5])
+        self.pt_fixed = bool(info[6])
+        self.plan_id = int(info[7])
+
+    def set_pt_order(self, fixed):
+        """True: P^T sums every pixel in time order (default); False: LDS atomics."""
+        _hip.call("cm2_tiles_set_pt_order", self.h, 1 if fixed else 0)
+        self.pt_fixed = bool(fixed)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -949,12 +957,13 @@ class FilterLO(_DeviceOp):
     def _tile_compatible(self, P):
         """The tile order has no slot for the samples ``P`` flags; the filter may run there only
         if it flags exactly the same samples (the reference passes ``P.pairs``)."""
-        cache = self.__dict__.setdefault("_flag_match", {})
-        if id(P) not in cache:
+        cache = self.__dict__.get("_flag_match")
+        if cache is None or cache[0]() is not P:          # weak reference: an id() can be reused
             a, b = self._d_pix, P._d_pix
-            cache[id(P)] = a.numel() == b.numel() and (
+            ok = a.numel() == b.numel() and (
                 a.data_ptr() == b.data_ptr() or bool(torch.equal(a < 0, b < 0)))
-        return cache[id(P)]
+            cache = self._flag_match = (weakref.ref(P), ok)
+        return cache[1]
 
     def _apply_tiles(self, T, d_in_tb, d_out_tb):
         """Filter a TOD held in the tile-bucketed order ``T``; False if the chunks do not fit

@@ -4,3 +4,4 @@ from .utilities_functions import *                           # noqa: F401,F403
 from .linear_algebra_funcs import *                          # noqa: F401,F403
 from .process_ces import *                                   # noqa: F401,F403
 from .healpy_functions import *                              # noqa: F401,F403
+from .IOfiles import *                                       # noqa: F401,F403

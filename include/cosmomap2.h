@@ -82,19 +82,25 @@ int cm2_PtNP_diag_apply(const cm2_pointing *p, const double *d_x, double *d_out,
  * a2-a3 (throughput form)  Tile-bucketed TOD order
  *   Samples grouped by pixel tile (stable, so time order inside a tile); the tile's
  *   slice of the map is staged in LDS, so P and P^T stream HBM with no random access.
- *   Same loops as above (linearoperators.py:483-489, :509-516); P^T adds with LDS
- *   atomics (term order not fixed: equal to the serial loop to rounding only).
+ *   Same loops as above (linearoperators.py:483-489, :509-516).  P^T by default adds every
+ *   pixel's terms in time order from 0 like the serial loop (one workgroup per tile, per-slice
+ *   lists sorted by (pixel, time), no atomics: bitwise reproducible); cm2_tiles_set_pt_order(t, 0)
+ *   or CM2_PT_ORDER=atomic selects LDS + global fp64 atomics (term order not fixed).
  * ------------------------------------------------------------------------- */
 typedef struct cm2_tiles cm2_tiles;
 int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
                      const double *d_sin, int64_t nt, int64_t npix, int pol, int tile_pixels,
                      int64_t slice_samples, void *stream);
 int cm2_tiles_destroy(cm2_tiles *t);
-/* h_info[0..5] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
+/* h_info[0..7] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
  * 1 if the plan stores one half-angle value per sample instead of cos and sin (done when every
  * (cos, sin) pair is on the unit circle to 1e-14; the kernels rebuild cos = +-(1-h^2)/(1+h^2),
- * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample) */
+ * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample), 1 if P^T sums in
+ * fixed (time) order, the plan's id (unique per plan in this process) */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
+/* fixed != 0: P^T adds each pixel's terms in time order (reference order, reproducible);
+ * fixed == 0: LDS / global atomics */
+int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
 /* d_tod_tb[k] = (P x) for the k-th sample in TB order */
 int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
 /* d_out = P^T v for a TB-ordered v (d_out is overwritten) */
@@ -242,6 +248,10 @@ int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const double *d_Z
  * reference's dgemm(A,B) helper (utilities/linear_algebra_funcs.py:16-29). */
 int cm2_gemm_atbt(int64_t m, int64_t n, int64_t k, const double *d_A, const double *d_B,
                   double *d_C, void *stream);
+/* d_out[c][r] = d_in[r][c] for a row-major rows x cols matrix: layout change between a set of
+ * contiguous map vectors (cols x n) and the row-major n x r panel that DeflationLO streams
+ * (the reference keeps Z as a list of column views, linearoperators.py:1059-1062). */
+int cm2_transpose(int64_t rows, int64_t cols, const double *d_in, double *d_out, void *stream);
 /* out[r] = M[r x r] (row-major) v  -- E^-1 held as an explicit small matrix */
 int cm2_small_matvec(int r, const double *d_M, const double *d_v, double *d_out, void *stream);
 /* fused second half of M2 r = M_BD (r - AZ y) + Z y  given y = E^-1 Z^T r:

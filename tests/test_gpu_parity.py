@@ -104,8 +104,8 @@ def test_pointing_bitexact(cm, oracle, pol, nt, npix):
 @pytest.mark.parametrize("pol", [1, 2, 3])
 @pytest.mark.parametrize("nt,npix,tp", [(300000, 5000, 2048), (50000, 100, 64), (400000, 70000, 1024)])
 def test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles):
-    """Tile-bucketed order: permutations exact, LDS-atomic scatter to rounding, the tiled
-    P^T N P equal to the exact three stages to 1e-13.  The gather is bit-exact when the tile
+    """Tile-bucketed order: permutations exact, fixed-order scatter bit-exact / reproducible,
+    LDS-atomic scatter to rounding, the tiled P^T N P equal to the exact three stages to 1e-13.  The gather is bit-exact when the tile
     plan keeps cos and sin ("full"); in the default half-angle storage (one double per sample,
     cos and sin rebuilt from tan of the half angle) it differs by an ulp or two of the map
     values."""
@@ -146,9 +146,32 @@ def test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles):
     back = D.empty(nt)
     _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(v_tb), D.ptr(back), st)
     np.testing.assert_array_equal(back.cpu().numpy(), np.where(pairs >= 0, v, 0.0))
+    # P^T, default = fixed order: every pixel's terms are added in time order starting from 0,
+    # as in the reference's serial loop.  With both angle arrays that is the oracle's result bit
+    # for bit; with half angles it differs by the rebuilt cos / sin (~2e-16) but is still
+    # bitwise reproducible from run to run.
+    assert T.pt_fixed
     _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
     ref = oracle.sparse_rmult(pol, npix, pairs, c, s, v)
+    fixed = out.cpu().numpy().copy()
+    if angles == "full" or pol == 1:
+        np.testing.assert_array_equal(fixed, ref)
+    else:
+        assert rel_l2(fixed, ref) < 1e-14
+    out.fill_(123.0)                                    # the kernel must overwrite, not add
+    _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+    np.testing.assert_array_equal(out.cpu().numpy(), fixed)
+    # tile ranges (the multi-GPU overlap path) give the same bits
+    out.fill_(-7.0)
+    cuts = [0, T.ntiles // 3, T.ntiles // 3, T.ntiles]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        _hip.call("cm2_Pt_tiles_apply_range", T.h, D.ptr(v_tb), D.ptr(out), lo, hi, st)
+    np.testing.assert_array_equal(out.cpu().numpy(), fixed)
+    # the LDS-atomic form: same terms, unspecified order
+    T.set_pt_order(False)
+    _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
     assert rel_l2(out.cpu().numpy(), ref) < 1e-14
+    T.set_pt_order(True)
     sizes = [nt // 4] * 4
     bands = [np.array([1.0 + 0.2 * b, 0.3, -0.1]) for b in range(4)]
     N = cm.I.BlockLO(sizes, bands, offdiag=True)
@@ -657,6 +680,65 @@ def test_pcg_matches_oracle_iterations_and_solution(cm, oracle, pol, offdiag):
     assert rel_l2(inv * b, xo) < 1e-4 and inv.converged == 0
 
 
+@pytest.mark.parametrize("pol,lam,angles,flags", [(3, 40, "half", 0.03), (3, 40, "full", 0.0),
+                                                  (2, 64, "half", 0.0), (1, 12, "half", 0.05)])
+def test_tiled_path_pcg_iteration_count_equals_oracle(cm, oracle, monkeypatch, pol, lam, angles, flags):
+    """The path bench.py times -- tile-bucketed order, half-angle storage, fixed-order P^T,
+    register-resident overlap-save FFT -- forced with set_pointing_mode("tiled") on a problem
+    the oracle can still run (2^21 samples, direct band sum of `lam` terms): the PCG iteration
+    count must be the oracle's, strictly, the residual history must agree to rounding, and the
+    solution to the north_star's 1e-6 (it agrees to ~1e-11)."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    monkeypatch.setenv("CM2_TILE_ANGLES", angles)
+    nt, npix, nb = 1 << 21, 12 * 32 * 32, 8
+    rng = np.random.default_rng(77 + pol)
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    if flags:
+        pairs[rng.random(nt) < flags] = -1
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.03 * b) * np.where(kk == 0, 1.0, -0.22 * np.exp(-kk / 9.0)) for b in range(nb)]
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    assert n == ro.new_npix and np.array_equal(pairs, po)
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    N = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=3)
+    c, s = ro.cos, ro.sin
+
+    def A_o(x):
+        return oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(
+            nt // nb, bands, True, oracle.sparse_mult(pol, po, c, s, x)))
+    M_o = lambda x: oracle.bd_precond_mult(pol, ro, x)
+    b_o = oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(nt // nb, bands, True, d))
+    L.set_pointing_mode("tiled")
+    try:
+        A = P.T * N * P
+        assert any(isinstance(op, L._TiledNormalLO) for op in A._compiled())
+        T = L._sparse_tiles(P)
+        assert T.pt_fixed and T.half_angle == (angles == "half" and pol > 1)
+        b = P.T * (N * d)
+        assert rel_l2(b, b_o) < 1e-12
+        res_g, res_o = [], []
+        xg, info_g = cm.cg(A, b, M=M, rtol=1e-6, maxiter=300,
+                           callback=lambda x: res_g.append(np.linalg.norm(b - A * x)))
+        xo, info_o = oracle.cg(A_o, b_o, M=M_o, rtol=1e-6, maxiter=300,
+                               callback=lambda x: res_o.append(np.linalg.norm(b_o - A_o(x))))
+        assert info_g == 0 and info_o == 0
+        assert len(res_g) == len(res_o), (len(res_g), len(res_o))        # strictly identical
+        np.testing.assert_allclose(res_g, res_o, rtol=1e-6)
+        assert rel_l2(xg, xo) < 1e-9
+        # not a knife-edge: the last residual is not within 1e-3 (relative) of the threshold
+        thr = 1e-6 * np.linalg.norm(b_o)
+        assert abs(res_o[-1] - thr) > 1e-3 * thr and (len(res_o) < 2 or abs(res_o[-2] - thr) > 1e-3 * thr)
+        # bitwise reproducible from run to run (no atomics anywhere on the path)
+        xg2, _ = cm.cg(A, b, M=M, rtol=1e-6, maxiter=300)
+        np.testing.assert_array_equal(xg2, xg)
+    finally:
+        L.set_pointing_mode("auto")
+
+
 def test_ritz_deflation_basis_speeds_up_pcg(cm, oracle):
     """Arnoldi (M inner product) -> Ritz vectors -> CoarseLO -> fused M2, all in HBM."""
     nt, npix, nb, pol = 60000, 400, 4, 3
@@ -690,11 +772,65 @@ def test_ritz_deflation_basis_speeds_up_pcg(cm, oracle):
     n1, n2 = [], []
     x1, i1 = cm.cg(A, b, M=M, rtol=1e-8, maxiter=2000, callback=lambda xk: n1.append(1))
     x2, i2 = cm.cg(A, b, M=M2, rtol=1e-8, maxiter=2000, callback=lambda xk: n2.append(1))
+    # With the reference generator's uniformly random pointing, M_BD A has ONE small eigenvalue
+    # (the constant I map, the only map the DC-suppressing band sees as a slow time-domain mode:
+    # 0.62 against a cluster at 23..25.4, dense eigen-decomposition of the oracle's operators).
+    # CG disposes of one isolated eigenvalue in about one step and M2 moves the deflated ones to
+    # 1, still outside the cluster, so both preconditioners need the same number of steps here.
     assert i1 == 0 and i2 == 0 and len(n2) <= len(n1)
     assert float((x2 - x1).norm() / x1.norm()) < 1e-6
     for j in range(r):                                    # deflated directions are solved exactly
         zj = Z[:, j].contiguous()
         assert float(((M2 * (A * zj)) - zj).norm() / zj.norm()) < 1e-8
+
+
+def test_ritz_deflation_on_raster_scan_needs_fewer_iterations(cm, oracle):
+    """What the two-level preconditioner is for: with a coherent scan the slow time-domain modes
+    the 1/f band suppresses ARE smooth maps, M_BD A has a tail of small eigenvalues and deflating
+    them pays (dense check on the oracle's operators for this problem: 48 PCG steps with M_BD, 33
+    with the 8 smallest eigenvectors deflated).  Strictly fewer iterations, same solution."""
+    nt, npix, nb, pol, dwell = 60000, 400, 4, 3, 5
+    rng = np.random.default_rng(8)
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    tt = np.arange(nt)
+    sweep, col = (tt // dwell) // npix, (tt // dwell) % npix
+    pairs = np.where(sweep % 2 == 0, col, npix - 1 - col).astype(np.int32)
+    lam = 64
+    k = np.arange(lam)
+    band = 0.6 * np.exp(-k / 20.0)
+    band[0] = 1.0 + 2 * band[1:].sum() * 0.98
+    band[1:] *= -1.0
+    bands = [band * (1 + 0.05 * b) for b in range(nb)]
+    N = cm.I.BlockLO(nt // nb, bands, offdiag=True)
+    po = pairs.copy()
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    A = P.T * N * P
+    b = cm.torch.from_numpy(P.T * (N * d)).cuda()
+    r = 8
+    Z, theta = cm.I.ritz_deflation_basis(A, M, b, r, 60)
+    AZ = cm.torch.empty_like(Z)
+    for j in range(r):
+        AZ[:, j] = A * Z[:, j].contiguous()
+    E = cm.I.CoarseLO(Z, AZ, r, apply='eig')
+    M2 = cm.I.TwoLevelPreconditionerLO(M, cm.I.DeflationLO(Z), cm.I.DeflationLO(AZ), E)
+    n1, n2, no = [], [], []
+    x1, i1 = cm.cg(A, b, M=M, rtol=1e-8, maxiter=2000, callback=lambda xk: n1.append(1))
+    x2, i2 = cm.cg(A, b, M=M2, rtol=1e-8, maxiter=2000, callback=lambda xk: n2.append(1))
+
+    def A_o(v):
+        return oracle.sparse_rmult(pol, n, po, ro.cos, ro.sin, oracle.blocklo_mult(
+            nt // nb, bands, True, oracle.sparse_mult(pol, po, ro.cos, ro.sin, v)))
+    xo, io = oracle.cg(A_o, b.cpu().numpy(), M=lambda v: oracle.bd_precond_mult(pol, ro, v),
+                       rtol=1e-8, maxiter=2000, callback=lambda xk: no.append(1))
+    assert i1 == 0 and i2 == 0 and io == 0
+    assert len(n1) == len(no)                              # M_BD: the oracle's count, strictly
+    assert len(n2) < len(n1) and len(n2) <= 0.8 * len(n1), (len(n1), len(n2))
+    assert float((x2 - x1).norm() / x1.norm()) < 1e-6
+    assert rel_l2(x1.cpu().numpy(), xo) < 1e-6
 
 
 # ------------------------------------------------------- a12 two-level precond ---
@@ -749,13 +885,30 @@ def test_two_level_preconditioner_invariants(cm, pol):
         assert len(its) == 1                          # tests/test_arnoldi_algorithm.py:91-93
     rr = np.random.rand(pol * npix)
     assert rel_l2(M2f * rr, M2 * rr) < 1e-10
-    # the deflated preconditioner must not need more PCG steps than M_BD alone
+    # PCG with M_BD and with M2: the counts must be those of the same recurrence run on the CPU
+    # with dense copies of the operators (the oracle's PCG), strictly.
     b = P.T * N * d
-    n1, n2 = [], []
+    n1, n2, o1, o2 = [], [], [], []
     x1, i1 = cm.cg(A, b, M=M, tol=1e-8, callback=lambda xk: n1.append(1))
     x2, i2 = cm.cg(A, b, M=M2f, tol=1e-8, callback=lambda xk: n2.append(1))
-    assert i1 == 0 and i2 == 0 and len(n2) <= len(n1) + 1
+    Ad, Md, M2d = A.to_array(), M.to_array(), M2f.to_array()
+    from oracle import oracle as orc
+    orc.cg(lambda v: Ad.dot(v), b, rtol=1e-8, M=lambda v: Md.dot(v), callback=lambda xk: o1.append(1))
+    orc.cg(lambda v: Ad.dot(v), b, rtol=1e-8, M=lambda v: M2d.dot(v), callback=lambda xk: o2.append(1))
+    assert i1 == 0 and i2 == 0 and len(n1) == len(o1) and len(n2) == len(o2)
     assert rel_l2(x2, x1) < 1e-6
+    # M2 maps the deflated eigenvalues of M_BD A to exactly 1.  That helps when they are the
+    # SMALL end of the spectrum and 1 lies inside or above the rest; it does not when the whole
+    # spectrum of M_BD A lies above 1, as for the reference's test problem with pol = 2 (band
+    # diagonal 1 + 0.5 u > 1, no hit-count normalisation of the QU block: spectrum in
+    # [1.43, 1.56], M2 adds an eigenvalue at 1.0 and the condition number goes from 1.09 to 1.56;
+    # the CPU recurrence needs 6 steps against 5 as well).  So "M2 never needs more steps" is
+    # asserted exactly where the theory gives it.
+    lam_mbd = np.sort(np.linalg.eigvals(Md.dot(Ad)).real)
+    if lam_mbd[r - 1] <= 1.0 <= lam_mbd[-1]:
+        assert len(n2) <= len(n1), (len(n1), len(n2))
+    else:
+        assert lam_mbd[0] > 1.0 and len(n2) <= len(n1) + 1, (lam_mbd[0], len(n1), len(n2))
 
 
 # ------------------------------------------------------------- f1: FilterLO -------
@@ -987,7 +1140,7 @@ def test_pcg_with_filter_as_noise_operator(cm, oracle):
         xo, info_o = oracle.cg(A_o, b, M=lambda v: oracle.bd_precond_mult(pol, ro, v), rtol=1e-8,
                                maxiter=200, callback=lambda xk: itso.append(1))
         assert info == 0 and info_o == 0
-        assert abs(len(its) - len(itso)) <= 1, (len(its), len(itso))
+        assert len(its) == len(itso), (len(its), len(itso))    # identical iteration counts
         assert rel_l2(A * xs, b) < 1e-7
 
 
@@ -1019,22 +1172,22 @@ def test_overlap_save_on_tile_order_list_modes(cm, oracle, monkeypatch, mode, tp
     assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12
 
 
-def test_full_size_properties_c4(cm):
-    """BASELINE config C4 at full size (nside 256 IQU, 1e8 samples, 100 Toeplitz blocks with
-    lambda = 2048, generated in HBM).  No oracle run at this size (the direct band sum is
-    2e11 multiply-adds per matvec on one core); instead: the tile-order chain with the LDS
-    FFT against the time-order chain built from independent pieces (exact pixel-major P^T,
-    rocFFT overlap-save), symmetry, positivity, linearity, and the zero boundary between
-    noise blocks."""
+def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
+    """Size-independent properties of P^T N^-1 P at a BASELINE configuration's full size
+    (generated in HBM).  No oracle run at this size (the direct band sum is 2e11 multiply-adds
+    per matvec on one core); instead: the tile-order chain with the register FFT against the
+    time-order chain built from independent pieces (exact pixel-major P^T, rocFFT overlap-save),
+    symmetry, positivity, linearity, run-to-run bit reproducibility, the zero boundary between
+    noise blocks, and a PCG solve with M_BD checked through its true residual."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import toeplitz_band
     from cosmomap2_amd.interfaces import linearoperators as L
     from cosmomap2_amd import device as D
     t = cm.torch
-    nside, nt, nb, pol, lam = 256, 100_000_000, 100, 3, 2048
+    pol, lam = 3, 2048
     npix = 12 * nside * nside
-    g = t.Generator(device="cuda").manual_seed(20161204)
+    g = t.Generator(device="cuda").manual_seed(seed)
     pix = t.randint(0, npix, (nt,), generator=g, device="cuda", dtype=t.int32)
     phi = 0.3 + (2 * np.pi * 2.5 / 200.0) * t.arange(nt, device="cuda", dtype=t.float64)
     rng = np.random.default_rng(11)
@@ -1044,13 +1197,14 @@ def test_full_size_properties_c4(cm):
     n = ces.get_new_pixel[0]
     assert n == npix
     P = cm.I.SparseLO(n, nt, pix, pol=pol, angle_processed=ces)
-    Nf = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=3)       # LDS FFT
+    Nf = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=3)       # register / LDS FFT
     Nr = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=2)       # rocFFT
     x = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
     y = t.rand(pol * n, generator=g, device="cuda", dtype=t.float64) - 0.5
     A = P.T * Nf * P
-    assert L._use_tiles(P)
+    assert L._use_tiles(P) and L._sparse_tiles(P).pt_fixed
     Ax = A * x
+    assert t.equal(A * x, Ax)                             # fixed-order P^T: same bits every run
     exact = P.T * (Nr * (P * x))
     assert float((Ax - exact).norm() / exact.norm()) < 1e-12
     Ay = A * y
@@ -1071,6 +1225,51 @@ def test_full_size_properties_c4(cm):
         np.testing.assert_allclose(r[bs:bs + lam].cpu().numpy(), bands[1], rtol=0,
                                    atol=1e-12 * abs(bands[1][0]))
         assert float(r[bs + lam:bs + 3 * lam].abs().max()) < 1e-12 * abs(bands[1][0])
+    del e, r, Nr
+    # PCG to the metric's 1e-6 with M_BD: converged, true residual at the tolerance, and the
+    # count reproducible (the bench prints this number for its own seed)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    d = t.rand(nt, generator=g, device="cuda", dtype=t.float64)
+    b = P.T * (Nf * d)
+    del d
+    its = []
+    xs, info = cm.cg(A, b, M=M, rtol=1e-6, maxiter=200, callback=lambda v: its.append(1))
+    assert info == 0 and 2 <= len(its) <= 30
+    true_res = float((b - A * xs).norm() / b.norm())
+    assert true_res < 2e-6, true_res
+    its_b = []
+    xs_b, _ = cm.cg(A, b, M=M, rtol=1e-6, maxiter=200, callback=lambda v: its_b.append(1))
+    assert len(its_b) == len(its) and t.equal(xs_b, xs)
+    if two_level_rank:
+        # BASELINE C4: two-level preconditioner, Arnoldi-built deflation space of dimension 32;
+        # its solution must be the M_BD one (1e-6) in no more iterations
+        r = two_level_rank
+        Z, theta = cm.I.ritz_deflation_basis(A, M, b, r, 96)
+        AZ = cm.I.apply_to_columns(A, Z)
+        E = cm.I.CoarseLO(Z, AZ, r, apply='eig')
+        M2 = cm.I.TwoLevelPreconditionerLO(M, cm.I.DeflationLO(Z), cm.I.DeflationLO(AZ), E)
+        its2 = []
+        x2, info2 = cm.cg(A, b, M=M2, rtol=1e-6, maxiter=200, callback=lambda v: its2.append(1))
+        assert info2 == 0 and len(its2) <= len(its), (len(its2), len(its))
+        assert float((x2 - xs).norm() / xs.norm()) < 1e-6
+        assert float((b - A * x2).norm() / b.norm()) < 2e-6
+
+
+def test_full_size_properties_c3(cm):
+    """BASELINE config C3: nside 128 IQU, 1e8 samples, Toeplitz lambda 2048 (100 blocks)."""
+    _full_size_toeplitz_properties(cm, 128, 100_000_000, 100, 20161205)
+
+
+def test_full_size_properties_c4(cm):
+    """BASELINE config C4 (one GPU's 1e8 samples): nside 256 IQU, lambda 2048, two-level
+    preconditioner with an Arnoldi-built deflation space of dimension 32."""
+    _full_size_toeplitz_properties(cm, 256, 100_000_000, 100, 20161204, two_level_rank=32)
+
+
+def test_full_size_properties_c5_share(cm):
+    """One GPU's share of BASELINE config C5: nside 512 IQU, 1.25e8 samples = 8 detector blocks
+    of 15 625 000, lambda 2048."""
+    _full_size_toeplitz_properties(cm, 512, 125_000_000, 8, 20161206)
 
 
 def test_config_c1_reference_runnable_case(cm, oracle):
@@ -1200,7 +1399,7 @@ def test_reference_api_surface(cm, oracle):
 
 
 def test_throughput_path_equals_exact_path_end_to_end(cm):
-    """The whole solve on the throughput path (tile order, half-angle storage, LDS atomics,
+    """The whole solve on the throughput path (tile order, half-angle storage, fixed-order P^T,
     register-resident FFT) against the exact path (time order, fixed-order P^T, direct band
     sum = the oracle's arithmetic): same PCG iteration count, maps equal far below the
     north_star's 1e-6."""
@@ -1233,7 +1432,7 @@ def test_throughput_path_equals_exact_path_end_to_end(cm):
         finally:
             L.set_pointing_mode("auto")
     (xe, ie), (xt, it) = sols["exact"], sols["tiled"]
-    assert abs(ie - it) <= 1, (ie, it)
+    assert ie == it, (ie, it)
     assert float((xt - xe).norm() / xe.norm()) < 1e-8
 
 

@@ -1,0 +1,183 @@
+"""
+CPU tests of the file formats either side of the solve: the pure-Python
+HDF5 subset (cosmomap2_amd/utilities/hdf5_lite.py) against files the reference's h5py code
+wrote, the CES readers and the Ritz-vector checkpoint.  No GPU: NumPy arrays only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def U():
+    import cosmomap2_amd.utilities as U
+    return U
+
+
+@pytest.mark.parametrize("case", [3, 4])
+def test_reader_on_the_reference_data_files(U, case):
+    """data/testcase_block_diag_{3,4}.hdf5 of the reference (h5py, big-endian datasets) through
+    the reader, against the arrays an independent minimal parser extracted from them
+    (tests/golden/make_hdf5_fixtures.py)."""
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    ref = np.load(os.path.join(GOLD, "reference_inputs.npz"))
+    path = os.path.join(GOLD, "testcase_block_diag_%d.hdf5" % case)
+    f = h5.read_file(path)
+    assert list(f) == ["bolo_pair"] and sorted(f["bolo_pair"]) == ["pixel", "pol_angle", "sum", "weight"]
+    for key in ("pixel", "pol_angle", "sum", "weight"):
+        want = ref["case%d_%s" % (case, key)]
+        got = f["bolo_pair"][key]
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+    det, pix, phi, w = U.read_from_hdf5(path)                 # IOfiles.py:317-330 return order
+    np.testing.assert_array_equal(det, ref["case%d_sum" % case])
+    np.testing.assert_array_equal(pix, ref["case%d_pixel" % case])
+    np.testing.assert_array_equal(phi, ref["case%d_pol_angle" % case])
+    np.testing.assert_array_equal(w, ref["case%d_weight" % case])
+
+
+def test_write_to_hdf5_reproduces_the_reference_files_content(U, tmp_path):
+    """write_to_hdf5 (IOfiles.py:277-300) followed by the reader gives back the inputs; the
+    datasets are stored big-endian like the reference's, and the object headers carry the same
+    messages as the h5py-written file (dataspace, datatype, fill value, layout)."""
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    ref = np.load(os.path.join(GOLD, "reference_inputs.npz"))
+    p = str(tmp_path / "t.hdf5")
+    U.write_to_hdf5(p, ref["case3_pixel"], ref["case3_weight"], ref["case3_sum"], phi=ref["case3_pol_angle"])
+    det, pix, phi, w = U.read_from_hdf5(p)
+    np.testing.assert_array_equal(det, ref["case3_sum"])
+    np.testing.assert_array_equal(pix, ref["case3_pixel"])
+    np.testing.assert_array_equal(phi, ref["case3_pol_angle"])
+    np.testing.assert_array_equal(w, ref["case3_weight"])
+
+    def dataset_messages(path, name):
+        data = open(path, "rb").read()
+        R = h5._Reader(data)
+        for t, q, s in R.messages(R.root_header):
+            if t == 0x11:
+                (g, ga), = R.group_entries(R.u64(q), R.u64(q + 8))
+        for t, q, s in R.messages(ga):
+            if t == 0x11:
+                ents = dict(R.group_entries(R.u64(q), R.u64(q + 8)))
+        return {t: data[q:q + s] for t, q, s in R.messages(ents[name])}
+    theirs = dataset_messages(os.path.join(GOLD, "testcase_block_diag_3.hdf5"), "pixel")
+    ours = dataset_messages(p, "pixel")
+    assert ours[0x03] == theirs[0x03]                         # datatype message: STD_I32BE
+    assert ours[0x05] == theirs[0x05]                         # fill-value message
+    assert ours[0x08][:2] == theirs[0x08][:2] == b"\x03\x01"  # layout v3, contiguous
+    assert dataset_messages(p, "sum")[0x03] == dataset_messages(
+        os.path.join(GOLD, "testcase_block_diag_3.hdf5"), "sum")[0x03]     # IEEE_F64BE
+
+
+def test_hdf5_lite_round_trip_groups_scalars_and_many_links(tmp_path):
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    rng = np.random.default_rng(0)
+    tree = {"a": rng.standard_normal((7, 3)), "n": np.array(5, dtype=">i4"),
+            "empty": np.zeros(0), "f4": rng.standard_normal(9).astype("<f4"),
+            "u": np.arange(4, dtype="<u8"),
+            "g": {"h": {"x": np.arange(6, dtype=">i4").reshape(2, 3)}},
+            "many": {"bolo_pair_%d" % i: {"pixel": np.arange(i + 1, dtype=">i4")} for i in range(200)}}
+    p = str(tmp_path / "rt.h5")
+    h5.write_file(p, tree)
+    g = h5.read_file(p)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            assert sorted(a) == sorted(b)
+            for k in a:
+                same(a[k], b[k])
+        else:
+            assert a.shape == np.asarray(b).shape and a.dtype == np.asarray(b).dtype.newbyteorder("=")
+            np.testing.assert_array_equal(a, b)
+    same(g, tree)
+    with pytest.raises(h5.Hdf5FormatError):
+        h5._Reader(b"not an hdf5 file at all")
+    with pytest.raises(h5.Hdf5FormatError):
+        h5.write_file(str(tmp_path / "bad.h5"), {"s": np.array(["text"])})
+
+
+def _write_ces(path, rng, npairs, ns, sub_n, sub_t, npix):
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    tree = {"obspix": np.arange(100, 100 + npix, dtype=">i4"),
+            "n_bolo_pair": np.array(npairs, dtype=">i4"), "n_sample_ces": np.array(ns, dtype=">i4"),
+            "subscans": {"n_sample": np.asarray(sub_n, dtype=">i4"), "t_start": np.asarray(sub_t, dtype=">i4")}}
+    for i in range(npairs):
+        tree["bolo_pair_%d" % i] = {
+            "pixel": rng.integers(0, npix, ns).astype(">i4"), "pol_angle": rng.random(ns).astype(">f8"),
+            "ground": rng.integers(0, 20, ns).astype(">f8"), "sum": rng.random(ns).astype(">f8"),
+            "dif": rng.random(ns).astype(">f8"), "weight_sum": np.array(1.0 + i, dtype=">f8"),
+            "weight_dif": np.array(2.0 + i, dtype=">f8")}
+    h5.write_file(path, tree)
+    return tree
+
+
+def test_ces_readers(U, tmp_path):
+    """read_from_data / read_from_data_with_subscan_resize / read_multiple_ces
+    (IOfiles.py:18-210) on two synthetic scans in the AnalysisBackend layout."""
+    rng = np.random.default_rng(3)
+    ns, npairs, npix = 120, 3, 30
+    sub_n, sub_t = [30, 40, 25], [5, 40, 90]
+    paths, trees = [], []
+    for k in range(2):
+        p = str(tmp_path / ("ces%d.hdf5" % k))
+        trees.append(_write_ces(p, rng, npairs, ns, sub_n, sub_t, npix))
+        paths.append(p)
+    d, w, phi, pix, hp, ground, n_ces = U.read_from_data(paths[0], 3)
+    assert n_ces == ns and d.shape == (npairs * ns,) and w.tolist() == [2.0, 3.0, 4.0]
+    np.testing.assert_array_equal(d[ns:2 * ns], trees[0]["bolo_pair_1"]["dif"])
+    np.testing.assert_array_equal(pix[:ns], trees[0]["bolo_pair_0"]["pixel"])
+    np.testing.assert_array_equal(hp, np.arange(100, 130))
+    assert ground.dtype.kind == "i"
+    d1, w1 = U.read_from_data(paths[0], 1, npairs=2)[:2]
+    assert d1.shape == (2 * ns,) and w1.tolist() == [1.0, 2.0]
+    np.testing.assert_array_equal(d1[:ns], trees[0]["bolo_pair_0"]["sum"])
+    out = U.read_from_data_with_subscan_resize(paths[0], 2)
+    pr = out[3][:ns]
+    keep = np.zeros(ns, dtype=bool)
+    for t, n in zip(sub_t, sub_n):
+        keep[t:t + n] = True
+    keep[sub_t[-1] + sub_n[-1]:] = True            # the reference leaves the tail unflagged (:149-155)
+    np.testing.assert_array_equal(pr[~keep], -1)
+    np.testing.assert_array_equal(pr[keep], np.asarray(trees[0]["bolo_pair_0"]["pixel"])[keep])
+    assert out[7] == npairs and out[8][0].tolist() == sub_n and out[8][1].tolist() == sub_t
+    res = U.read_multiple_ces(paths, 3)
+    assert len(res) == 10 and res[0].shape == (2 * npairs * ns,) and res[1].shape == (2 * npairs,)
+    assert res[8] == [ns, ns] and res[9] == [npairs, npairs]
+    assert [s.tolist() for s in res[6]] == [sub_n, sub_n] and [s.tolist() for s in res[7]] == [sub_t, sub_t]
+    res2 = U.read_multiple_ces(paths, 1, filtersubscan=False)
+    assert len(res2) == 8 and res2[0].shape == (2 * npairs * ns,)
+    a, b = np.array([1, 2, 3, 4]), np.array([2, 3, 4, 5])
+    U.flagging_not_in_allCES([a, b])
+    assert a.tolist() == [-1, 2, 3, 4] and b.tolist() == [2, 3, 4, -1]
+
+
+def test_ritz_checkpoint_and_map_lists(U, tmp_path):
+    """write_ritz_eigenvectors_to_hdf5 / read_ritz_eigenvectors_from_hdf5 (IOfiles.py:214-256):
+    reference dataset names, values back bit for bit; save_maplist / read_maplist (:351-375);
+    obspix (:258-275)."""
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    rng = np.random.default_rng(5)
+    z, ev = rng.standard_normal((301, 6)), np.sort(rng.random(6))
+    p = str(tmp_path / "ritz.hdf5")
+    U.write_ritz_eigenvectors_to_hdf5(z, p, eigvals=ev)
+    f = h5.read_file(p)
+    assert sorted(f) == ["Ritz_eigenvalues", "Ritz_eigenvectors"]
+    assert sorted(f["Ritz_eigenvectors"]) == ["Eigenvectors", "n_eigenvectors"]
+    z2, n2, ev2 = U.read_ritz_eigenvectors_from_hdf5(p, eigvals=True)
+    np.testing.assert_array_equal(z2, z)
+    np.testing.assert_array_equal(ev2, ev)
+    assert int(n2) == 6
+    assert len(U.read_ritz_eigenvectors_from_hdf5(p)) == 2
+    fn = U.write_ritz_eigenvectors(z, str(tmp_path / "ck"))
+    assert fn.endswith("ck.hdf5")
+    np.testing.assert_array_equal(U.read_ritz_eigenvectors(str(tmp_path / "ck")), z)
+    maps = [rng.standard_normal(12), rng.standard_normal(12)]
+    U.save_maplist(maps, str(tmp_path / "maps.h5"))
+    got, n = U.read_maplist(str(tmp_path / "maps.h5"))
+    assert n == 2 and all(np.array_equal(a, b) for a, b in zip(got, maps))
+    U.write_obspix_to_hdf5(str(tmp_path / "o.h5"), np.array([5, 9, 11]))
+    assert U.read_obspix_from_hdf5(str(tmp_path / "o.h5")).tolist() == [5, 9, 11]
