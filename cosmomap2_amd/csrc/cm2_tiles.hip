@@ -301,6 +301,13 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
 // 4 B + half angle 8 B (both in sorted order) = 20 B, all 16-B-per-lane style streams; the next
 // slice is fetched into registers while the current one is reduced.
 constexpr int kFxT = 512;
+constexpr int kFxDepth = 3;            // slices fetched ahead of the one being reduced
+
+// LDS pitch of the sorted-order arrays: entry i of the slice sits at (i % PER) * pitch + i / PER,
+// so that thread t finds its chunk [t PER, (t+1) PER) at m * pitch + t (consecutive lanes,
+// consecutive addresses) and the coalesced staging stores (lane = entry) spread over all banks
+__host__ __device__ constexpr int fx_pitch_f64() { return kFxT + 4; }
+__host__ __device__ constexpr int fx_pitch_u32() { return kFxT + 8; }
 
 template <int POL, bool HALF, int PER>
 __global__ __launch_bounds__(kFxT) void k_Pt_tiles_fixed(
@@ -308,14 +315,16 @@ __global__ __launch_bounds__(kFxT) void k_Pt_tiles_fixed(
     const uint32_t *__restrict__ ent, const double *__restrict__ fa,
     const double *__restrict__ fb, const double *__restrict__ v_tb, double *__restrict__ out)
 {
-    constexpr int S = PER * kFxT;
+    constexpr int S = PER * kFxT, D = kFxDepth;
+    constexpr int LOGPER = PER == 1 ? 0 : (PER == 2 ? 1 : (PER == 4 ? 2 : 3));
+    constexpr int PF = fx_pitch_f64(), PU = fx_pitch_u32();
     constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
     extern __shared__ double sm[];
     double *tile = sm;                                   // tp * POL accumulators
     double *vbuf = sm + (int64_t)tp * POL;               // S values, TB order
-    double *abuf = vbuf + S;                             // S half angles (or cos), sorted order
-    double *bbuf = abuf + (ANG ? S : 0);                 // S sin (full-angle mode)
-    uint32_t *ebuf = reinterpret_cast<uint32_t *>(bbuf + (TWO ? S : 0));
+    double *abuf = vbuf + S;                             // PER * PF half angles (or cos), sorted order
+    double *bbuf = abuf + (ANG ? PER * PF : 0);          // PER * PF sin (full-angle mode)
+    uint32_t *ebuf = reinterpret_cast<uint32_t *>(bbuf + (TWO ? PER * PF : 0));   // PER * PU
     const int tid = threadIdx.x;
     const int b = tile0 + blockIdx.x;
     const int64_t p0 = (int64_t)b * tp;
@@ -326,107 +335,119 @@ __global__ __launch_bounds__(kFxT) void k_Pt_tiles_fixed(
     const int64_t k_begin = tile_off[b], k_end = tile_off[b + 1];
     const int nsl = (int)((k_end - k_begin + S - 1) / S);
 
-    double pv[PER], pa[PER], pb[PER];
-    uint32_t pe[PER];
-    auto fetch = [&](int64_t kb, int len) {
+    // register ring: slice j lives in slot j % D from the moment slice j - D has been staged
+    double pv[D][PER], pa[D][PER], pb[D][PER];
+    uint32_t pe[D][PER];
+    auto fetch = [&](int slot, int j) {
+        if (j >= nsl) return;
+        const int64_t kb = k_begin + (int64_t)j * S;
+        const int len = (int)((k_end - kb < S) ? k_end - kb : S);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int i = tid + u * kFxT;
             if (i < len) {
-                pv[u] = v_tb[kb + i];
-                pe[u] = ent[kb + i];
-                if (ANG) pa[u] = fa[kb + i];
-                if (TWO) pb[u] = fb[kb + i];
+                pv[slot][u] = v_tb[kb + i];
+                pe[slot][u] = ent[kb + i];
+                if (ANG) pa[slot][u] = fa[kb + i];
+                if (TWO) pb[slot][u] = fb[kb + i];
             }
         }
     };
-    if (nsl > 0) fetch(k_begin, (int)((k_end - k_begin < S) ? k_end - k_begin : S));
-    for (int j = 0; j < nsl; ++j) {
-        const int64_t kb = k_begin + (int64_t)j * S;
-        const int len = (int)((k_end - kb < S) ? k_end - kb : S);
-        __syncthreads();                      // the previous slice is reduced (j = 0: tile zeroed)
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = tid + u * kFxT;
-            if (i < len) {
-                vbuf[i] = pv[u];
-                ebuf[i] = pe[u];
-                if (ANG) abuf[i] = pa[u];
-                if (TWO) bbuf[i] = pb[u];
+    for (int dd = 0; dd < D; ++dd) fetch(dd, dd);
+    constexpr uint32_t QM = HALF ? 0x7FFFu : 0xFFFFu;
+    auto EU = [](int i) { return (i & (PER - 1)) * PU + (i >> LOGPER); };
+    auto EF = [](int i) { return (i & (PER - 1)) * PF + (i >> LOGPER); };
+    for (int jj = 0; jj < nsl; jj += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const int j = jj + dd;
+            if (j >= nsl) break;
+            const int64_t kb = k_begin + (int64_t)j * S;
+            const int len = (int)((k_end - kb < S) ? k_end - kb : S);
+            __syncthreads();                  // the previous slice is reduced (j = 0: tile zeroed)
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = tid + u * kFxT;
+                if (i < len) {
+                    vbuf[i] = pv[dd][u];
+                    ebuf[EU(i)] = pe[dd][u];
+                    if (ANG) abuf[EF(i)] = pa[dd][u];
+                    if (TWO) bbuf[EF(i)] = pb[dd][u];
+                }
             }
-        }
-        __syncthreads();
-        if (j + 1 < nsl) fetch(kb + S, (int)((k_end - kb - S < S) ? k_end - kb - S : S));
-        const int e0 = tid * PER;
-        int e1 = e0 + PER;
-        if (e1 > len) e1 = len;
-        constexpr uint32_t QM = HALF ? 0x7FFFu : 0xFFFFu;
-        int i = e0;
-        if (e0 > 0 && e0 < len) {
-            const uint32_t qprev = ebuf[e0 - 1] & QM;
-            while (i < e1 && (ebuf[i] & QM) == qprev) ++i;
-        }
-        int cur = -1;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        while (i < len) {
-            const uint32_t w = ebuf[i];
-            const int q = (int)(w & QM);
-            if (q != cur) {
-                if (i >= e1) break;                       // the next run belongs to another thread
-                if (cur >= 0) {
+            __syncthreads();
+            fetch(dd, j + D);
+            const int e0 = tid * PER;
+            int e1 = e0 + PER;
+            if (e1 > len) e1 = len;
+            int i = e0;
+            if (e0 > 0 && e0 < len) {
+                const uint32_t qprev = ebuf[EU(e0 - 1)] & QM;
+                while (i < e1 && (ebuf[EU(i)] & QM) == qprev) ++i;
+            }
+            int cur = -1;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            while (i < len) {
+                const uint32_t w = ebuf[EU(i)];
+                const int q = (int)(w & QM);
+                if (q != cur) {
+                    if (i >= e1) break;                   // the next run belongs to another thread
+                    if (cur >= 0) {
+                        if (POL == 1) {
+                            tile[cur] = a0;
+                        } else if (POL == 2) {
+                            tile[2 * cur] = a1;
+                            tile[2 * cur + 1] = a2;
+                        } else {
+                            tile[3 * cur] = a0;
+                            tile[3 * cur + 1] = a1;
+                            tile[3 * cur + 2] = a2;
+                        }
+                    }
+                    cur = q;
                     if (POL == 1) {
-                        tile[cur] = a0;
+                        a0 = tile[q];
                     } else if (POL == 2) {
-                        tile[2 * cur] = a1;
-                        tile[2 * cur + 1] = a2;
+                        a1 = tile[2 * q];
+                        a2 = tile[2 * q + 1];
                     } else {
-                        tile[3 * cur] = a0;
-                        tile[3 * cur + 1] = a1;
-                        tile[3 * cur + 2] = a2;
+                        a0 = tile[3 * q];
+                        a1 = tile[3 * q + 1];
+                        a2 = tile[3 * q + 2];
                     }
                 }
-                cur = q;
+                const double v = vbuf[w >> 16];
                 if (POL == 1) {
-                    a0 = tile[q];
+                    a0 += v;
+                } else {
+                    double cc, ss;
+                    if (HALF) {
+                        const double h = abuf[EF(i)], h2 = h * h, inv = 1.0 / (1.0 + h2);
+                        cc = (1.0 - h2) * inv;
+                        ss = (h + h) * inv;
+                        if (w & 0x8000u) cc = -cc;
+                    } else {
+                        cc = abuf[EF(i)];
+                        ss = bbuf[EF(i)];
+                    }
+                    if (POL == 3) a0 += v;
+                    a1 += v * cc;
+                    a2 += v * ss;
+                }
+                ++i;
+            }
+            if (cur >= 0) {
+                if (POL == 1) {
+                    tile[cur] = a0;
                 } else if (POL == 2) {
-                    a1 = tile[2 * q];
-                    a2 = tile[2 * q + 1];
+                    tile[2 * cur] = a1;
+                    tile[2 * cur + 1] = a2;
                 } else {
-                    a0 = tile[3 * q];
-                    a1 = tile[3 * q + 1];
-                    a2 = tile[3 * q + 2];
+                    tile[3 * cur] = a0;
+                    tile[3 * cur + 1] = a1;
+                    tile[3 * cur + 2] = a2;
                 }
-            }
-            const double v = vbuf[w >> 16];
-            if (POL == 1) {
-                a0 += v;
-            } else {
-                double cc, ss;
-                if (HALF) {
-                    const double h = abuf[i], h2 = h * h, inv = 1.0 / (1.0 + h2);
-                    cc = (1.0 - h2) * inv;
-                    ss = (h + h) * inv;
-                    if (w & 0x8000u) cc = -cc;
-                } else {
-                    cc = abuf[i];
-                    ss = bbuf[i];
-                }
-                if (POL == 3) a0 += v;
-                a1 += v * cc;
-                a2 += v * ss;
-            }
-            ++i;
-        }
-        if (cur >= 0) {
-            if (POL == 1) {
-                tile[cur] = a0;
-            } else if (POL == 2) {
-                tile[2 * cur] = a1;
-                tile[2 * cur + 1] = a2;
-            } else {
-                tile[3 * cur] = a0;
-                tile[3 * cur + 1] = a1;
-                tile[3 * cur + 2] = a2;
             }
         }
     }
@@ -761,8 +782,10 @@ extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid :
 // ---- fixed-order P^T: plan (built on first use) and launch ----
 static size_t fx_lds_bytes(const cm2_tiles *t, int S)
 {
-    size_t b = sizeof(double) * (size_t)t->tp * t->pol + sizeof(double) * S + sizeof(uint32_t) * S;
-    if (t->pol > 1) b += sizeof(double) * S * (t->half ? 1 : 2);
+    const size_t per = (size_t)(S / kFxT);
+    size_t b = sizeof(double) * (size_t)t->tp * t->pol + sizeof(double) * S +
+               sizeof(uint32_t) * per * fx_pitch_u32();
+    if (t->pol > 1) b += sizeof(double) * per * fx_pitch_f64() * (t->half ? 1 : 2);
     return b;
 }
 

@@ -161,7 +161,9 @@ def run_krypy_arnoldi(A, x0, M, tol, maxiter=None):
     nmax = n if maxiter is None else int(maxiter)
     V, H, k_done = _arnoldi_M(A, x0d, M, nmax)
     Vh = np.column_stack([D.to_host(v) for v in V])
-    Hh = H[:Vh.shape[1] if Vh.shape[1] > k_done else k_done + 1, :k_done]
+    # k completed steps give V (n x (k+1)) and H ((k+1) x k); when the Krylov space is exhausted
+    # (invariant subspace) there is no (k+1)-th vector and A V_k = V_k H_k holds with the square H
+    Hh = H[:k_done + 1, :k_done] if Vh.shape[1] > k_done else H[:k_done, :k_done]
     m = Vh.shape[1]
     print("Residual after  %d Arnoldi iterations, r^(k)= %g \nExiting Arnoldi ..."
           % (m, float(np.linalg.norm(Vh[:, -1]))))

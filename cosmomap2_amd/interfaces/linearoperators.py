@@ -210,7 +210,16 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
     """Tile-bucketed plan of a SparseLO, built on first use (sort by pixel tile)."""
     if getattr(P, "_tiles", None) is None:
         if tile_pixels is None:
-            tile_pixels = {1: 4096, 2: 2048, 3: 2048}[P.pol]       # 32 / 32 / 48 KB of LDS per tile
+            if os.environ.get("CM2_PT_ORDER", "fixed") == "atomic":
+                tile_pixels = {1: 4096, 2: 2048, 3: 2048}[P.pol]   # 32 / 32 / 48 KB of LDS per tile
+            else:
+                # fixed-order P^T: one workgroup owns a tile from its first sample to its last and
+                # keeps the tile (32 / 32 / 36 KB) plus a slice of the bucket (40 KB) in LDS, two
+                # workgroups per CU -- so there should be at least 2 x 256 tiles
+                tile_pixels = {1: 4096, 2: 2048, 3: 1536}[P.pol]
+                want = -(-P.ncols // 512)
+                want = max(64, -(-want // 64) * 64)
+                tile_pixels = min(tile_pixels, want)
             if os.environ.get("CM2_TILE_PIXELS"):
                 tile_pixels = int(os.environ["CM2_TILE_PIXELS"])
             while tile_pixels > 64 and tile_pixels // 2 >= P.ncols:
