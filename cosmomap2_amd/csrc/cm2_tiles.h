@@ -1,0 +1,59 @@
+// cm2_tiles.h -- the tile-bucketed pointing plan shared by cm2_tiles.hip (plan, P, atomic P^T,
+// permutations) and cm2_tiles_fixed.hip (fixed-order P^T)
+#pragma once
+#include "cm2_pixindex.h"
+
+#include <vector>
+
+struct cm2_tiles {
+    int64_t nt = 0, npix = 0, nvalid = 0;
+    int pol = 0;
+    int tp = 0;                  // pixels per tile
+    int64_t ntiles = 0, nitems = 0;
+    uint32_t *d_tb_dst = nullptr;   // [nt]
+    uint16_t *d_pl = nullptr;       // [nvalid]
+    double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]  (full-angle mode)
+    // half-angle mode: ONE double per sample, h = sin / (1 + |cos|) (= tan of half the angle
+    // folded into [-1, 1]) and the sign of cos in bit 15 of d_pl; cos = +-(1 - h^2)/(1 + h^2),
+    // sin = 2h/(1 + h^2) are rebuilt in the kernels (absolute error ~2e-16): 8 bytes less per
+    // sample in each of the two tile kernels
+    bool half = false;
+    double *d_half = nullptr;                    // [nvalid]
+    int32_t *d_item_tile = nullptr; // [nitems]
+    int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
+    int64_t *d_item_k1 = nullptr;
+    std::vector<int64_t> tile_item0;   // [ntiles+1] first work item of every tile (host)
+    // address-sorted lists of the windowed permutations (built on first use): for every window
+    // of kPermWin consecutive time samples, its samples' TB positions in ascending order and
+    // their offsets in the window
+    uint32_t *d_perm_k = nullptr;
+    uint16_t *d_perm_q = nullptr;
+    int64_t nperm_win = 0;
+    // identity of this plan for the caches other objects key on it (noise / filter lists): a
+    // device address can be reused by a later plan, a plan id cannot
+    uint64_t plan_id = 0;
+    // fixed-order P^T (cm2_tiles_fixed.hip), built on first use: every tile bucket is cut into
+    // slices of fx_S consecutive TB samples; per slice the samples sorted by (pixel, time) are
+    // packed into groups of 4 list entries that hold whole runs (= samples of one pixel)
+    int pt_fixed = 1;
+    int fx_S = 0;
+    std::vector<int64_t> tile_off;      // [ntiles+1] first TB position of every tile (host)
+    int64_t *d_tile_off = nullptr;
+    int64_t *d_fx_slice0 = nullptr;     // [ntiles+1] first slice of every tile
+    uint2 *d_fx_meta = nullptr;         // [nslices+1] {first group, first tail run} of every slice
+    uint4 *d_fx_gent = nullptr;         // [ngroups] 4 entries: pl word | offset in slice << 16 | level << 28
+    double *d_fx_ga = nullptr, *d_fx_gb = nullptr;   // [4 ngroups] half angle (or cos, sin)
+    uint2 *d_fx_trun = nullptr;         // [ntail runs + 1] {first tail entry, pixel in tile}
+    uint32_t *d_fx_tent = nullptr;      // [ntail entries] entries of the runs kept out of the groups
+    double *d_fx_ta = nullptr, *d_fx_tb = nullptr;
+    int64_t fx_ngroups = 0, fx_nslices = 0;
+};
+
+namespace cm2 {
+int fx_plan(const cm2_tiles *t, hipStream_t st, bool *use);
+int fx_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
+              int64_t tile_hi, hipStream_t stream);
+void fx_free(cm2_tiles *t);
+int64_t fx_designed_bytes(const cm2_tiles *t);
+}  // namespace cm2
+

@@ -30,51 +30,11 @@
 //
 // Reference loops replaced: interfaces/linearoperators.py:483-489 (mult_iqu) and :509-516
 // (rmult_iqu) and their I / QU variants.
-#include "cm2_pixindex.h"
+#include "cm2_tiles.h"
 
 #include <hipcub/hipcub.hpp>
-#include <vector>
 
 using namespace cm2;
-
-struct cm2_tiles {
-    int64_t nt = 0, npix = 0, nvalid = 0;
-    int pol = 0;
-    int tp = 0;                  // pixels per tile
-    int64_t ntiles = 0, nitems = 0;
-    uint32_t *d_tb_dst = nullptr;   // [nt]
-    uint16_t *d_pl = nullptr;       // [nvalid]
-    double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]  (full-angle mode)
-    // half-angle mode: ONE double per sample, h = sin / (1 + |cos|) (= tan of half the angle
-    // folded into [-1, 1]) and the sign of cos in bit 15 of d_pl; cos = +-(1 - h^2)/(1 + h^2),
-    // sin = 2h/(1 + h^2) are rebuilt in the kernels (absolute error ~2e-16): 8 bytes less per
-    // sample in each of the two tile kernels
-    bool half = false;
-    double *d_half = nullptr;                    // [nvalid]
-    int32_t *d_item_tile = nullptr; // [nitems]
-    int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
-    int64_t *d_item_k1 = nullptr;
-    std::vector<int64_t> tile_item0;   // [ntiles+1] first work item of every tile (host)
-    // address-sorted lists of the windowed permutations (built on first use): for every window
-    // of kPermWin consecutive time samples, its samples' TB positions in ascending order and
-    // their offsets in the window
-    uint32_t *d_perm_k = nullptr;
-    uint16_t *d_perm_q = nullptr;
-    int64_t nperm_win = 0;
-    // identity of this plan for the caches other objects key on it (noise / filter lists): a
-    // device address can be reused by a later plan, a plan id cannot
-    uint64_t plan_id = 0;
-    // fixed-order P^T (k_Pt_tiles_fixed): every tile bucket is cut into slices of fx_S
-    // consecutive TB samples; fx_ent lists each slice's samples sorted by (pixel, time):
-    // bits 0..15 = the pl word of the sample (pixel in tile, sign of cos), bits 16..31 = its
-    // offset in the slice; fx_a (fx_b) = half angle (cos, sin) in that same sorted order
-    int pt_fixed = 1;
-    int fx_S = 0;
-    std::vector<int64_t> tile_off;      // [ntiles+1] first TB position of every tile (host)
-    int64_t *d_tile_off = nullptr;
-    uint32_t *d_fx_ent = nullptr;
-    double *d_fx_a = nullptr, *d_fx_b = nullptr;
-};
 
 static uint64_t next_plan_id()
 {
@@ -284,222 +244,6 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) atomicAdd(&o[i], tile[i]);
 }
 
-// ------------------------------------------------- P^T (TB), fixed order ------
-// The reference's scatter (linearoperators.py:509-516) is a serial loop: every pixel's sum
-// starts at 0 and receives its samples in time order.  Here ONE workgroup owns a tile from
-// its first sample to its last, so the tile's accumulators stay in LDS for the whole bucket
-// and nothing is flushed with atomics.  The bucket is walked slice by slice (S consecutive
-// TB samples = S consecutive-in-time samples of this tile).  Per slice a list sorted by
-// (pixel, time) -- built once at plan time -- turns the scatter into runs: thread t owns the
-// runs that START in entries [t PER, (t+1) PER) of the sorted list (it skips the leading
-// entries that continue the previous thread's run and follows its own last run past the end
-// of its chunk), reads the run's pixel accumulators from LDS, adds the run's samples one after
-// the other and writes them back.  A pixel is touched by exactly one thread per slice and the
-// slices follow each other in time, so each sum is the reference's, term by term.
-//
-// HBM per sample: v 8 B (TB order, staged through LDS and picked up by offset) + list entry
-// 4 B + half angle 8 B (both in sorted order) = 20 B, all 16-B-per-lane style streams; the next
-// slice is fetched into registers while the current one is reduced.
-constexpr int kFxT = 512;
-constexpr int kFxDepth = 3;            // slices fetched ahead of the one being reduced
-
-// LDS pitch of the sorted-order arrays: entry i of the slice sits at (i % PER) * pitch + i / PER,
-// so that thread t finds its chunk [t PER, (t+1) PER) at m * pitch + t (consecutive lanes,
-// consecutive addresses) and the coalesced staging stores (lane = entry) spread over all banks
-__host__ __device__ constexpr int fx_pitch_f64() { return kFxT + 4; }
-__host__ __device__ constexpr int fx_pitch_u32() { return kFxT + 8; }
-
-template <int POL, bool HALF, int PER>
-__global__ __launch_bounds__(kFxT) void k_Pt_tiles_fixed(
-    int tp, int64_t npix, int tile0, const int64_t *__restrict__ tile_off,
-    const uint32_t *__restrict__ ent, const double *__restrict__ fa,
-    const double *__restrict__ fb, const double *__restrict__ v_tb, double *__restrict__ out)
-{
-    constexpr int S = PER * kFxT, D = kFxDepth;
-    constexpr int LOGPER = PER == 1 ? 0 : (PER == 2 ? 1 : (PER == 4 ? 2 : 3));
-    constexpr int PF = fx_pitch_f64(), PU = fx_pitch_u32();
-    constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
-    extern __shared__ double sm[];
-    double *tile = sm;                                   // tp * POL accumulators
-    double *vbuf = sm + (int64_t)tp * POL;               // S values, TB order
-    double *abuf = vbuf + S;                             // PER * PF half angles (or cos), sorted order
-    double *bbuf = abuf + (ANG ? PER * PF : 0);          // PER * PF sin (full-angle mode)
-    uint32_t *ebuf = reinterpret_cast<uint32_t *>(bbuf + (TWO ? PER * PF : 0));   // PER * PU
-    const int tid = threadIdx.x;
-    const int b = tile0 + blockIdx.x;
-    const int64_t p0 = (int64_t)b * tp;
-    int64_t np = npix - p0;
-    if (np > tp) np = tp;
-    const int nvals = (int)(np * POL);
-    for (int i = tid; i < nvals; i += kFxT) tile[i] = 0.0;
-    const int64_t k_begin = tile_off[b], k_end = tile_off[b + 1];
-    const int nsl = (int)((k_end - k_begin + S - 1) / S);
-
-    // register ring: slice j lives in slot j % D from the moment slice j - D has been staged
-    double pv[D][PER], pa[D][PER], pb[D][PER];
-    uint32_t pe[D][PER];
-    auto fetch = [&](int slot, int j) {
-        if (j >= nsl) return;
-        const int64_t kb = k_begin + (int64_t)j * S;
-        const int len = (int)((k_end - kb < S) ? k_end - kb : S);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = tid + u * kFxT;
-            if (i < len) {
-                pv[slot][u] = v_tb[kb + i];
-                pe[slot][u] = ent[kb + i];
-                if (ANG) pa[slot][u] = fa[kb + i];
-                if (TWO) pb[slot][u] = fb[kb + i];
-            }
-        }
-    };
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) fetch(dd, dd);
-    constexpr uint32_t QM = HALF ? 0x7FFFu : 0xFFFFu;
-    auto EU = [](int i) { return (i & (PER - 1)) * PU + (i >> LOGPER); };
-    auto EF = [](int i) { return (i & (PER - 1)) * PF + (i >> LOGPER); };
-    for (int jj = 0; jj < nsl; jj += D) {
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-            const int j = jj + dd;
-            if (j >= nsl) break;
-            const int64_t kb = k_begin + (int64_t)j * S;
-            const int len = (int)((k_end - kb < S) ? k_end - kb : S);
-            __syncthreads();                  // the previous slice is reduced (j = 0: tile zeroed)
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int i = tid + u * kFxT;
-                if (i < len) {
-                    vbuf[i] = pv[dd][u];
-                    ebuf[EU(i)] = pe[dd][u];
-                    if (ANG) abuf[EF(i)] = pa[dd][u];
-                    if (TWO) bbuf[EF(i)] = pb[dd][u];
-                }
-            }
-            __syncthreads();
-            fetch(dd, j + D);
-            const int e0 = tid * PER;
-            int e1 = e0 + PER;
-            if (e1 > len) e1 = len;
-            int i = e0;
-            if (e0 > 0 && e0 < len) {
-                const uint32_t qprev = ebuf[EU(e0 - 1)] & QM;
-                while (i < e1 && (ebuf[EU(i)] & QM) == qprev) ++i;
-            }
-            int cur = -1;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            while (i < len) {
-                const uint32_t w = ebuf[EU(i)];
-                const int q = (int)(w & QM);
-                if (q != cur) {
-                    if (i >= e1) break;                   // the next run belongs to another thread
-                    if (cur >= 0) {
-                        if (POL == 1) {
-                            tile[cur] = a0;
-                        } else if (POL == 2) {
-                            tile[2 * cur] = a1;
-                            tile[2 * cur + 1] = a2;
-                        } else {
-                            tile[3 * cur] = a0;
-                            tile[3 * cur + 1] = a1;
-                            tile[3 * cur + 2] = a2;
-                        }
-                    }
-                    cur = q;
-                    if (POL == 1) {
-                        a0 = tile[q];
-                    } else if (POL == 2) {
-                        a1 = tile[2 * q];
-                        a2 = tile[2 * q + 1];
-                    } else {
-                        a0 = tile[3 * q];
-                        a1 = tile[3 * q + 1];
-                        a2 = tile[3 * q + 2];
-                    }
-                }
-                const double v = vbuf[w >> 16];
-                if (POL == 1) {
-                    a0 += v;
-                } else {
-                    double cc, ss;
-                    if (HALF) {
-                        const double h = abuf[EF(i)], h2 = h * h, inv = 1.0 / (1.0 + h2);
-                        cc = (1.0 - h2) * inv;
-                        ss = (h + h) * inv;
-                        if (w & 0x8000u) cc = -cc;
-                    } else {
-                        cc = abuf[EF(i)];
-                        ss = bbuf[EF(i)];
-                    }
-                    if (POL == 3) a0 += v;
-                    a1 += v * cc;
-                    a2 += v * ss;
-                }
-                ++i;
-            }
-            if (cur >= 0) {
-                if (POL == 1) {
-                    tile[cur] = a0;
-                } else if (POL == 2) {
-                    tile[2 * cur] = a1;
-                    tile[2 * cur + 1] = a2;
-                } else {
-                    tile[3 * cur] = a0;
-                    tile[3 * cur + 1] = a1;
-                    tile[3 * cur + 2] = a2;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    double *o = out + p0 * POL;
-    for (int i = tid; i < nvals; i += kFxT) o[i] = tile[i];
-}
-
-// keys of the per-slice sort: (global slice number << 16) | pixel in tile; value = the list entry
-__global__ __launch_bounds__(256) void k_fx_keys(int64_t nvalid, int64_t ntiles, int S, uint32_t qmask,
-                                                  const int64_t *__restrict__ tile_off,
-                                                  const int64_t *__restrict__ tile_slice0,
-                                                  const uint16_t *__restrict__ pl,
-                                                  uint64_t *__restrict__ keys,
-                                                  uint32_t *__restrict__ vals)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nvalid; k += stride) {
-        int64_t lo = 0, hi = ntiles;                      // largest b with tile_off[b] <= k
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (tile_off[mid] <= k) lo = mid; else hi = mid;
-        }
-        const int64_t r = k - tile_off[lo];
-        const uint32_t w = pl[k];
-        keys[k] = ((uint64_t)(tile_slice0[lo] + r / S) << 16) | (uint64_t)(w & qmask);
-        vals[k] = w | ((uint32_t)(r % S) << 16);
-    }
-}
-
-// angles of the sorted entries: entry j of a slice describes TB sample (slice start + offset)
-__global__ __launch_bounds__(256) void k_fx_angles(int64_t nvalid, int64_t ntiles, int S,
-                                                    const int64_t *__restrict__ tile_off,
-                                                    const uint32_t *__restrict__ ent,
-                                                    const double *__restrict__ a_tb,
-                                                    const double *__restrict__ b_tb,
-                                                    double *__restrict__ fa, double *__restrict__ fb)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nvalid; j += stride) {
-        int64_t lo = 0, hi = ntiles;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (tile_off[mid] <= j) lo = mid; else hi = mid;
-        }
-        const int64_t r = j - tile_off[lo];
-        const int64_t src = tile_off[lo] + (r / S) * S + (int64_t)(ent[j] >> 16);
-        fa[j] = a_tb[src];
-        if (b_tb) fb[j] = b_tb[src];
-    }
-}
-
 // ------------------------------------------------------- time <-> TB order ------
 // each workgroup owns ONE contiguous time range, so that the K sequential tile streams
 // it touches stay in its XCD's L2 until their lines are complete
@@ -624,10 +368,10 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
     void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
-                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off,
-                    t->d_fx_ent, t->d_fx_a, t->d_fx_b};
+                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    cm2::fx_free(t);
     delete t;
     return 0;
 }
@@ -766,6 +510,7 @@ extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
     h_info[0] = t->nt; h_info[1] = t->nvalid; h_info[2] = t->tp;
     h_info[3] = t->ntiles; h_info[4] = t->nitems; h_info[5] = t->half ? 1 : 0;
     h_info[6] = t->pt_fixed; h_info[7] = (int64_t)t->plan_id;
+    h_info[8] = t->fx_S; h_info[9] = cm2::fx_designed_bytes(t);
     return 0;
 }
 
@@ -778,125 +523,6 @@ extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t) { return t ? t->plan_id : 0; }
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid : 0; }
-
-// ---- fixed-order P^T: plan (built on first use) and launch ----
-static size_t fx_lds_bytes(const cm2_tiles *t, int S)
-{
-    const size_t per = (size_t)(S / kFxT);
-    size_t b = sizeof(double) * (size_t)t->tp * t->pol + sizeof(double) * S +
-               sizeof(uint32_t) * per * fx_pitch_u32();
-    if (t->pol > 1) b += sizeof(double) * per * fx_pitch_f64() * (t->half ? 1 : 2);
-    return b;
-}
-
-static int fx_slice_len(const cm2_tiles *t)
-{
-    int per = 4;                                         // S = 2048
-    if (const char *e = getenv("CM2_PT_SLICE")) {
-        const int v = atoi(e) / kFxT;
-        if (v == 1 || v == 2 || v == 4 || v == 8) per = v;
-    }
-    while (per > 1 && fx_lds_bytes(t, per * kFxT) > 159 * 1024) per >>= 1;
-    return per * kFxT;
-}
-
-static int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
-{
-    cm2_tiles *t = const_cast<cm2_tiles *>(tc);         // lazily built cache
-    *use = false;
-    if (!t->pt_fixed) return 0;
-    if (t->fx_S == 0) {
-        const int S = fx_slice_len(t);
-        if (fx_lds_bytes(t, S) > 159 * 1024) {           // tile too large for tile + slice in LDS
-            t->pt_fixed = 0;
-            return 0;
-        }
-        const int64_t nv = t->nvalid;
-        std::vector<int64_t> slice0((size_t)t->ntiles + 1, 0);
-        for (int64_t b = 0; b < t->ntiles; ++b)
-            slice0[(size_t)b + 1] = slice0[(size_t)b] + (t->tile_off[(size_t)b + 1] - t->tile_off[(size_t)b] + S - 1) / S;
-        const int64_t nslices = slice0[(size_t)t->ntiles];
-        if (nv > 0) {
-            DevTemp<int64_t> d_slice0;
-            DevTemp<uint64_t> keys_in, keys_out;
-            DevTemp<uint32_t> vals_in, ent;
-            DevTemp<double> fa, fb;
-            DevTemp<char> d_temp;
-            CM2_HIP(d_slice0.alloc(slice0.size()));
-            CM2_HIP(hipMemcpyAsync(d_slice0, slice0.data(), sizeof(int64_t) * slice0.size(),
-                                   hipMemcpyHostToDevice, st));
-            CM2_HIP(keys_in.alloc(nv));
-            CM2_HIP(keys_out.alloc(nv));
-            CM2_HIP(vals_in.alloc(nv));
-            CM2_HIP(ent.alloc(nv));
-            const uint32_t qmask = t->half ? 0x7FFFu : 0xFFFFu;
-            k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_tile_off, d_slice0,
-                                                      t->d_pl, keys_in, vals_in);
-            CM2_LAUNCH_OK();
-            int end_bit = 17;
-            while (((int64_t)1 << (end_bit - 16)) <= nslices && end_bit < 64) ++end_bit;
-            size_t tb = 0;
-            CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                       ent.p, nv, 0, end_bit, st));
-            CM2_HIP(d_temp.alloc(tb + 16));
-            CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                       ent.p, nv, 0, end_bit, st));
-            if (t->pol > 1) {
-                CM2_HIP(fa.alloc(nv));
-                if (!t->half) CM2_HIP(fb.alloc(nv));
-                k_fx_angles<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, t->d_tile_off, ent,
-                                                            t->half ? t->d_half : t->d_cos,
-                                                            t->half ? nullptr : t->d_sin, fa, fb);
-                CM2_LAUNCH_OK();
-            }
-            CM2_HIP(hipStreamSynchronize(st));
-            t->d_fx_ent = ent.keep();
-            t->d_fx_a = fa.keep();
-            t->d_fx_b = fb.keep();
-        }
-        t->fx_S = S;
-    }
-    *use = true;
-    return 0;
-}
-
-template <int POL, bool HALF, int PER>
-static int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
-                          int64_t tile_hi, hipStream_t stream)
-{
-    const size_t lds = fx_lds_bytes(t, PER * kFxT);
-    CM2_HIP(hipFuncSetAttribute((const void *)k_Pt_tiles_fixed<POL, HALF, PER>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_Pt_tiles_fixed<POL, HALF, PER><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
-        t->tp, t->npix, (int)tile_lo, t->d_tile_off, t->d_fx_ent, t->d_fx_a, t->d_fx_b, d_tod_tb,
-        d_out);
-    CM2_LAUNCH_OK();
-    return 0;
-}
-
-template <int POL, bool HALF>
-static int fx_launch_per(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
-                         int64_t tile_hi, hipStream_t stream)
-{
-    switch (t->fx_S / kFxT) {
-    case 1: return fx_launch_inst<POL, HALF, 1>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    case 2: return fx_launch_inst<POL, HALF, 2>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    case 8: return fx_launch_inst<POL, HALF, 8>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    default: return fx_launch_inst<POL, HALF, 4>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    }
-}
-
-static int fx_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
-                     int64_t tile_hi, hipStream_t stream)
-{
-    if (tile_hi <= tile_lo) return 0;
-    if (t->pol == 1) return fx_launch_per<1, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    if (t->pol == 2)
-        return t->half ? fx_launch_per<2, true>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream)
-                       : fx_launch_per<2, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    return t->half ? fx_launch_per<3, true>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream)
-                   : fx_launch_per<3, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-}
 
 extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb,
                                  void *stream_)
@@ -923,8 +549,8 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
     CM2_CHECK(t && d_out && (d_tod_tb || t->nvalid == 0), "cm2_Pt_tiles_apply: NULL argument");
     hipStream_t stream = as_stream(stream_);
     bool fixed = false;
-    if (int rc = fx_plan(t, stream, &fixed)) return rc;
-    if (fixed) return fx_launch(t, d_tod_tb, d_out, 0, t->ntiles, stream);
+    if (int rc = cm2::fx_plan(t, stream, &fixed)) return rc;
+    if (fixed) return cm2::fx_launch(t, d_tod_tb, d_out, 0, t->ntiles, stream);
     CM2_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * t->npix * t->pol, stream));
     if (t->nitems == 0) return 0;
     const size_t lds = sizeof(double) * t->tp * t->pol;
@@ -950,8 +576,8 @@ extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_
     if (tile_lo == tile_hi) return 0;
     hipStream_t stream = as_stream(stream_);
     bool fixed = false;
-    if (int rc = fx_plan(t, stream, &fixed)) return rc;
-    if (fixed) return fx_launch(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+    if (int rc = cm2::fx_plan(t, stream, &fixed)) return rc;
+    if (fixed) return cm2::fx_launch(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
     const int64_t p0 = tile_lo * t->tp;
     const int64_t p1 = tile_hi * t->tp < t->npix ? tile_hi * t->tp : t->npix;
     CM2_HIP(hipMemsetAsync(d_out + p0 * t->pol, 0, sizeof(double) * (p1 - p0) * t->pol, stream));

@@ -1,0 +1,596 @@
+// cm2_tiles_fixed.hip -- P^T on the tile-bucketed order with every pixel's terms added IN TIME
+// ORDER starting from 0, exactly like the reference's serial scatter loop
+// (interfaces/linearoperators.py:394-400, :452-458, :509-516): no atomics, bitwise reproducible
+// from run to run, and bit-identical to the serial loop when the plan keeps cos and sin
+// (CM2_TILE_ANGLES=full; the default half-angle storage rebuilds them to ~2e-16).
+//
+// ONE workgroup owns a tile from its first sample to its last: the tile's accumulators stay in
+// LDS for the whole bucket and are written out once with plain stores.  The bucket is walked
+// slice by slice (S consecutive TB samples = S consecutive-in-time samples of this tile).  At
+// plan time the samples of a slice are sorted by (pixel, time) and packed into GROUPS of four
+// list entries such that a group holds whole runs (run = the slice's samples of one pixel):
+//
+//   entry  = pl word (pixel in tile, sign of cos) | offset in the slice << 16 | level << 28
+//   group  = 4 entries + their 4 half angles (or cos, sin), padded with null entries
+//   thread t of the workgroup owns group t of the slice: it reads its 16 + 32 bytes with
+//   three 16-byte loads straight into registers -- two slices ahead of the one it reduces --,
+//   picks the 4 TOD values out of the slice staged in LDS, and adds each run to the pixel's LDS
+//   accumulators one term after the other.  A pixel is touched by one thread per slice and the
+//   slices follow each other in time, so each sum is the reference's, term by term.
+//
+// Runs of 5..60 samples are cut into pieces of 4 in consecutive groups, piece p carrying
+// level p: the workgroup makes one pass per level, separated by a barrier, so the pieces are
+// added in order.  Longer runs (a pixel hit > 60 times inside one slice: hot pixels) are kept
+// out of the groups and walked by one thread each from a separate list.
+//
+// HBM per sample: 8 B TOD + ~1.2 x 12 B of list (padding of the groups) = ~22.5 B, every load
+// 16 B per lane and coalesced.
+#include "cm2_tiles.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace cm2;
+
+namespace {
+
+constexpr int kFxT = 512;               // threads = groups per slice handled in one round
+constexpr int kFxDepth = 2;             // slices fetched ahead of the one being reduced
+constexpr uint32_t kFxNull = 0xFFFFFFFFu;
+constexpr int kFxMaxLevel = 14;         // pieces of 4: runs up to 60 samples go into groups
+
+// ------------------------------------------------------------------- kernel --------
+template <int POL, bool HALF, int VPT>
+__global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
+    int tp, int64_t npix, int tile0, int S, const int64_t *__restrict__ tile_off,
+    const int64_t *__restrict__ slice0, const uint2 *__restrict__ meta,
+    const uint4 *__restrict__ gent, const double2 *__restrict__ ga,
+    const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
+    const uint32_t *__restrict__ tent, const double *__restrict__ ta,
+    const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out)
+{
+    constexpr int D = kFxDepth;
+    constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
+    constexpr uint32_t QM = HALF ? 0x7FFFu : 0xFFFFu;
+    extern __shared__ double sm[];
+    double *tile = sm;                                   // tp * POL accumulators
+    double *vbuf = sm + (int64_t)tp * POL;               // VPT * kFxT values of the slice, TB order
+    const int tid = threadIdx.x;
+    const int b = tile0 + blockIdx.x;
+    const int64_t p0 = (int64_t)b * tp;
+    int64_t np = npix - p0;
+    if (np > tp) np = tp;
+    const int nvals = (int)(np * POL);
+    for (int i = tid; i < nvals; i += kFxT) tile[i] = 0.0;
+    const int64_t k_begin = tile_off[b], k_end = tile_off[b + 1];
+    const int64_t s0 = slice0[b];
+    const int nsl = (int)(slice0[b + 1] - s0);
+
+    // register ring: slice j lives in slot j % D from the moment slice j - D has been staged.
+    // All loads are unconditional (indices clamped) and kept together per slice, so that the
+    // compiler counts outstanding loads (s_waitcnt vmcnt(N)) instead of draining them.
+    double pv[D][VPT];
+    uint4 pe[D];
+    double2 pa[D][2], pb[D][2];
+    uint2 pm[D][2];                                      // meta of slice j and j + 1
+    auto fetch = [&](int slot, int j) {
+        const int jc = j < nsl ? j : nsl - 1;
+        const int64_t kb = k_begin + (int64_t)jc * S;
+        const int len = (int)((k_end - kb < S) ? k_end - kb : S);
+        const uint2 m0 = meta[s0 + jc], m1 = meta[s0 + jc + 1];
+        pm[slot][0] = m0;
+        pm[slot][1] = m1;
+        const uint32_t G = m1.x - m0.x;
+        const int64_t g = (int64_t)m0.x + ((uint32_t)tid < G ? tid : 0);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int i = tid + u * kFxT;
+            pv[slot][u] = v_tb[kb + (i < len ? i : len - 1)];
+        }
+        pe[slot] = gent[g];
+        if (ANG) {
+            pa[slot][0] = ga[2 * g];
+            pa[slot][1] = ga[2 * g + 1];
+        }
+        if (TWO) {
+            pb[slot][0] = gb[2 * g];
+            pb[slot][1] = gb[2 * g + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // terms of one list entry: (v, v cos, v sin)
+    auto terms = [&](uint32_t w, double a, double bsin, double v, double &t1, double &t2) {
+        if (POL == 1) return;
+        double cc, ss;
+        if (HALF) {
+            const double h2 = a * a, inv = 1.0 / (1.0 + h2);
+            cc = (1.0 - h2) * inv;
+            ss = (a + a) * inv;
+            if (w & 0x8000u) cc = -cc;
+        } else {
+            cc = a;
+            ss = bsin;
+        }
+        t1 = v * cc;
+        t2 = v * ss;
+    };
+    auto tile_load = [&](int q, double &a0, double &a1, double &a2) {
+        if (POL == 1) {
+            a0 = tile[q];
+        } else if (POL == 2) {
+            a1 = tile[2 * q];
+            a2 = tile[2 * q + 1];
+        } else {
+            a0 = tile[3 * q];
+            a1 = tile[3 * q + 1];
+            a2 = tile[3 * q + 2];
+        }
+    };
+    auto tile_store = [&](int q, double a0, double a1, double a2) {
+        if (POL == 1) {
+            tile[q] = a0;
+        } else if (POL == 2) {
+            tile[2 * q] = a1;
+            tile[2 * q + 1] = a2;
+        } else {
+            tile[3 * q] = a0;
+            tile[3 * q + 1] = a1;
+            tile[3 * q + 2] = a2;
+        }
+    };
+    // one group: its runs added to the tile accumulators, term after term
+    auto reduce_group = [&](const uint32_t (&w)[4], const double (&v)[4], const double (&t1)[4],
+                            const double (&t2)[4]) {
+        int q[4];
+        bool ok[4];
+        double l0[4], l1[4], l2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            ok[m] = w[m] != kFxNull;
+            q[m] = ok[m] ? (int)(w[m] & QM) : 0;
+            l0[m] = l1[m] = l2[m] = 0.0;
+            tile_load(q[m], l0[m], l1[m], l2[m]);       // (runs of a group are different pixels)
+        }
+        double a0 = l0[0], a1 = l1[0], a2 = l2[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m > 0 && ok[m] && q[m] != q[m - 1]) {
+                tile_store(q[m - 1], a0, a1, a2);
+                a0 = l0[m];
+                a1 = l1[m];
+                a2 = l2[m];
+            }
+            if (ok[m]) {
+                if (POL != 2) a0 += v[m];
+                if (POL > 1) {
+                    a1 += t1[m];
+                    a2 += t2[m];
+                }
+            }
+            if (ok[m] && (m == 3 || w[m + 1 < 4 ? m + 1 : 3] == kFxNull))
+                tile_store(q[m], a0, a1, a2);
+        }
+    };
+
+    if (nsl > 0) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) fetch(dd, dd);
+    }
+    for (int jj = 0; jj < nsl; jj += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const int j = jj + dd;
+            if (j >= nsl) break;
+            // ---- stage the slice's TOD values (everyone is past the previous slice's last
+            //      barrier; j = 0: the barrier below also covers the zeroing of the tile) ----
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) vbuf[tid + u * kFxT] = pv[dd][u];
+            const uint2 m0 = pm[dd][0], m1 = pm[dd][1];
+            uint32_t w[4] = {pe[dd].x, pe[dd].y, pe[dd].z, pe[dd].w};
+            double a[4] = {0.0, 0.0, 0.0, 0.0}, bs[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ANG) {
+                a[0] = pa[dd][0].x; a[1] = pa[dd][0].y; a[2] = pa[dd][1].x; a[3] = pa[dd][1].y;
+            }
+            if (TWO) {
+                bs[0] = pb[dd][0].x; bs[1] = pb[dd][0].y; bs[2] = pb[dd][1].x; bs[3] = pb[dd][1].y;
+            }
+            __syncthreads();
+            fetch(dd, j + D);
+            const uint32_t G = m1.x - m0.x, ntail = m1.y - m0.y;
+            for (uint32_t g0 = 0; g0 < G || g0 == 0; g0 += kFxT) {
+                const bool mine = g0 + tid < G;
+                if (g0 > 0) {                             // more groups than threads: direct loads
+                    const int64_t g = (int64_t)m0.x + (mine ? g0 + tid : 0);
+                    const uint4 e = gent[g];
+                    w[0] = e.x; w[1] = e.y; w[2] = e.z; w[3] = e.w;
+                    if (ANG) {
+                        const double2 x0 = ga[2 * g], x1 = ga[2 * g + 1];
+                        a[0] = x0.x; a[1] = x0.y; a[2] = x1.x; a[3] = x1.y;
+                    }
+                    if (TWO) {
+                        const double2 x0 = gb[2 * g], x1 = gb[2 * g + 1];
+                        bs[0] = x0.x; bs[1] = x0.y; bs[2] = x1.x; bs[3] = x1.y;
+                    }
+                }
+                if (!mine) w[0] = w[1] = w[2] = w[3] = kFxNull;
+                double v[4], t1[4], t2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t off = (w[m] >> 16) & 0xFFFu;
+                    v[m] = vbuf[w[m] != kFxNull ? off : 0];
+                    t1[m] = t2[m] = 0.0;
+                    terms(w[m], a[m], bs[m], v[m], t1[m], t2[m]);
+                }
+                const int level = mine ? (int)((w[0] >> 28) & 15u) : 0;
+                if (g0 == 0) {
+                    // runs too long for the groups: one thread walks a whole run
+                    for (uint32_t r = tid; r < ntail; r += kFxT) {
+                        const uint2 r0 = trun[(int64_t)m0.y + r], r1 = trun[(int64_t)m0.y + r + 1];
+                        const int q = (int)r0.y;
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                        tile_load(q, a0, a1, a2);
+                        for (uint32_t e = r0.x; e < r1.x; ++e) {
+                            const uint32_t we = tent[e];
+                            const double ve = vbuf[(we >> 16) & 0xFFFu];
+                            double u1 = 0.0, u2 = 0.0;
+                            terms(we, ANG ? ta[e] : 0.0, TWO ? tb[e] : 0.0, ve, u1, u2);
+                            if (POL != 2) a0 += ve;
+                            if (POL > 1) {
+                                a1 += u1;
+                                a2 += u2;
+                            }
+                        }
+                        tile_store(q, a0, a1, a2);
+                    }
+                }
+                // one pass per level: piece p of a long run is added after piece p - 1
+                int p = 0;
+                int more;
+                do {
+                    if (mine && level == p) reduce_group(w, v, t1, t2);
+                    more = __syncthreads_or(mine && level > p);
+                    ++p;
+                } while (more);
+            }
+        }
+    }
+    __syncthreads();
+    double *o = out + p0 * POL;
+    for (int i = tid; i < nvals; i += kFxT) o[i] = tile[i];
+}
+
+// ------------------------------------------------------------------- plan -----------
+// keys of the per-slice sort: (global slice number << 16) | pixel in tile; value = list entry
+__global__ __launch_bounds__(256) void k_fx_keys(int64_t nvalid, int64_t ntiles, int S, uint32_t qmask,
+                                                  const int64_t *__restrict__ tile_off,
+                                                  const int64_t *__restrict__ tile_slice0,
+                                                  const uint16_t *__restrict__ pl,
+                                                  uint64_t *__restrict__ keys,
+                                                  uint32_t *__restrict__ vals)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nvalid; k += stride) {
+        int64_t lo = 0, hi = ntiles;                      // largest b with tile_off[b] <= k
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (tile_off[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int64_t r = k - tile_off[lo];
+        const uint32_t w = pl[k];
+        keys[k] = ((uint64_t)(tile_slice0[lo] + r / S) << 16) | (uint64_t)(w & qmask);
+        vals[k] = w | ((uint32_t)(r % S) << 16);
+    }
+}
+
+// One thread per slice walks the slice's sorted entries and packs the runs into groups.
+// WRITE = false: counts[3 s + {0, 1, 2}] = groups, tail runs, tail entries of slice s.
+// WRITE = true: the groups / tail lists are written at the offsets of the slice.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_fx_pack(
+    int64_t nslices, uint32_t qmask, const int64_t *__restrict__ slice_k0,
+    const uint32_t *__restrict__ ent, const double *__restrict__ a_tb,
+    const double *__restrict__ b_tb, uint32_t *__restrict__ counts,
+    const uint2 *__restrict__ meta, const uint32_t *__restrict__ tent_off,
+    uint32_t *__restrict__ gent, double *__restrict__ ga, double *__restrict__ gb,
+    uint2 *__restrict__ trun, uint32_t *__restrict__ tent, double *__restrict__ ta,
+    double *__restrict__ tb)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const int64_t k0 = slice_k0[s];
+    const int len = (int)(slice_k0[s + 1] - k0);
+    int64_t g = WRITE ? (int64_t)meta[s].x : 0;
+    uint32_t ntr = 0, nte = 0, ng = 0;
+    int fill = 0;
+    auto put = [&](int slot, uint32_t w, uint32_t level) {
+        if (!WRITE) return;
+        const int64_t at = 4 * g + slot;
+        gent[at] = w | (level << 28);
+        const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
+        if (ga) ga[at] = a_tb[src];
+        if (gb) gb[at] = b_tb[src];
+    };
+    auto close = [&]() {
+        if (WRITE)
+            for (int slot = fill; slot < 4; ++slot) {
+                gent[4 * g + slot] = kFxNull;
+                if (ga) ga[4 * g + slot] = 0.0;
+                if (gb) gb[4 * g + slot] = 0.0;
+            }
+        ++g;
+        ++ng;
+        fill = 0;
+    };
+    int i = 0;
+    while (i < len) {
+        const uint32_t q = ent[k0 + i] & qmask;
+        int L = 1;
+        while (i + L < len && (ent[k0 + i + L] & qmask) == q) ++L;
+        if (L > 4 * (kFxMaxLevel + 1)) {
+            if (WRITE) {
+                const uint32_t e0 = tent_off[s] + nte;
+                trun[(int64_t)meta[s].y + ntr] = make_uint2(e0, q);
+                for (int m = 0; m < L; ++m) {
+                    const uint32_t w = ent[k0 + i + m];
+                    tent[e0 + m] = w;
+                    const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
+                    if (ta) ta[e0 + m] = a_tb[src];
+                    if (tb) tb[e0 + m] = b_tb[src];
+                }
+            }
+            ++ntr;
+            nte += (uint32_t)L;
+        } else if (L <= 4) {
+            if (fill + L > 4) close();
+            for (int m = 0; m < L; ++m) put(fill + m, ent[k0 + i + m], 0);
+            fill += L;
+            if (fill == 4) close();
+        } else {
+            if (fill > 0) close();
+            for (int m = 0; m < L; ++m) {
+                put(fill, ent[k0 + i + m], (uint32_t)(m / 4));
+                if (++fill == 4) close();
+            }
+            if (fill > 0) close();
+        }
+        i += L;
+    }
+    if (fill > 0) close();
+    if (!WRITE) {
+        counts[3 * s] = ng;
+        counts[3 * s + 1] = ntr;
+        counts[3 * s + 2] = nte;
+    }
+}
+
+size_t fx_lds_bytes(const cm2_tiles *t, int S)
+{
+    int vpt = (S + kFxT - 1) / kFxT;
+    vpt = vpt <= 2 ? 2 : 4;
+    return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT);
+}
+
+void fx_release(cm2_tiles *t)
+{
+    void **ptrs[] = {(void **)&t->d_fx_slice0, (void **)&t->d_fx_meta, (void **)&t->d_fx_gent,
+                     (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
+                     (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb};
+    for (void **q : ptrs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    t->fx_S = 0;
+    t->fx_ngroups = t->fx_nslices = 0;
+}
+
+// builds the lists for slices of S samples; *mean_groups = average groups per full slice,
+// *over = fraction of slices with more groups than threads
+int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *over)
+{
+    fx_release(t);
+    const int64_t nv = t->nvalid;
+    std::vector<int64_t> slice0((size_t)t->ntiles + 1, 0), k0;
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        const int64_t lo = t->tile_off[(size_t)b], hi = t->tile_off[(size_t)b + 1];
+        slice0[(size_t)b + 1] = slice0[(size_t)b] + (hi - lo + S - 1) / S;
+        for (int64_t k = lo; k < hi; k += S) k0.push_back(k);
+    }
+    const int64_t nslices = slice0[(size_t)t->ntiles];
+    k0.push_back(nv);
+    // (a tile's last slice ends where the next tile's first one starts: k0 is the cut list)
+    CM2_CHECK(nslices < ((int64_t)1 << 31), "cm2_tiles: too many slices");
+    CM2_HIP(hipMalloc(&t->d_fx_slice0, sizeof(int64_t) * slice0.size()));
+    CM2_HIP(hipMemcpyAsync(t->d_fx_slice0, slice0.data(), sizeof(int64_t) * slice0.size(),
+                           hipMemcpyHostToDevice, st));
+    std::vector<uint2> meta((size_t)nslices + 1, make_uint2(0, 0));
+    std::vector<uint32_t> tent_off((size_t)nslices + 1, 0);
+    int64_t ngroups = 0, ntrun = 0, ntent = 0;
+    *mean_groups = 0.0;
+    *over = 0.0;
+    if (nv > 0) {
+        DevTemp<int64_t> d_k0;
+        DevTemp<uint64_t> keys_in, keys_out;
+        DevTemp<uint32_t> vals_in, ent, d_counts, d_tent_off;
+        DevTemp<char> d_temp;
+        CM2_HIP(d_k0.alloc(k0.size()));
+        CM2_HIP(hipMemcpyAsync(d_k0, k0.data(), sizeof(int64_t) * k0.size(), hipMemcpyHostToDevice, st));
+        CM2_HIP(keys_in.alloc(nv));
+        CM2_HIP(keys_out.alloc(nv));
+        CM2_HIP(vals_in.alloc(nv));
+        CM2_HIP(ent.alloc(nv));
+        const uint32_t qmask = t->half ? 0x7FFFu : 0xFFFFu;
+        k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_tile_off,
+                                                  t->d_fx_slice0, t->d_pl, keys_in, vals_in);
+        CM2_LAUNCH_OK();
+        int end_bit = 17;
+        while (((int64_t)1 << (end_bit - 16)) <= nslices && end_bit < 64) ++end_bit;
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   ent.p, nv, 0, end_bit, st));
+        CM2_HIP(d_temp.alloc(tb + 16));
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   ent.p, nv, 0, end_bit, st));
+        CM2_HIP(d_counts.alloc(3 * nslices));
+        const int pgrid = (int)((nslices + 63) / 64);
+        k_fx_pack<false><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
+                                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                               nullptr, nullptr, nullptr);
+        CM2_LAUNCH_OK();
+        std::vector<uint32_t> counts((size_t)(3 * nslices));
+        CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(),
+                               hipMemcpyDeviceToHost, st));
+        CM2_HIP(hipStreamSynchronize(st));
+        int64_t nfull = 0, nover = 0;
+        double gsum = 0.0;
+        for (int64_t s = 0; s < nslices; ++s) {
+            meta[(size_t)s] = make_uint2((uint32_t)ngroups, (uint32_t)ntrun);
+            tent_off[(size_t)s] = (uint32_t)ntent;
+            ngroups += counts[(size_t)(3 * s)];
+            ntrun += counts[(size_t)(3 * s + 1)];
+            ntent += counts[(size_t)(3 * s + 2)];
+            if (counts[(size_t)(3 * s)] > (uint32_t)kFxT) ++nover;
+            if (k0[(size_t)s + 1] - k0[(size_t)s] == S) {
+                ++nfull;
+                gsum += counts[(size_t)(3 * s)];
+            }
+        }
+        meta[(size_t)nslices] = make_uint2((uint32_t)ngroups, (uint32_t)ntrun);
+        tent_off[(size_t)nslices] = (uint32_t)ntent;
+        CM2_CHECK(ngroups < ((int64_t)1 << 32) && ntent < ((int64_t)1 << 32),
+                  "cm2_tiles: fixed-order lists exceed 32-bit offsets");
+        *mean_groups = nfull ? gsum / (double)nfull : 0.0;
+        *over = (double)nover / (double)nslices;
+        // (+1 group: a slice without groups at the very end still loads "its" group 0)
+        const int64_t ng1 = ngroups + 1, nt1 = ntent ? ntent : 1;
+        CM2_HIP(hipMalloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
+        CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
+                               hipMemcpyHostToDevice, st));
+        CM2_HIP(d_tent_off.alloc(tent_off.size()));
+        CM2_HIP(hipMemcpyAsync(d_tent_off, tent_off.data(), sizeof(uint32_t) * tent_off.size(),
+                               hipMemcpyHostToDevice, st));
+        CM2_HIP(hipMalloc(&t->d_fx_gent, sizeof(uint4) * ng1));
+        CM2_HIP(hipMalloc(&t->d_fx_trun, sizeof(uint2) * (ntrun + 1)));
+        CM2_HIP(hipMalloc(&t->d_fx_tent, sizeof(uint32_t) * nt1));
+        if (t->pol > 1) {
+            CM2_HIP(hipMalloc(&t->d_fx_ga, sizeof(double) * 4 * ng1));
+            CM2_HIP(hipMalloc(&t->d_fx_ta, sizeof(double) * nt1));
+            if (!t->half) {
+                CM2_HIP(hipMalloc(&t->d_fx_gb, sizeof(double) * 4 * ng1));
+                CM2_HIP(hipMalloc(&t->d_fx_tb, sizeof(double) * nt1));
+            }
+        }
+        const uint2 last = make_uint2((uint32_t)ntent, 0);
+        CM2_HIP(hipMemcpyAsync(t->d_fx_trun + ntrun, &last, sizeof(uint2), hipMemcpyHostToDevice, st));
+        k_fx_pack<true><<<pgrid, 64, 0, st>>>(
+            nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos, t->half ? nullptr : t->d_sin,
+            nullptr, t->d_fx_meta, d_tent_off, reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga,
+            t->d_fx_gb, t->d_fx_trun, t->d_fx_tent, t->d_fx_ta, t->d_fx_tb);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipStreamSynchronize(st));
+    } else {
+        CM2_HIP(hipMalloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
+        CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
+                               hipMemcpyHostToDevice, st));
+        CM2_HIP(hipMalloc(&t->d_fx_gent, sizeof(uint4)));
+        CM2_HIP(hipMalloc(&t->d_fx_trun, sizeof(uint2)));
+        CM2_HIP(hipMalloc(&t->d_fx_tent, sizeof(uint32_t)));
+        CM2_HIP(hipStreamSynchronize(st));
+    }
+    t->fx_S = S;
+    t->fx_ngroups = ngroups;
+    t->fx_nslices = nslices;
+    return 0;
+}
+
+template <int POL, bool HALF, int VPT>
+int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
+                   int64_t tile_hi, hipStream_t stream)
+{
+    const size_t lds = fx_lds_bytes(t, t->fx_S);
+    CM2_HIP(hipFuncSetAttribute((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
+        t->tp, t->npix, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
+        t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
+        reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
+        t->d_fx_tb, d_tod_tb, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+template <int POL, bool HALF>
+int fx_launch_vpt(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
+                  int64_t tile_hi, hipStream_t stream)
+{
+    const int vpt = (t->fx_S + kFxT - 1) / kFxT;
+    if (vpt <= 2) return fx_launch_inst<POL, HALF, 2>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+    return fx_launch_inst<POL, HALF, 4>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+}
+
+}  // namespace
+
+namespace cm2 {
+
+void fx_free(cm2_tiles *t) { fx_release(t); }
+
+int64_t fx_designed_bytes(const cm2_tiles *t)
+{
+    if (!t || !t->fx_S) return 0;
+    const int64_t per_group = 16 + (t->pol > 1 ? (t->half ? 32 : 64) : 0);
+    return 8 * t->nvalid + per_group * t->fx_ngroups + 8 * t->fx_nslices;
+}
+
+// plan of the fixed-order P^T, built on first use.  Slice length: a slice should fill most of
+// the workgroup's 512 groups but rarely more; the number of groups per sample depends on how
+// often a pixel is hit twice inside a slice, so it is measured: a trial plan with S = 1536 gives
+// the groups per slice, S is then set for ~0.92 x 512 groups and the plan rebuilt
+// (CM2_PT_SLICE = samples fixes S).
+int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
+{
+    cm2_tiles *t = const_cast<cm2_tiles *>(tc);
+    *use = false;
+    if (!t->pt_fixed) return 0;
+    if (t->fx_S == 0) {
+        int smax = 4 * kFxT;                             // 4 staged values per thread at most
+        while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
+        if (fx_lds_bytes(t, smax) > 159 * 1024) {        // the tile alone fills LDS: atomics
+            t->pt_fixed = 0;
+            return 0;
+        }
+        int forced = 0;
+        if (const char *e = getenv("CM2_PT_SLICE")) forced = atoi(e);
+        double mean = 0.0, over = 0.0;
+        if (forced >= 64 && forced <= 4 * kFxT) {
+            if (int rc = fx_build(t, forced < smax ? forced : smax, st, &mean, &over)) return rc;
+        } else {
+            int S = 1536 < smax ? 1536 : smax;
+            if (int rc = fx_build(t, S, st, &mean, &over)) return rc;
+            for (int iter = 0; iter < 3 && mean > 0.0; ++iter) {
+                int want = (int)(0.92 * kFxT * S / mean) / 64 * 64;
+                if (over > 0.10) want = want < S * 7 / 8 ? want : S * 7 / 8 / 64 * 64;
+                if (want > smax) want = smax;
+                if (want < 256) want = 256;
+                const bool close_enough = want >= S * 15 / 16 && want <= S * 17 / 16 && over <= 0.10;
+                if (close_enough || want == S) break;
+                S = want;
+                if (int rc = fx_build(t, S, st, &mean, &over)) return rc;
+            }
+        }
+    }
+    *use = true;
+    return 0;
+}
+
+int fx_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
+              int64_t tile_hi, hipStream_t stream)
+{
+    if (tile_hi <= tile_lo) return 0;
+    if (t->pol == 1) return fx_launch_vpt<1, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+    if (t->pol == 2)
+        return t->half ? fx_launch_vpt<2, true>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream)
+                       : fx_launch_vpt<2, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+    return t->half ? fx_launch_vpt<3, true>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream)
+                   : fx_launch_vpt<3, false>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+}
+
+}  // namespace cm2

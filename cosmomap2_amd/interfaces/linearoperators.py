@@ -185,12 +185,22 @@ class _TileHandle(object):
 
     def __init__(self, handle):
         self.h = handle
-        info = (ctypes.c_int64 * 8)()
-        _hip.call("cm2_tiles_info", handle, info)
+        info = self._info()
         self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info[:5]]
         self.half_angle = bool(info[5])
         self.pt_fixed = bool(info[6])
         self.plan_id = int(info[7])
+
+    def _info(self):
+        info = (ctypes.c_int64 * 10)()
+        _hip.call("cm2_tiles_info", self.h, info)
+        return info
+
+    def fixed_order_info(self):
+        """(slice length, designed bytes per application) of the fixed-order P^T lists; zeros
+        until the first P^T has built them."""
+        info = self._info()
+        return int(info[8]), int(info[9])
 
     def set_pt_order(self, fixed):
         """True: P^T sums every pixel in time order (default); False: LDS atomics."""

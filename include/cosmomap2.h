@@ -92,11 +92,13 @@ int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
                      const double *d_sin, int64_t nt, int64_t npix, int pol, int tile_pixels,
                      int64_t slice_samples, void *stream);
 int cm2_tiles_destroy(cm2_tiles *t);
-/* h_info[0..7] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
+/* h_info[0..9] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
  * 1 if the plan stores one half-angle value per sample instead of cos and sin (done when every
  * (cos, sin) pair is on the unit circle to 1e-14; the kernels rebuild cos = +-(1-h^2)/(1+h^2),
  * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample), 1 if P^T sums in
- * fixed (time) order, the plan's id (unique per plan in this process) */
+ * fixed (time) order, the plan's id (unique per plan in this process), slice length of the
+ * fixed-order lists (0 until the first P^T builds them) and the bytes one fixed-order P^T is
+ * designed to read (TOD + padded lists) */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* fixed != 0: P^T adds each pixel's terms in time order (reference order, reproducible);
  * fixed == 0: LDS / global atomics */

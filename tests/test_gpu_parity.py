@@ -102,7 +102,8 @@ def test_pointing_bitexact(cm, oracle, pol, nt, npix):
 
 @pytest.mark.parametrize("angles", ["half", "full"])
 @pytest.mark.parametrize("pol", [1, 2, 3])
-@pytest.mark.parametrize("nt,npix,tp", [(300000, 5000, 2048), (50000, 100, 64), (400000, 70000, 1024)])
+@pytest.mark.parametrize("nt,npix,tp", [(300000, 5000, 2048), (50000, 100, 64), (400000, 70000, 1024),
+                                      (40000, 20, 64)])    # the last two: runs of 5..60 and > 60 per slice
 def test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles):
     """Tile-bucketed order: permutations exact, fixed-order scatter bit-exact / reproducible,
     LDS-atomic scatter to rounding, the tiled P^T N P equal to the exact three stages to 1e-13.  The gather is bit-exact when the tile
