@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void k_fx_keys(int64_t nvalid, int64_t ntiles,
 // One thread per slice walks the slice's sorted entries and packs the runs into groups.
 // WRITE = false: counts[3 s + {0, 1, 2}] = groups, tail runs, tail entries of slice s.
 // WRITE = true: the groups / tail lists are written at the offsets of the slice.
-template <bool WRITE>
+// NANG = angle arrays to carry along: 0 (pol = 1), 1 (half angle), 2 (cos and sin); a compile-time
+// switch, because a run-time "if (ga)" does not keep the compiler from issuing the a_tb load.
+template <bool WRITE, int NANG>
 __global__ __launch_bounds__(64) void k_fx_pack(
     int64_t nslices, uint32_t qmask, const int64_t *__restrict__ slice_k0,
     const uint32_t *__restrict__ ent, const double *__restrict__ a_tb,
@@ -307,15 +309,15 @@ __global__ __launch_bounds__(64) void k_fx_pack(
         const int64_t at = 4 * g + slot;
         gent[at] = w | (level << 28);
         const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
-        if (ga) ga[at] = a_tb[src];
-        if (gb) gb[at] = b_tb[src];
+        if (NANG >= 1) ga[at] = a_tb[src];
+        if (NANG == 2) gb[at] = b_tb[src];
     };
     auto close = [&]() {
         if (WRITE)
             for (int slot = fill; slot < 4; ++slot) {
                 gent[4 * g + slot] = kFxNull;
-                if (ga) ga[4 * g + slot] = 0.0;
-                if (gb) gb[4 * g + slot] = 0.0;
+                if (NANG >= 1) ga[4 * g + slot] = 0.0;
+                if (NANG == 2) gb[4 * g + slot] = 0.0;
             }
         ++g;
         ++ng;
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(64) void k_fx_pack(
                     const uint32_t w = ent[k0 + i + m];
                     tent[e0 + m] = w;
                     const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
-                    if (ta) ta[e0 + m] = a_tb[src];
-                    if (tb) tb[e0 + m] = b_tb[src];
+                    if (NANG >= 1) ta[e0 + m] = a_tb[src];
+                    if (NANG == 2) tb[e0 + m] = b_tb[src];
                 }
             }
             ++ntr;
@@ -432,7 +434,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
                                                    ent.p, nv, 0, end_bit, st));
         CM2_HIP(d_counts.alloc(3 * nslices));
         const int pgrid = (int)((nslices + 63) / 64);
-        k_fx_pack<false><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
+        k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
                                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                nullptr, nullptr, nullptr);
         CM2_LAUNCH_OK();
@@ -481,10 +483,15 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         }
         const uint2 last = make_uint2((uint32_t)ntent, 0);
         CM2_HIP(hipMemcpyAsync(t->d_fx_trun + ntrun, &last, sizeof(uint2), hipMemcpyHostToDevice, st));
-        k_fx_pack<true><<<pgrid, 64, 0, st>>>(
-            nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos, t->half ? nullptr : t->d_sin,
-            nullptr, t->d_fx_meta, d_tent_off, reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga,
-            t->d_fx_gb, t->d_fx_trun, t->d_fx_tent, t->d_fx_ta, t->d_fx_tb);
+#define CM2_FX_PACK(NANG)                                                                       \
+    k_fx_pack<true, NANG><<<pgrid, 64, 0, st>>>(                                                  \
+        nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos, t->half ? nullptr : t->d_sin,  \
+        nullptr, t->d_fx_meta, d_tent_off, reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, \
+        t->d_fx_gb, t->d_fx_trun, t->d_fx_tent, t->d_fx_ta, t->d_fx_tb)
+        if (t->pol == 1) CM2_FX_PACK(0);
+        else if (t->half) CM2_FX_PACK(1);
+        else CM2_FX_PACK(2);
+#undef CM2_FX_PACK
         CM2_LAUNCH_OK();
         CM2_HIP(hipStreamSynchronize(st));
     } else {
