@@ -40,7 +40,7 @@ struct cm2_tiles {
     std::vector<int64_t> tile_off;      // [ntiles+1] first TB position of every tile (host)
     int64_t *d_tile_off = nullptr;
     int64_t *d_fx_slice0 = nullptr;     // [ntiles+1] first slice of every tile
-    uint2 *d_fx_meta = nullptr;         // [nslices+1] {first group, first tail run} of every slice
+    uint2 *d_fx_meta = nullptr;         // [nslices+1] {first group, first tail run | max level << 28}
     uint4 *d_fx_gent = nullptr;         // [ngroups] 4 entries: pl word | offset in slice << 16 | level << 28
     double *d_fx_ga = nullptr, *d_fx_gb = nullptr;   // [4 ngroups] half angle (or cos, sin)
     uint2 *d_fx_trun = nullptr;         // [ntail runs + 1] {first tail entry, pixel in tile}

@@ -14,17 +14,26 @@
 //   group  = 4 entries + their 4 half angles (or cos, sin), padded with null entries
 //   thread t of the workgroup owns group t of the slice: it reads its 16 + 32 bytes with
 //   three 16-byte loads straight into registers -- two slices ahead of the one it reduces --,
-//   picks the 4 TOD values out of the slice staged in LDS, and adds each run to the pixel's LDS
-//   accumulators one term after the other.  A pixel is touched by one thread per slice and the
-//   slices follow each other in time, so each sum is the reference's, term by term.
+//   picks the 4 TOD values out of the slice staged in LDS, and adds its entries to the pixels' LDS
+//   accumulators one after the other (ds_add_f64: adds of one thread to one address happen in
+//   program order).  A pixel is touched by one thread per pass and the slices follow each other
+//   in time, so each sum is the reference's, term by term.
 //
 // Runs of 5..60 samples are cut into pieces of 4 in consecutive groups, piece p carrying
-// level p: the workgroup makes one pass per level, separated by a barrier, so the pieces are
-// added in order.  Longer runs (a pixel hit > 60 times inside one slice: hot pixels) are kept
-// out of the groups and walked by one thread each from a separate list.
+// level p: the workgroup makes one pass per level (the slice's highest level is known at plan
+// time), separated by a barrier, so the pieces are added in order.  Longer runs (a pixel hit
+// > 60 times inside one slice: hot pixels) are kept out of the groups and walked by one thread
+// each from a separate list.
 //
-// HBM per sample: 8 B TOD + ~1.2 x 12 B of list (padding of the groups) = ~22.5 B, every load
-// 16 B per lane and coalesced.
+// HBM per sample: 8 B TOD + ~1.14 x 12 B of list (padding of the groups) = ~21.7 B, every load
+// 16 B per lane and coalesced.  What the kernel had to get right to stream at HBM speed
+// (measured, 1e8 samples, nside 256: 0.37 ms with the reduction switched off, 0.45 ms with it):
+//   * no register spill in the slice loop: a scratch reload is a VMEM operation, and waiting for
+//     it (vmcnt counts in order) drains every prefetched load issued before it;
+//   * unconditional loads (clamped indices) and a scheduling barrier per slice, so that the
+//     compiler waits with s_waitcnt vmcnt(N > 0) for the oldest slice only;
+//   * LDS adds instead of a load / add / store chain per run (12 of 24 LDS operations less per
+//     thread and slice, and no dependent round trip).
 #include "cm2_tiles.h"
 
 #include <hipcub/hipcub.hpp>
@@ -72,13 +81,21 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     uint4 pe[D];
     double2 pa[D][2], pb[D][2];
     uint2 pm[D][2];                                      // meta of slice j and j + 1
+    // {first group, first tail run} of the NEXT slice to fetch and of its successor: loaded one
+    // fetch ahead, so that the group addresses never wait for them
+    uint2 nx0 = meta[s0], nx1 = meta[s0 + (nsl > 0 ? 1 : 0)];
     auto fetch = [&](int slot, int j) {
         const int jc = j < nsl ? j : nsl - 1;
         const int64_t kb = k_begin + (int64_t)jc * S;
         const int len = (int)((k_end - kb < S) ? k_end - kb : S);
-        const uint2 m0 = meta[s0 + jc], m1 = meta[s0 + jc + 1];
+        const uint2 m0 = nx0, m1 = nx1;
         pm[slot][0] = m0;
         pm[slot][1] = m1;
+        {
+            const int jn = j + 1 < nsl ? j + 1 : nsl - 1;
+            nx0 = meta[s0 + jn];
+            nx1 = meta[s0 + jn + 1];
+        }
         const uint32_t G = m1.x - m0.x;
         const int64_t g = (int64_t)m0.x + ((uint32_t)tid < G ? tid : 0);
 #pragma unroll
@@ -114,62 +131,28 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
         t1 = v * cc;
         t2 = v * ss;
     };
-    auto tile_load = [&](int q, double &a0, double &a1, double &a2) {
+    // tile[pixel] += term with the LDS adder (ds_add_f64, nothing returned): the same IEEE addition
+    // the serial loop performs on its accumulator, and the adds one thread issues to one address
+    // are performed in program order -- so a run is summed term after term without a register
+    // round trip.  Within a pass no two threads touch the same pixel.
+    auto tile_add = [&](int q, double v, double t1, double t2) {
         if (POL == 1) {
-            a0 = tile[q];
+            atomicAdd(&tile[q], v);
         } else if (POL == 2) {
-            a1 = tile[2 * q];
-            a2 = tile[2 * q + 1];
+            atomicAdd(&tile[2 * q], t1);
+            atomicAdd(&tile[2 * q + 1], t2);
         } else {
-            a0 = tile[3 * q];
-            a1 = tile[3 * q + 1];
-            a2 = tile[3 * q + 2];
+            atomicAdd(&tile[3 * q], v);
+            atomicAdd(&tile[3 * q + 1], t1);
+            atomicAdd(&tile[3 * q + 2], t2);
         }
     };
-    auto tile_store = [&](int q, double a0, double a1, double a2) {
-        if (POL == 1) {
-            tile[q] = a0;
-        } else if (POL == 2) {
-            tile[2 * q] = a1;
-            tile[2 * q + 1] = a2;
-        } else {
-            tile[3 * q] = a0;
-            tile[3 * q + 1] = a1;
-            tile[3 * q + 2] = a2;
-        }
-    };
-    // one group: its runs added to the tile accumulators, term after term
+    // one group: its entries added to the tile accumulators in list (= time) order
     auto reduce_group = [&](const uint32_t (&w)[4], const double (&v)[4], const double (&t1)[4],
                             const double (&t2)[4]) {
-        int q[4];
-        bool ok[4];
-        double l0[4], l1[4], l2[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            ok[m] = w[m] != kFxNull;
-            q[m] = ok[m] ? (int)(w[m] & QM) : 0;
-            l0[m] = l1[m] = l2[m] = 0.0;
-            tile_load(q[m], l0[m], l1[m], l2[m]);       // (runs of a group are different pixels)
-        }
-        double a0 = l0[0], a1 = l1[0], a2 = l2[0];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m > 0 && ok[m] && q[m] != q[m - 1]) {
-                tile_store(q[m - 1], a0, a1, a2);
-                a0 = l0[m];
-                a1 = l1[m];
-                a2 = l2[m];
-            }
-            if (ok[m]) {
-                if (POL != 2) a0 += v[m];
-                if (POL > 1) {
-                    a1 += t1[m];
-                    a2 += t2[m];
-                }
-            }
-            if (ok[m] && (m == 3 || w[m + 1 < 4 ? m + 1 : 3] == kFxNull))
-                tile_store(q[m], a0, a1, a2);
-        }
+        for (int m = 0; m < 4; ++m)
+            if (w[m] != kFxNull) tile_add((int)(w[m] & QM), v[m], t1[m], t2[m]);
     };
 
     if (nsl > 0) {
@@ -196,7 +179,8 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
             }
             __syncthreads();
             fetch(dd, j + D);
-            const uint32_t G = m1.x - m0.x, ntail = m1.y - m0.y;
+            const uint32_t G = m1.x - m0.x, ntail = (m1.y & 0x0FFFFFFFu) - (m0.y & 0x0FFFFFFFu);
+            const int maxlevel = (int)(m0.y >> 28);      // highest level in this slice (plan time)
             for (uint32_t g0 = 0; g0 < G || g0 == 0; g0 += kFxT) {
                 const bool mine = g0 + tid < G;
                 if (g0 > 0) {                             // more groups than threads: direct loads
@@ -225,32 +209,23 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
                 if (g0 == 0) {
                     // runs too long for the groups: one thread walks a whole run
                     for (uint32_t r = tid; r < ntail; r += kFxT) {
-                        const uint2 r0 = trun[(int64_t)m0.y + r], r1 = trun[(int64_t)m0.y + r + 1];
+                        const uint2 r0 = trun[(int64_t)(m0.y & 0x0FFFFFFFu) + r],
+                                    r1 = trun[(int64_t)(m0.y & 0x0FFFFFFFu) + r + 1];
                         const int q = (int)r0.y;
-                        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-                        tile_load(q, a0, a1, a2);
                         for (uint32_t e = r0.x; e < r1.x; ++e) {
                             const uint32_t we = tent[e];
                             const double ve = vbuf[(we >> 16) & 0xFFFu];
                             double u1 = 0.0, u2 = 0.0;
                             terms(we, ANG ? ta[e] : 0.0, TWO ? tb[e] : 0.0, ve, u1, u2);
-                            if (POL != 2) a0 += ve;
-                            if (POL > 1) {
-                                a1 += u1;
-                                a2 += u2;
-                            }
+                            tile_add(q, ve, u1, u2);
                         }
-                        tile_store(q, a0, a1, a2);
                     }
                 }
                 // one pass per level: piece p of a long run is added after piece p - 1
-                int p = 0;
-                int more;
-                do {
+                for (int p = 0; p <= maxlevel; ++p) {
                     if (mine && level == p) reduce_group(w, v, t1, t2);
-                    more = __syncthreads_or(mine && level > p);
-                    ++p;
-                } while (more);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -283,7 +258,7 @@ __global__ __launch_bounds__(256) void k_fx_keys(int64_t nvalid, int64_t ntiles,
 }
 
 // One thread per slice walks the slice's sorted entries and packs the runs into groups.
-// WRITE = false: counts[3 s + {0, 1, 2}] = groups, tail runs, tail entries of slice s.
+// WRITE = false: counts[4 s + {0, 1, 2, 3}] = groups, tail runs, tail entries, highest level.
 // WRITE = true: the groups / tail lists are written at the offsets of the slice.
 // NANG = angle arrays to carry along: 0 (pol = 1), 1 (half angle), 2 (cos and sin); a compile-time
 // switch, because a run-time "if (ga)" does not keep the compiler from issuing the a_tb load.
@@ -302,7 +277,7 @@ __global__ __launch_bounds__(64) void k_fx_pack(
     const int64_t k0 = slice_k0[s];
     const int len = (int)(slice_k0[s + 1] - k0);
     int64_t g = WRITE ? (int64_t)meta[s].x : 0;
-    uint32_t ntr = 0, nte = 0, ng = 0;
+    uint32_t ntr = 0, nte = 0, ng = 0, maxlev = 0;
     int fill = 0;
     auto put = [&](int slot, uint32_t w, uint32_t level) {
         if (!WRITE) return;
@@ -331,7 +306,7 @@ __global__ __launch_bounds__(64) void k_fx_pack(
         if (L > 4 * (kFxMaxLevel + 1)) {
             if (WRITE) {
                 const uint32_t e0 = tent_off[s] + nte;
-                trun[(int64_t)meta[s].y + ntr] = make_uint2(e0, q);
+                trun[(int64_t)(meta[s].y & 0x0FFFFFFFu) + ntr] = make_uint2(e0, q);
                 for (int m = 0; m < L; ++m) {
                     const uint32_t w = ent[k0 + i + m];
                     tent[e0 + m] = w;
@@ -349,6 +324,7 @@ __global__ __launch_bounds__(64) void k_fx_pack(
             if (fill == 4) close();
         } else {
             if (fill > 0) close();
+            if ((uint32_t)((L - 1) / 4) > maxlev) maxlev = (uint32_t)((L - 1) / 4);
             for (int m = 0; m < L; ++m) {
                 put(fill, ent[k0 + i + m], (uint32_t)(m / 4));
                 if (++fill == 4) close();
@@ -359,16 +335,17 @@ __global__ __launch_bounds__(64) void k_fx_pack(
     }
     if (fill > 0) close();
     if (!WRITE) {
-        counts[3 * s] = ng;
-        counts[3 * s + 1] = ntr;
-        counts[3 * s + 2] = nte;
+        counts[4 * s] = ng;
+        counts[4 * s + 1] = ntr;
+        counts[4 * s + 2] = nte;
+        counts[4 * s + 3] = maxlev;
     }
 }
 
 size_t fx_lds_bytes(const cm2_tiles *t, int S)
 {
     int vpt = (S + kFxT - 1) / kFxT;
-    vpt = vpt <= 2 ? 2 : 4;
+    vpt = vpt <= 2 ? 2 : vpt;
     return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT);
 }
 
@@ -432,34 +409,36 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         CM2_HIP(d_temp.alloc(tb + 16));
         CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
                                                    ent.p, nv, 0, end_bit, st));
-        CM2_HIP(d_counts.alloc(3 * nslices));
+        CM2_HIP(d_counts.alloc(4 * nslices));
         const int pgrid = (int)((nslices + 63) / 64);
         k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
                                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                nullptr, nullptr, nullptr);
         CM2_LAUNCH_OK();
-        std::vector<uint32_t> counts((size_t)(3 * nslices));
+        std::vector<uint32_t> counts((size_t)(4 * nslices));
         CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(),
                                hipMemcpyDeviceToHost, st));
         CM2_HIP(hipStreamSynchronize(st));
         int64_t nfull = 0, nover = 0;
         double gsum = 0.0;
         for (int64_t s = 0; s < nslices; ++s) {
-            meta[(size_t)s] = make_uint2((uint32_t)ngroups, (uint32_t)ntrun);
+            // .y = first tail run | highest level of the slice << 28
+            meta[(size_t)s] = make_uint2((uint32_t)ngroups,
+                                         (uint32_t)ntrun | (counts[(size_t)(4 * s + 3)] << 28));
             tent_off[(size_t)s] = (uint32_t)ntent;
-            ngroups += counts[(size_t)(3 * s)];
-            ntrun += counts[(size_t)(3 * s + 1)];
-            ntent += counts[(size_t)(3 * s + 2)];
-            if (counts[(size_t)(3 * s)] > (uint32_t)kFxT) ++nover;
+            ngroups += counts[(size_t)(4 * s)];
+            ntrun += counts[(size_t)(4 * s + 1)];
+            ntent += counts[(size_t)(4 * s + 2)];
+            if (counts[(size_t)(4 * s)] > (uint32_t)kFxT) ++nover;
             if (k0[(size_t)s + 1] - k0[(size_t)s] == S) {
                 ++nfull;
-                gsum += counts[(size_t)(3 * s)];
+                gsum += counts[(size_t)(4 * s)];
             }
         }
         meta[(size_t)nslices] = make_uint2((uint32_t)ngroups, (uint32_t)ntrun);
         tent_off[(size_t)nslices] = (uint32_t)ntent;
-        CM2_CHECK(ngroups < ((int64_t)1 << 32) && ntent < ((int64_t)1 << 32),
-                  "cm2_tiles: fixed-order lists exceed 32-bit offsets");
+        CM2_CHECK(ngroups < ((int64_t)1 << 32) && ntent < ((int64_t)1 << 32) &&
+                  ntrun < ((int64_t)1 << 28), "cm2_tiles: fixed-order lists exceed their offsets");
         *mean_groups = nfull ? gsum / (double)nfull : 0.0;
         *over = (double)nover / (double)nslices;
         // (+1 group: a slice without groups at the very end still loads "its" group 0)
@@ -531,6 +510,7 @@ int fx_launch_vpt(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int
 {
     const int vpt = (t->fx_S + kFxT - 1) / kFxT;
     if (vpt <= 2) return fx_launch_inst<POL, HALF, 2>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
+    if (vpt == 3) return fx_launch_inst<POL, HALF, 3>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
     return fx_launch_inst<POL, HALF, 4>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
 }
 
