@@ -236,6 +236,58 @@ static inline int pow2_at_least(int r)
     return p;
 }
 
+// Wide form for r = 2 LPR with LPR a power of two <= 32 (r = 16, 32, 64 ...): LPR lanes read one
+// row with 16-byte loads (a wave covers 64 / LPR rows per instruction, 8 instructions in
+// flight), every lane keeps the partial sums of its two columns, and the lanes / waves of a
+// workgroup are combined in LDS in a fixed order.  Streams Z at HBM speed (the narrow kernel
+// above issues 8-byte loads, one row per 32 lanes: 3.1 TB/s at n = 2.4e6, r = 32).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_Zt_partial_wide(int64_t n, int64_t rows_per_blk,
+                                                          const double *__restrict__ Z,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ partial)
+{
+    constexpr int R = 2 * LPR, RPW = 64 / LPR, RSTEP = 4 * RPW, U = 8;
+    __shared__ double lds[256 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rg = lane / LPR;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    double a0 = 0.0, a1 = 0.0;
+    int64_t i = r0 + wave * RPW + rg;
+    for (; i + (U - 1) * RSTEP < r1; i += U * RSTEP) {
+        double2 z[U];
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            z[u] = *reinterpret_cast<const double2 *>(Z + (i + u * RSTEP) * R + 2 * sub);
+            xv[u] = x[i + u * RSTEP];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a0 += z[u].x * xv[u];
+            a1 += z[u].y * xv[u];
+        }
+    }
+    for (; i < r1; i += RSTEP) {
+        const double2 z = *reinterpret_cast<const double2 *>(Z + i * R + 2 * sub);
+        const double xv = x[i];
+        a0 += z.x * xv;
+        a1 += z.y * xv;
+    }
+    lds[2 * threadIdx.x] = a0;
+    lds[2 * threadIdx.x + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < R) {                 // column c: its lanes are sub = c / 2 of every row group
+        const int c = threadIdx.x;
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int g = 0; g < RPW; ++g) s += lds[2 * (64 * w + g * LPR + c / 2) + (c & 1)];
+        partial[(int64_t)blockIdx.x * R + c] = s;
+    }
+}
+
 extern "C" int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d_x, double *d_out,
                             double *d_work, void *stream_)
 {
@@ -243,6 +295,20 @@ extern "C" int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d
     CM2_CHECK(d_Z && d_x && d_out && d_work, "cm2_Zt_apply: NULL argument");
     hipStream_t stream = as_stream(stream_);
     const int rp = pow2_at_least(r);
+    if ((r == 16 || r == 32 || r == 64) && n >= 4096 && (reinterpret_cast<uintptr_t>(d_Z) & 15) == 0) {
+        const int rstep = 4 * (128 / r);
+        int nblk = kRedBlocks;
+        int64_t rows = (n + nblk - 1) / nblk;
+        rows = ((rows + rstep - 1) / rstep) * rstep;
+        nblk = (int)((n + rows - 1) / rows);
+        if (r == 16) k_Zt_partial_wide<8><<<nblk, kBlock, 0, stream>>>(n, rows, d_Z, d_x, d_work);
+        else if (r == 32) k_Zt_partial_wide<16><<<nblk, kBlock, 0, stream>>>(n, rows, d_Z, d_x, d_work);
+        else k_Zt_partial_wide<32><<<nblk, kBlock, 0, stream>>>(n, rows, d_Z, d_x, d_work);
+        CM2_LAUNCH_OK();
+        k_Zt_final<<<1, kBlock, 0, stream>>>(nblk, r, rp, d_work, d_out);
+        CM2_LAUNCH_OK();
+        return 0;
+    }
     const int rstep = 256 / rp;
     int nblk = red_blocks(n);
     int64_t rows = (n + nblk - 1) / nblk;
@@ -375,6 +441,115 @@ __global__ __launch_bounds__(256) void k_gemm_tn_final(int nparts, int rr,
     E[e] = acc;
 }
 
+// The same contraction for R = 32 h (h = 1, 2) with 16-byte loads: lane (m, k) reads the column
+// PAIR (32 g + 2 m, 32 g + 2 m + 1) of row i0 + k, which feeds the MFMA tiles 2 g and 2 g + 1 --
+// tile a = 2 g + e holds the columns 32 g + 2 m + e, m = 0..15 -- so one dwordx4 load supplies
+// two A (or B) operands; the tiles are un-permuted when the partial E is written.  Four row
+// quads are in flight per wave, and a workgroup's four waves are combined in LDS, so that 512
+// workgroups (two per CU) leave 512 partial matrices like the kernel above.
+template <int H>
+__global__ __launch_bounds__(256) void k_gemm_tn_mfma_pairs(int64_t n, const double *__restrict__ Z1,
+                                                             const double *__restrict__ Z2,
+                                                             double *__restrict__ work)
+{
+    constexpr int R = 32 * H, T = 2 * H, U = 4;
+    __shared__ double red[3][R * R > 1024 ? 1024 : R * R];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave = (int)(blockIdx.x * 4 + w);
+    const int nwaves = (int)gridDim.x * 4;
+    const int m = lane & 15, k = lane >> 4;
+    double4_t acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int64_t chunk = (n + nwaves - 1) / nwaves;
+    chunk = (chunk + 3) & ~(int64_t)3;
+    const int64_t i_begin = (int64_t)wave * chunk;
+    int64_t i_end = i_begin + chunk;
+    if (i_end > n) i_end = n;
+    int64_t i0 = i_begin;
+    for (; i0 + 4 * U <= i_end; i0 += 4 * U) {
+        double2 av[U][H], bv[U][H];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + 4 * u + k;
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                av[u][g] = *reinterpret_cast<const double2 *>(Z1 + i * R + 32 * g + 2 * m);
+                bv[u][g] = *reinterpret_cast<const double2 *>(Z2 + i * R + 32 * g + 2 * m);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    const double x = (a & 1) ? av[u][a >> 1].y : av[u][a >> 1].x;
+                    const double y = (b & 1) ? bv[u][b >> 1].y : bv[u][b >> 1].x;
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a][b], 0, 0, 0);
+                }
+    }
+    for (; i0 < i_end; i0 += 4) {
+        const int64_t i = i0 + k;
+        const bool ok = i < i_end;
+        double2 av[H], bv[H];
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            av[g] = ok ? *reinterpret_cast<const double2 *>(Z1 + i * R + 32 * g + 2 * m) : make_double2(0.0, 0.0);
+            bv[g] = ok ? *reinterpret_cast<const double2 *>(Z2 + i * R + 32 * g + 2 * m) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                const double x = (a & 1) ? av[a >> 1].y : av[a >> 1].x;
+                const double y = (b & 1) ? bv[b >> 1].y : bv[b >> 1].x;
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a][b], 0, 0, 0);
+            }
+    }
+    // E entry of accumulator register j of tile (a, b): row 32 (a >> 1) + 2 ((lane >> 4) + 4 j) + (a & 1),
+    // column 32 (b >> 1) + 2 (lane & 15) + (b & 1).  Waves 1..3 hand their partials to wave 0
+    // through LDS, one 1024-entry slab at a time (R = 64: four slabs), added in wave order.
+    double *out = work + (int64_t)blockIdx.x * R * R;
+    constexpr int SLAB = 1024, NSLAB = R * R / SLAB;
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        // slab sl = rows [16 sl * 32 / R ...): with R = 32 one slab is the whole matrix; with
+        // R = 64 slab sl holds the E rows 16 sl .. 16 sl + 15
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 32 * (a >> 1) + 2 * ((lane >> 4) + 4 * j) + (a & 1);
+                    const int col = 32 * (b >> 1) + 2 * (lane & 15) + (b & 1);
+                    const int e = row * R + col;
+                    if (e / SLAB == sl) {
+                        if (w > 0) red[w - 1][e % SLAB] = acc[a][b][j];
+                    }
+                }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = 32 * (a >> 1) + 2 * ((lane >> 4) + 4 * j) + (a & 1);
+                        const int col = 32 * (b >> 1) + 2 * (lane & 15) + (b & 1);
+                        const int e = row * R + col;
+                        if (e / SLAB == sl)
+                            out[e] = ((acc[a][b][j] + red[0][e % SLAB]) + red[1][e % SLAB]) + red[2][e % SLAB];
+                    }
+        }
+    }
+}
+
 extern "C" int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const double *d_Z2,
                            double *d_E, double *d_work, void *stream_)
 {
@@ -385,7 +560,12 @@ extern "C" int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const 
     const int rr = r1 * r2;
     int nparts;
     const bool mfma = (r1 % 16 == 0) && (r2 % 16 == 0) && r1 <= 64 && r2 <= 64 && r1 == r2;
-    if (mfma) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_Z1) | reinterpret_cast<uintptr_t>(d_Z2)) & 15) == 0;
+    if (mfma && aligned && (r1 == 32 || r1 == 64)) {
+        nparts = kGemmBlocks * 4;                       // one partial per workgroup
+        if (r1 == 32) k_gemm_tn_mfma_pairs<1><<<nparts, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+        else k_gemm_tn_mfma_pairs<2><<<nparts, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
+    } else if (mfma) {
         nparts = kGemmBlocks * 4;
         if (r1 == 16) k_gemm_tn_mfma<1, 1><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
         else if (r1 == 32) k_gemm_tn_mfma<2, 2><<<kGemmBlocks, kBlock, 0, stream>>>(n, d_Z1, d_Z2, d_work);
@@ -469,6 +649,74 @@ __global__ __launch_bounds__(256) void k_m2_finish(
     }
 }
 
+// Wide form of the same tail for r = 2 LPR (r = 16, 32, 64): a workgroup takes 64 pixels
+// (64 POL rows of Z and of AZ); LPR lanes read one row with 16-byte loads, form the two partial
+// products with y, and a fixed butterfly over the LPR lanes gives Z y and AZ y of that row; the
+// row results go through LDS to one thread per pixel, which applies the M_BD block.  Z and AZ
+// are streamed once at HBM speed (the thread-per-pixel kernel above walks each 256-byte row
+// with 8-byte loads: 3.4 TB/s).
+template <int POL, int LPR>
+__global__ __launch_bounds__(256) void k_m2_finish_wide(
+    int64_t npix, const double *__restrict__ Z, const double *__restrict__ AZ,
+    const double *__restrict__ y, const double *__restrict__ res,
+    const double *__restrict__ hits, const double *__restrict__ c, const double *__restrict__ s,
+    const double *__restrict__ c2, const double *__restrict__ s2, const double *__restrict__ cs,
+    const double *__restrict__ det, const uint8_t *__restrict__ mask, double *__restrict__ out)
+{
+    constexpr int R = 2 * LPR, RPW = 64 / LPR, PB = 64, ROWS = PB * POL, RSTEP = 4 * RPW;
+    constexpr int NIT = (ROWS + RSTEP - 1) / RSTEP;
+    __shared__ double zy[ROWS], azy[ROWS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rg = lane / LPR;
+    const double y0 = y[2 * sub], y1 = y[2 * sub + 1];
+    const int64_t nblk = (npix + PB - 1) / PB;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row0 = blk * ROWS;
+        int64_t nrows = npix * POL - row0;
+        if (nrows > ROWS) nrows = ROWS;
+        double2 zv[NIT], av[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rl = it * RSTEP + wave * RPW + rg;
+            const int64_t i = row0 + (rl < nrows ? rl : nrows - 1);
+            zv[it] = *reinterpret_cast<const double2 *>(Z + i * R + 2 * sub);
+            av[it] = *reinterpret_cast<const double2 *>(AZ + i * R + 2 * sub);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            double pz = zv[it].x * y0 + zv[it].y * y1;
+            double pa = av[it].x * y0 + av[it].y * y1;
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1) {
+                pz += __shfl_xor(pz, off, 64);
+                pa += __shfl_xor(pa, off, 64);
+            }
+            const int rl = it * RSTEP + wave * RPW + rg;
+            if (sub == 0 && rl < ROWS) {
+                zy[rl] = pz;
+                azy[rl] = pa;
+            }
+        }
+        __syncthreads();
+        const int64_t j = blk * PB + threadIdx.x;
+        if (threadIdx.x < PB && j < npix) {
+            double t[3], o[3];
+#pragma unroll
+            for (int a = 0; a < POL; ++a) t[a] = res[POL * j + a] - azy[POL * threadIdx.x + a];
+            const bool m = mask[j] != 0;
+            if (POL == 1)
+                bd_inverse_block<1>(hits[j], 0, 0, 0, 0, 0, 0, m, t, o);
+            else if (POL == 2)
+                bd_inverse_block<2>(0, 0, 0, c2[j], s2[j], cs[j], det[j], m, t, o);
+            else
+                bd_inverse_block<3>(hits[j], c[j], s[j], c2[j], s2[j], cs[j], det[j], m, t, o);
+#pragma unroll
+            for (int a = 0; a < POL; ++a) out[POL * j + a] = o[a] + zy[POL * threadIdx.x + a];
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int cm2_m2_finish(int pol, int64_t npix, int r, const double *d_Z, const double *d_AZ,
                              const double *d_y, const double *d_res, const double *d_counts,
                              const double *d_cosine, const double *d_sine, const double *d_cos2,
@@ -479,6 +727,24 @@ extern "C" int cm2_m2_finish(int pol, int64_t npix, int r, const double *d_Z, co
     CM2_CHECK(r >= 1 && r <= 256, "cm2_m2_finish: r=%d out of range [1,256]", r);
     CM2_CHECK(d_Z && d_AZ && d_y && d_res && d_mask && d_out, "cm2_m2_finish: NULL argument");
     hipStream_t stream = as_stream(stream_);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_Z) | reinterpret_cast<uintptr_t>(d_AZ)) & 15) == 0;
+    if ((r == 16 || r == 32 || r == 64) && aligned && npix >= 64) {
+        const int64_t nblk = (npix + 63) / 64;
+        const int g = (int)(nblk < kNumCU * 16 ? nblk : kNumCU * 16);
+#define CM2_M2W(POL, LPR)                                                                       \
+    k_m2_finish_wide<POL, LPR><<<g, kBlock, 0, stream>>>(npix, d_Z, d_AZ, d_y, d_res, d_counts, \
+                                                        d_cosine, d_sine, d_cos2, d_sin2,      \
+                                                        d_sincos, d_det, d_mask, d_out)
+#define CM2_M2WP(POL)                                                                           \
+    do {                                                                                        \
+        if (r == 16) CM2_M2W(POL, 8); else if (r == 32) CM2_M2W(POL, 16); else CM2_M2W(POL, 32); \
+    } while (0)
+        if (pol == 1) CM2_M2WP(1); else if (pol == 2) CM2_M2WP(2); else CM2_M2WP(3);
+#undef CM2_M2WP
+#undef CM2_M2W
+        CM2_LAUNCH_OK();
+        return 0;
+    }
     const int g = grid_for(npix);
 #define CM2_M2(POL)                                                                          \
     k_m2_finish<POL><<<g, kBlock, 0, stream>>>(npix, r, d_Z, d_AZ, d_y, d_res, d_counts,     \
