@@ -726,7 +726,7 @@ class CoarseLO(_DeviceOp):
     (:994-1015).  Vectors already in HBM are multiplied by the explicit r x r inverse.
     """
 
-    def __init__(self, Z, Az, r, apply='LU'):
+    def __init__(self, Z, Az, r, apply='LU', allreduce=None):
         D.require_gpu()
         dZ, dAZ = _dev_matrix(Z), _dev_matrix(Az)
         n, rz = int(dZ.shape[0]), int(dZ.shape[1])
@@ -736,6 +736,8 @@ class CoarseLO(_DeviceOp):
         work = D.empty(int(_hip.load().cm2_gemm_tn_work_doubles(rz, rz)))
         _hip.call("cm2_gemm_tn", n, rz, rz, D.ptr(dZ), D.ptr(dAZ), D.ptr(dE), D.ptr(work),
                   D.stream())
+        if allreduce is not None:             # Z, Az hold this rank's rows only (sharding.py)
+            allreduce(dE)
         M = D.to_host(dE).reshape(rz, rz)                      # :1019  dgemm(Z, Az.T)
         self.E = M.copy()
         self.r = rz
@@ -793,10 +795,11 @@ class TwoLevelPreconditionerLO(_DeviceOp):
     that also applies the per-pixel M_BD block.
     """
 
-    def __init__(self, Mbd, Zd, AZd, E):
+    def __init__(self, Mbd, Zd, AZd, E, allreduce=None):
         if not isinstance(Mbd, BlockDiagonalPreconditionerLO):
             raise TypeError("Mbd must be a BlockDiagonalPreconditionerLO")
         self.Mbd, self.Zd, self.AZd, self.E = Mbd, Zd, AZd, E
+        self._allreduce = allreduce           # row-sharded vectors: Z^T r summed over ranks
         n = Mbd.size
         if Zd.nrows != n or AZd.nrows != n or Zd.ncols != AZd.ncols:
             raise lp.ShapeError("Z / AZ shapes do not match the map size %d" % n)
@@ -806,6 +809,8 @@ class TwoLevelPreconditionerLO(_DeviceOp):
     def mult(self, x):
         res = D.f64(x)
         y0 = self.Zd.rmult(res)
+        if self._allreduce is not None:
+            self._allreduce(y0)
         y = self.E._device_mult(y0)
         out = D.empty(self.Mbd.size)
         w = self.Mbd._w

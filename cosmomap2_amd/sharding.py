@@ -10,12 +10,21 @@ couples them:
 
     A x = sum_ranks  P_k^T N_k^-1 P_k x          (one all-reduce of pol*npix doubles)
 
-Map-domain vectors (x, r, p, z, Z) are replicated on every rank, so the two CG dot
-products and the preconditioners need no communication; after the all-reduce every
-rank holds bit-identical data and takes the same branches.  As a guard against a
-non-bitwise-identical collective, :func:`make_sync` max-reduces the 8-byte ||r||^2 the
-stop test reads.  Per PCG iteration the wire traffic is one all-reduce of the map
-(18.9 MB at nside 256, 75.5 MB at nside 512).
+Two layouts of the map-domain vectors (x, r, p, z, Z):
+
+* replicated (:class:`ShardedLO`): every rank holds whole vectors, so the two CG dot products
+  and the preconditioners need no communication; after the all-reduce every rank holds
+  bit-identical data and takes the same branches.  As a guard against a non-bitwise-identical
+  collective, :func:`make_sync` max-reduces the 8-byte ||r||^2 the stop test reads.  Per PCG
+  iteration the wire traffic is one all-reduce of the map (18.9 MB at nside 256, 75.5 MB at
+  nside 512); every rank does the pixel-domain work of the whole map.
+* row-sharded (:class:`RowShards`, :class:`RowShardedNormalLO`, :func:`row_sharded_bd`,
+  :func:`row_sharded_two_level`; SURVEY 8e's preferred variant): rank k owns the contiguous,
+  pixel-aligned rows [k n/N, (k+1) n/N) of every map vector and of Z / AZ.  One matvec =
+  all-gather of p, local P^T N^-1 P, reduce-scatter of the result (the same bytes on the wire
+  as the all-reduce); the dot products are local sums + an 8-byte all-reduce, Z^T r an r-vector
+  all-reduce; M_BD, the vector updates and the passes over Z / AZ (3 n r 8 bytes per M2, 1.8 GB
+  at nside 256, r = 32) shrink by the number of ranks.
 """
 import numpy as np
 
@@ -24,7 +33,8 @@ from . import linop as lp
 
 torch = D.torch
 
-__all__ = ["shard_blocks", "allreduce_sum_", "ShardedLO", "make_sync", "world"]
+__all__ = ["shard_blocks", "allreduce_sum_", "ShardedLO", "make_sync", "world", "RowShards",
+           "RowShardedNormalLO", "row_sharded_bd", "row_sharded_two_level"]
 
 
 def world(group=None):
@@ -130,3 +140,129 @@ class ShardedLO(lp.LinearOperator):
         elif not y.is_contiguous():
             y = y.contiguous()
         return allreduce_sum_(y, self.group)
+
+
+# ------------------------------------------------------------ row-sharded vectors -----
+class RowShards(object):
+    """
+    Partition of the ``pol * npix`` map rows into one contiguous, pixel-aligned range per rank,
+    all of the same length ``rows`` (the last ranks' ranges are padded with rows that stay 0), so
+    that ``all_gather_into_tensor`` / ``reduce_scatter_tensor`` move equal pieces.  Works on
+    HBM tensors (RCCL), CPU tensors and NumPy arrays (gloo).
+    """
+
+    def __init__(self, npix, pol, group=None):
+        self.group = group
+        self.rank, self.world = world(group)
+        self.npix, self.pol = int(npix), int(pol)
+        self.n = self.npix * self.pol
+        self.pix_per_rank = -(-self.npix // self.world)
+        self.rows = self.pix_per_rank * self.pol
+        self.pix_lo = min(self.rank * self.pix_per_rank, self.npix)
+        self.pix_hi = min(self.pix_lo + self.pix_per_rank, self.npix)
+        self.lo, self.hi = self.pix_lo * self.pol, self.pix_hi * self.pol
+
+    # -- helpers for the three vector kinds
+    @staticmethod
+    def _as_tensor(a):
+        return torch.from_numpy(a) if isinstance(a, np.ndarray) else a
+
+    def _like(self, a, length):
+        if isinstance(a, np.ndarray):
+            return np.zeros(length, dtype=np.float64)
+        return torch.zeros(length, dtype=torch.float64, device=a.device)
+
+    def local(self, full):
+        """This rank's (padded) rows of a whole vector."""
+        out = self._like(full, self.rows)
+        out[:self.hi - self.lo] = full[self.lo:self.hi]
+        return out
+
+    def gather(self, loc):
+        """Whole vector from every rank's rows (all-gather)."""
+        if self.world == 1:
+            return loc[:self.n] if len(loc) != self.n else loc
+        full = self._like(loc, self.rows * self.world)
+        torch.distributed.all_gather_into_tensor(self._as_tensor(full), self._as_tensor(
+            loc if not isinstance(loc, np.ndarray) else np.ascontiguousarray(loc)), group=self.group)
+        return full[:self.n]
+
+    def reduce_scatter(self, full):
+        """This rank's rows of the sum over ranks of whole vectors (reduce-scatter)."""
+        if self.world == 1:
+            return self.local(full)
+        padded = self._like(full, self.rows * self.world)
+        padded[:self.n] = full
+        out = self._like(full, self.rows)
+        torch.distributed.reduce_scatter_tensor(self._as_tensor(out), self._as_tensor(padded),
+                                                op=torch.distributed.ReduceOp.SUM, group=self.group)
+        return out
+
+    def allreduce_(self, t):
+        """In-place sum over ranks (dot products, Z^T r)."""
+        return allreduce_sum_(t, self.group)
+
+    def bytes_per_matvec(self):
+        """Bytes each rank sends per matvec (ring collectives): all-gather + reduce-scatter."""
+        return 2 * (self.world - 1) * self.rows * 8
+
+
+class RowShardedNormalLO(lp.LinearOperator):
+    """``A`` on row-sharded vectors: all-gather, this rank's ``P_k^T N_k^-1 P_k``, reduce-scatter.
+    Input and output are the rank's (padded) rows."""
+
+    def __init__(self, local_op, shards):
+        self.local_op, self.shards = local_op, shards
+        if local_op.shape[0] != shards.n:
+            raise lp.ShapeError("operator has %d rows, the shards cover %d" % (local_op.shape[0], shards.n))
+        super(RowShardedNormalLO, self).__init__(shards.rows, shards.rows, self._mult, symmetric=True,
+                                                 device_ok=lp.supports_device(local_op))
+
+    def _mult(self, p_loc):
+        full = self.shards.gather(p_loc)
+        if not isinstance(full, np.ndarray) and not full.is_contiguous():
+            full = full.contiguous()
+        y = self.local_op.matvec(full)
+        return self.shards.reduce_scatter(y)
+
+
+class _SlicedWeights(object):
+    """The per-pixel weight arrays of a ProcessTimeSamples restricted to a pixel range (padded
+    with empty pixels: hits 0, which M_BD maps to 0)."""
+
+    def __init__(self, ces, shards):
+        from .utilities.process_ces import _FIELDS
+        npad = shards.pix_per_rank
+        dev = getattr(ces, "_dev_weights", None) or {}
+        self._dev_weights = {}
+        for k in _FIELDS:
+            src = dev.get(k)
+            if src is None:
+                self._dev_weights[k] = None
+                continue
+            out = torch.zeros(npad, dtype=torch.float64, device=src.device)
+            out[:shards.pix_hi - shards.pix_lo] = src[shards.pix_lo:shards.pix_hi]
+            self._dev_weights[k] = out
+
+    def __getattr__(self, name):
+        dw = self.__dict__.get("_dev_weights", {})
+        if name in dw and dw[name] is not None:
+            return D.to_host(dw[name])
+        raise AttributeError(name)
+
+
+def row_sharded_bd(ces, shards):
+    """``M_BD`` acting on this rank's rows (its pixels' blocks only)."""
+    from .interfaces.linearoperators import BlockDiagonalPreconditionerLO
+    return BlockDiagonalPreconditionerLO(_SlicedWeights(ces, shards), shards.pix_per_rank, pol=shards.pol)
+
+
+def row_sharded_two_level(Mbd_loc, Z_loc, AZ_loc, shards, apply="eig"):
+    """Two-level preconditioner on row-sharded vectors: ``Z_loc`` / ``AZ_loc`` are this rank's
+    rows of Z and A Z (``rows x r``, padded rows zero).  ``E = Z^T A Z`` is the all-reduced sum of
+    the local contractions, ``Z^T r`` the all-reduced sum of the local products."""
+    from .interfaces.linearoperators import CoarseLO, DeflationLO, TwoLevelPreconditionerLO
+    r = int(Z_loc.shape[1])
+    E = CoarseLO(Z_loc, AZ_loc, r, apply=apply, allreduce=shards.allreduce_)
+    return TwoLevelPreconditionerLO(Mbd_loc, DeflationLO(Z_loc), DeflationLO(AZ_loc), E,
+                                    allreduce=shards.allreduce_)

@@ -50,7 +50,7 @@ def _apply(op, x):
 
 
 def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rtol=1e-5,
-       sync=None):
+       sync=None, dot_reduce=None):
     """
     Solve ``A x = b`` by PCG on the GPU.  Arguments and return value ``(x, info)`` follow
     ``scipy.sparse.linalg.cg``; ``tol`` is accepted as the old name of ``rtol`` (the
@@ -59,7 +59,10 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
 
     ``sync``: optional callable mapping the host value of ||r||^2 to the value every
     rank must use (sharding.py passes an all-reduce so that all ranks take the same
-    branch).
+    branch).  ``dot_reduce``: optional callable summing a device scalar over ranks in place --
+    for row-sharded vectors (sharding.RowShards.allreduce_), where every rank holds only its
+    rows and each scalar product is a local sum plus an 8-byte all-reduce; alpha and beta still
+    never visit the host.
     """
     D.require_gpu()
     if tol is not None:
@@ -73,6 +76,8 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
 
     def dot_into(out, u, v):
         _hip.check(lib.cm2_dot(n, D.ptr(u), D.ptr(v), D.ptr(out), D.ptr(work), st()))
+        if dot_reduce is not None:
+            dot_reduce(out)
 
     scal = D.zeros(5)                   # rho_a, rho_b, pq, rr, tmp  (device scalars)
     rho = [scal[0:1], scal[1:2]]
@@ -119,6 +124,8 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
         _hip.check(lib.cm2_pcg_update_xr(n, D.ptr(rho[cur]), D.ptr(pq), D.ptr(p), D.ptr(q),
                                          D.ptr(x), D.ptr(r), D.ptr(rr), D.ptr(work), st()))
         cur = 1 - cur
+        if dot_reduce is not None:
+            dot_reduce(rr)
         rr_host = float(rr.item())
         if sync is not None:
             rr_host = sync(rr_host)

@@ -15,7 +15,8 @@
  * Pinning status: the weave loops restated here (P, P^T, weight accumulation,
  * flagging, M_BD pol=2/3) cannot be executed from the reference in this
  * container (weave/blitz are absent), so they are pinned by reading plus the
- * reference tests' algebraic invariants (tests/test_oracle_invariants.py);
+ * reference tests' algebraic invariants (re-expressed in tests/test_gpu_parity.py and
+ * tests/test_oracle_golden.py);
  * the NumPy-level pieces (Toeplitz product, BlockDiagonalLO, M_BD pol=1,
  * repixelization, DeflationLO, CoarseLO, arnoldi, dgemm/norm2/scalprod) are
  * pinned against outputs of the reference's own function bodies executed here

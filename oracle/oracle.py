@@ -176,6 +176,19 @@ class ProcessedSamples(object):
     pass
 
 
+def repixelization(mask, npix, obspix, arrays):
+    """new_repixelization / repixelization (utilities/process_ces.py:192-349, :351-401): keep the
+    masked pixels in increasing order.  Returns ``(old2new, new_npix, obspix', arrays')`` with
+    ``old2new[j]`` the rank of pixel j among the kept ones or -1, and every per-pixel array
+    compacted to the kept pixels."""
+    keep = np.zeros(npix, dtype=bool)
+    keep[np.asarray(mask, dtype=np.int64)] = True
+    old2new = np.full(npix, -1, dtype=np.int64)
+    old2new[keep] = np.arange(int(keep.sum()))
+    return (old2new, int(keep.sum()), np.asarray(obspix)[:npix][keep],
+            {k: np.asarray(v)[keep] for k, v in arrays.items()})
+
+
 def process_time_samples(pixs, npix, pol=1, phi=None, w=None, threshold_cond=1.e3,
                          obspix=None):
     """Restates __init__ -> initializeweights -> new_repixelization ->
@@ -217,17 +230,14 @@ def process_time_samples(pixs, npix, pol=1, phi=None, w=None, threshold_cond=1.e
         if pol == 3:
             mask2 = np.where(counts > 2)[0]                 # :554-555
             mask = np.intersect1d(mask2, mask)
-    # new_repixelization (:205-228): keep masked pixels in increasing order.
-    keep = np.zeros(npix, dtype=bool)
-    keep[mask] = True
-    old2new = np.full(npix, -1, dtype=np.int64)
-    old2new[keep] = np.arange(int(keep.sum()))
+    old2new, new_npix, r.obspix, compacted = repixelization(
+        mask, npix, obspix, dict(counts=counts, cosine=cosine, sine=sine, cos2=cos2, sin2=sin2,
+                                 sincos=sincos))
     r.mask = mask
     r.old2new = old2new
-    r.new_npix = int(keep.sum())
-    r.obspix = np.asarray(obspix)[keep]
-    r.counts, r.cosine, r.sine = counts[keep], cosine[keep], sine[keep]
-    r.cos2, r.sin2, r.sincos = cos2[keep], sin2[keep], sincos[keep]
+    r.new_npix = new_npix
+    r.counts, r.cosine, r.sine = compacted["counts"], compacted["cosine"], compacted["sine"]
+    r.cos2, r.sin2, r.sincos = compacted["cos2"], compacted["sin2"], compacted["sincos"]
     # flagging_samples (:411-418)
     lib().orc_flag_samples(ctypes.c_int64(nt), pix.ctypes.data_as(_I32),
                            old2new.ctypes.data_as(_I64))

@@ -80,6 +80,51 @@ def main():
         assert e3 < 1e-7, ("sharded vs single-rank PCG solution", e3)
         print("SHARDED-OK matvec %.1e / %.1e, PCG %d vs %d iterations, solution %.1e"
               % (err, e2, len(its), len(its1), e3), flush=True)
+    # ---- row-sharded vectors (reduce-scatter variant), M_BD and two-level preconditioner:
+    #      same iteration counts and, to rounding, the same solutions as the replicated variant
+    from cosmomap2_amd.sharding import (RowShards, RowShardedNormalLO, row_sharded_bd,
+                                        row_sharded_two_level)
+    from cosmomap2_amd.interfaces import (CoarseLO, DeflationLO, TwoLevelPreconditionerLO,
+                                          ritz_deflation_basis, apply_to_columns)
+    sh = RowShards(n, pol)
+    Ar = RowShardedNormalLO(P.T * N * P, sh)
+    Mr = row_sharded_bd(ces, sh)
+    b_loc = sh.local(b)
+    y_rows = Ar * sh.local(x)
+    e4 = float((sh.gather(y_rows) - y4).norm() / y4.norm())
+    assert e4 < 1e-13, ("row-sharded vs replicated matvec", e4)
+    its_r = []
+    xr, info_r = cosmomap2_amd.cg(Ar, b_loc, M=Mr, rtol=1e-8, maxiter=200,
+                                  callback=lambda v: its_r.append(1), dot_reduce=sh.allreduce_)
+    assert info_r == 0 and len(its_r) == len(its), (len(its_r), len(its))
+    e5 = float((sh.gather(xr) - xs).norm() / xs.norm())
+    assert e5 < 1e-12, ("row-sharded vs replicated PCG solution", e5)
+    # two-level: Z from the replicated operator (identical on both ranks), then its rows
+    r = 8
+    Z, theta = ritz_deflation_basis(A, M, b, r, 24)
+    AZ = apply_to_columns(A, Z)
+    M2 = TwoLevelPreconditionerLO(M, DeflationLO(Z), DeflationLO(AZ), CoarseLO(Z, AZ, r, apply='eig'))
+    its2 = []
+    x2, info2 = cosmomap2_amd.cg(A, b, M=M2, rtol=1e-8, maxiter=200, callback=lambda v: its2.append(1),
+                                 sync=make_sync())
+
+    def rows_of(mat):
+        out = torch.zeros(sh.rows, mat.shape[1], dtype=torch.float64, device=mat.device)
+        out[:sh.hi - sh.lo] = mat[sh.lo:sh.hi]
+        return out
+    M2r = row_sharded_two_level(Mr, rows_of(Z), rows_of(AZ), sh, apply='eig')
+    rr0 = sh.local(x)
+    e6 = float((sh.gather(M2r * rr0) - M2 * x).norm() / (M2 * x).norm())
+    assert e6 < 1e-12, ("row-sharded vs replicated M2", e6)
+    its2r = []
+    x2r, info2r = cosmomap2_amd.cg(Ar, b_loc, M=M2r, rtol=1e-8, maxiter=200,
+                                   callback=lambda v: its2r.append(1), dot_reduce=sh.allreduce_)
+    assert info2 == 0 and info2r == 0 and len(its2r) == len(its2), (len(its2r), len(its2))
+    e7 = float((sh.gather(x2r) - x2).norm() / x2.norm())
+    assert e7 < 1e-12, ("row-sharded vs replicated two-level solution", e7)
+    if rank == 0:
+        print("ROWSHARDED-OK matvec %.1e, PCG %d its (%.1e), M2 %.1e, two-level %d its (%.1e)"
+              % (e4, len(its_r), e5, e6, len(its2r), e7), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -24,3 +24,4 @@ def test_two_ranks_share_one_gpu():
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "SHARDED-OK" in res.stdout, res.stdout[-2000:]
+    assert "ROWSHARDED-OK" in res.stdout, res.stdout[-2000:]

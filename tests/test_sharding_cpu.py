@@ -118,6 +118,42 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(lo, hi)
         sync = make_sync()
         assert sync(float(rank + 1)) == float(world)        # max over ranks
+
+        # ---- row-sharded vectors (reduce-scatter variant): every rank owns n / N rows
+        from cosmomap2_amd.sharding import RowShards, RowShardedNormalLO
+        sh = RowShards(npix, pol)
+        assert sh.rows == -(-npix // world) * pol and sh.lo == rank * sh.rows
+        Ar = RowShardedNormalLO(A_local, sh)
+        x_loc = sh.local(x)
+        assert np.array_equal(sh.gather(x_loc), x)                       # all-gather restores x
+        y_loc = Ar * x_loc
+        assert np.allclose(y_loc[:sh.hi - sh.lo], y_ref[sh.lo:sh.hi], rtol=1e-12, atol=1e-12)
+        assert np.all(y_loc[sh.hi - sh.lo:] == 0.0)
+        # PCG in the scipy recurrence on the local rows: dots = local sums + all-reduce
+        def rdot(u, v):
+            return float(sh.allreduce_(np.array([np.dot(u, v)]))[0])
+        Mfull = lambda v: orc.bd_precond_mult(pol, glob, v)
+        def M_loc(v_loc):               # M_BD is per pixel: apply it on a padded whole vector
+            full = np.zeros(pol * npix)
+            full[sh.lo:sh.hi] = v_loc[:sh.hi - sh.lo]
+            return sh.local(Mfull(full))
+        b_rows = sh.reduce_scatter(b_loc)
+        assert np.allclose(sh.gather(b_rows), b, rtol=1e-13, atol=1e-13)
+        xr, rr = np.zeros(sh.rows), b_rows.copy()
+        atol = 1e-8 * np.sqrt(rdot(b_rows, b_rows))
+        nit, rho_prev, p = 0, None, None
+        while np.sqrt(rdot(rr, rr)) >= atol and nit < 500:
+            z = M_loc(rr)
+            rho = rdot(rr, z)
+            p = z.copy() if p is None else z + (rho / rho_prev) * p
+            q = Ar * p
+            alpha = rho / rdot(p, q)
+            xr += alpha * p
+            rr -= alpha * q
+            rho_prev = rho
+            nit += 1
+        assert nit == len(its)                                           # same count as replicated
+        assert np.linalg.norm(sh.gather(xr) - xs) <= 1e-10 * np.linalg.norm(xs)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("%d" % len(its))
     finally:
         dist.destroy_process_group()
