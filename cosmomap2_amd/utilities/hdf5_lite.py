@@ -279,14 +279,18 @@ def _dtype_msg(dt):
 
 
 class _Writer(object):
+    """Lays the file out as a list of (address, bytes-like) pieces; dataset payloads are kept as
+    views of the caller's arrays and go to the file with one write each."""
+
     def __init__(self):
-        self.buf = bytearray(96)                   # superblock, filled in at the end
+        self.pieces = []
+        self.end = 96                               # superblock, written last
 
     def alloc(self, data):
-        while len(self.buf) % 8:
-            self.buf.append(0)
-        addr = len(self.buf)
-        self.buf += data
+        self.end += -self.end % 8
+        addr = self.end
+        self.pieces.append((addr, data))
+        self.end += len(data) if not isinstance(data, memoryview) else data.nbytes
         return addr
 
     def header(self, msgs):
@@ -297,13 +301,15 @@ class _Writer(object):
         arr = np.asarray(arr)
         if arr.dtype.kind not in "iuf":
             raise Hdf5FormatError("only integer and float datasets can be written")
-        raw = np.ascontiguousarray(arr).tobytes()
-        daddr = self.alloc(raw) if raw else _UNDEF
+        if not arr.flags.c_contiguous:                   # (ascontiguousarray would make 0-d arrays 1-d)
+            arr = np.array(arr, order="C")
+        nbytes = arr.nbytes
+        daddr = self.alloc(memoryview(arr.reshape(-1).view(np.uint8))) if nbytes else _UNDEF
         space = struct.pack("<BBB5x", 1, arr.ndim, 0) + b"".join(struct.pack("<Q", s) for s in arr.shape)
         # fill value: version 2, late allocation, written if set, defined with size 0 -- the
         # message h5py's create_dataset leaves (reference test files, data/testcase_block_diag_*)
         fill = struct.pack("<BBBBI", 2, 2, 2, 1, 0)
-        layout = struct.pack("<BBQQ", 3, 1, daddr, len(raw))
+        layout = struct.pack("<BBQQ", 3, 1, daddr, nbytes)
         return self.header([_msg(0x01, space), _msg(0x03, _dtype_msg(arr.dtype), flags=1),
                             _msg(0x05, fill, flags=1), _msg(0x08, layout, flags=1)])
 
@@ -348,19 +354,21 @@ class _Writer(object):
         hdr = self.header([_msg(0x11, struct.pack("<QQ", bt_addr, heap_addr))])
         return hdr, bt_addr, heap_addr
 
-    def finish(self, root):
+    def finish(self, root, path):
         hdr, bt, heap = root
         sb = _SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, _LEAF_K, _INT_K, 0)
-        sb += struct.pack("<QQQQ", 0, _UNDEF, len(self.buf), _UNDEF)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, self.end, _UNDEF)
         sb += struct.pack("<QQII", 0, hdr, 1, 0) + struct.pack("<QQ", bt, heap)
         assert len(sb) == 96
-        self.buf[:96] = sb
-        return bytes(self.buf)
+        with open(path, "wb") as f:
+            f.write(sb)
+            for addr, data in self.pieces:
+                f.seek(addr)
+                f.write(data)
+            f.truncate(self.end)
 
 
 def write_file(path, tree):
     """Write nested dicts (groups) of arrays (datasets) as an HDF5 file."""
     w = _Writer()
-    data = w.finish(w.group(tree))
-    with open(path, "wb") as f:
-        f.write(data)
+    w.finish(w.group(tree), path)
