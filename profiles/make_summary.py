@@ -21,7 +21,9 @@ import os
 import shutil
 import sys
 
-HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles", "k_PtNP_sell", "k_P_time", "k_Pt_sell"]
+HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles_fixed", "k_Pt_tiles<", "k_PtNP_sell", "k_P_time",
+       "k_Pt_sell", "k_Zt_partial_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs",
+       "k_bdprecond", "k_dot_partial", "k_pcg_update_xr", "k_pcg_update_p"]
 
 
 def main(src, tag):
@@ -32,6 +34,9 @@ def main(src, tag):
     ks = newest(os.path.join(src, "kt", "**", "*_kernel_stats.csv"))
     shutil.copy(ks, os.path.join(here, tag + "_rocprofv3_kernel_stats_c4.csv"))
     rows = list(csv.DictReader(open(ks)))
+    # (k_Z_apply with r = 32 and with the Arnoldi panel width differ only in arguments: the rows
+    # of one kernel name are merged by rocprofv3; the deflation kernels are listed for the M2 /
+    # Arnoldi legs of the bench, the first six for the timed matvec)
 
     def counters(kind):
         f = newest(os.path.join(src, kind, "**", "*_counter_collection.csv"))
@@ -44,9 +49,17 @@ def main(src, tag):
     fe, wr = counters("fetch"), counters("write")
     nt = bench["config"]["nt_per_gpu"]
     npix = bench["config"]["npix"]
+    n = 3 * npix
+    r = (bench.get("pcg") or {}).get("two_level", {}).get("rank", 32)
+    zb = 8.0 * n * r
     alg = {"k_P_tiles": 28.0 * nt + 24 * npix, "k_overlap_save": 16.0 * nt,
-           "k_Pt_tiles": 28.0 * nt + 24 * npix, "k_PtNP_sell": 28.0 * nt + 48 * npix,
-           "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix}
+           "k_Pt_tiles_fixed": 28.0 * nt + 24 * npix, "k_Pt_tiles<": 28.0 * nt + 24 * npix,
+           "k_PtNP_sell": 28.0 * nt + 48 * npix,
+           "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix,
+           "k_Zt_partial_wide": zb + 8.0 * n, "k_Z_apply": zb + 16.0 * n,
+           "k_m2_finish_wide": 2 * zb + 16.0 * n + 56.0 * npix, "k_gemm_tn_mfma_pairs": 2 * zb,
+           "k_bdprecond": 16.0 * n + 56.0 * npix, "k_dot_partial": 16.0 * n,
+           "k_pcg_update_xr": 40.0 * n, "k_pcg_update_p": 24.0 * n}
     table = {}
     for r in rows:
         for h in HOT:
@@ -60,15 +73,16 @@ def main(src, tag):
                             else 2 * f * 1024 + w * 1024,
                             "algorithmic_bytes": alg[h]}
     out = {"workload": bench["config"]["workload"], "nt_per_gpu": nt, "kernels": table,
+           "commit": os.environ.get("CM2_PROFILE_COMMIT") or bench.get("commit"),
            "note": "hbm_traffic_bytes = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE "
                    "correction); separate --pmc passes"}
     json.dump(out, open(os.path.join(here, tag + "_pmc_c4.json"), "w"), indent=1)
 
     md = ["# rocprofv3 summary %s -- `python3 bench.py` (%s)" % (tag, bench["config"]["workload"]), "",
           "Commands (MI355X box, after `cd /tmp && export TMPDIR=/tmp`):", "",
-          "    rocprofv3 --kernel-trace --stats -d out/kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-pcg --no-filters --no-raster",
-          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg --no-filters --no-raster",
-          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcg --no-filters --no-raster",
+          "    rocprofv3 --kernel-trace --stats -d out/kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-filters --no-raster",
+          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-filters --no-raster --arnoldi-steps 40",
+          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-filters --no-raster --arnoldi-steps 40",
           "", "Full kernel table: `%s_rocprofv3_kernel_stats_c4.csv`; machine-readable: `%s_pmc_c4.json`." % (tag, tag),
           "", "| kernel | calls | avg ms (rocprofv3) | 2*FETCH_SIZE GB | WRITE_SIZE GB | HBM traffic GB | algorithmic GB | GB/s algorithmic |",
           "|---|---|---|---|---|---|---|---|"]
@@ -84,8 +98,12 @@ def main(src, tag):
            % (bench["ms_per_step"], bench["value"], 100 * bench["step_frac_of_hbm_peak"])]
     md += ["", "Algorithmic bytes are SURVEY 8(d)'s (P and P^T: pixel 4 + cos 8 + sin 8 + TOD 8 = 28 B per "
            "sample).  The tile plan stores a 2-byte pixel-in-tile index and, by default, one half-angle "
-           "value instead of cos and sin: P and P^T are designed to move 18 B per sample, which is why "
-           "their measured traffic is below the algorithmic figure."]
+           "value instead of cos and sin: P is designed to move 18 B per sample, the fixed-order P^T "
+           "~21.7 B (8 B TOD + padded groups of 4-byte list entries and half angles), which is why their "
+           "measured traffic is below the algorithmic figure.  FETCH_SIZE is doubled as the guide "
+           "prescribes for wide coalesced reads; for the overlap-save kernel, whose loads are 8-byte "
+           "list-driven gathers, that makes the figure an upper estimate.  The deflation rows use the "
+           "bytes of Z / AZ (8 n r each) plus the map vectors."]
     open(os.path.join(here, tag + "_pmc_c4.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md[10:]))
 
