@@ -49,6 +49,20 @@ static inline int grid_for(int64_t n, int block = kBlock, int max_blocks = kNumC
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: granted[] (one
+// static array per kernel instance at the call site) remembers what each device was given, so the
+// runtime is asked once per device and again only when a launch needs more.
+static inline hipError_t ensure_dynamic_lds(const void *func, size_t bytes, size_t (&granted)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && granted[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) granted[dev] = bytes;
+    return e;
+}
+
 // Scratch allocation of a setup routine: freed on every exit path (the CM2_HIP / CM2_CHECK
 // macros return early on failure).  keep() hands the buffer over to a longer-lived owner.
 template <typename T>

@@ -1008,10 +1008,8 @@ template <int R1, int R2, int R3, bool INDIRECT>
 static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
                   hipStream_t stream)
 {
-    // per launch: the attribute is per device, and setting it is cheap
-    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save<R1, R2, R3, INDIRECT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)f->lds_bytes));
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save<R1, R2, R3, INDIRECT>, f->lds_bytes, granted));
     const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
         f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx,
@@ -1024,9 +1022,8 @@ template <bool LISTS>
 static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
-    // per launch: the attribute is per device, and setting it is cheap
-    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_reg<LISTS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_reg<LISTS>, lds, granted));
     if (f->npairs_reg == 0) return 0;
     const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
     k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
@@ -1041,9 +1038,8 @@ static int launch_real(const FusedOS *f, const uint32_t *d_idx, const double *d_
                        hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * 2 * (size_t)(kRealM + kRealM / 32);
-    // per launch: the attribute is per device, and setting it is cheap
-    CM2_HIP(hipFuncSetAttribute((const void *)k_overlap_save_real<INDIRECT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_real<INDIRECT>, lds, granted));
     if (f->nsegs == 0) return 0;
     const int grid = (int)(((f->nsegs + 7) / 8) * 8);
     k_overlap_save_real<INDIRECT><<<grid, kRealT, lds, stream>>>(

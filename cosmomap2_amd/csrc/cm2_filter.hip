@@ -765,9 +765,8 @@ template <int K>
 int launch_windows(const cm2_filter *f, const double *d_in, double *d_out, hipStream_t st)
 {
     constexpr size_t lds = sizeof(double) * kWinLen + kWinLen;
-    // per launch: the attribute is per device, and setting it is cheap
-    CM2_HIP(hipFuncSetAttribute((const void *)k_filter_windows<K>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_filter_windows<K>, lds, granted));
     const int grid = (int)(((f->nwin + 7) / 8) * 8);
     k_filter_windows<K><<<grid, kWinT, lds, st>>>(f->d_wins, (int)f->nwin, f->d_start, f->d_len,
                                                   f->d_kind, f->d_toff, f->d_table, f->d_coef,

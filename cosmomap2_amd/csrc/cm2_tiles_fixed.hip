@@ -493,8 +493,8 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
                    int64_t tile_hi, hipStream_t stream)
 {
     const size_t lds = fx_lds_bytes(t, t->fx_S);
-    CM2_HIP(hipFuncSetAttribute((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
     k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
         t->tp, t->npix, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
