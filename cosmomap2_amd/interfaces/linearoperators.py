@@ -10,7 +10,9 @@ the HIP library and a GPU the constructors raise.
 
 Ownership: the reference keeps *references* to the caller's arrays
 (linearoperators.py:531-534, 848-856).  Here the arrays are snapshotted into HBM
-at construction; later host-side mutation is not seen.
+at construction (NumPy arrays by their upload, HBM tensors by a copy); later mutation
+is not seen.  The one shared buffer is the flagged pixel stream of a ProcessTimeSamples
+handed over as ``pix_samples is CES.pixs``: it is final once ProcessTimeSamples returns.
 """
 import ctypes
 import os
@@ -78,6 +80,11 @@ class SparseLO(_DeviceOp):
             self._d_pix = shared                     # already flagged and resident
         if self._d_pix is None:
             self._d_pix = D.i32(pix_samples)
+            if D.is_dev(pix_samples) and self._d_pix.data_ptr() == pix_samples.data_ptr():
+                # a caller-owned HBM tensor: snapshot it, like a NumPy array is by its upload --
+                # P_time reads the live buffer while the pixel-major and tile plans are built
+                # once, so flagging samples after construction would make P and P^T disagree
+                self._d_pix = self._d_pix.clone()
         if self._d_pix.numel() != self.nrows:
             raise lp.ShapeError("pix_samples has %d entries, expected m=%d"
                                 % (self._d_pix.numel(), self.nrows))
