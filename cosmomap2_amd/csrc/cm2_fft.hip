@@ -30,10 +30,8 @@
 //                                      2048, 8192; time order, or tile order through idx / lists)
 //   k_overlap_save_reg                 register-resident pair kernel for N = 8192 on the tile
 //                                      order: two workgroups per CU (default for long bands)
-//   k_overlap_save_real<INDIRECT>      real-input variant (CM2_FUSED_VARIANT=real), kept for
-//                                      comparison
-// Environment knobs (read when an operator / its lists are built): CM2_FUSED_VARIANT = pair |
-// real, CM2_OS_LISTS = 0 (per-sample index instead of address-sorted lists), CM2_FUSED_FFT_LEN.
+// Environment knobs (read when an operator / its lists are built): CM2_FUSED_VARIANT = pair,
+// CM2_OS_LISTS = 0 (per-sample index instead of address-sorted lists), CM2_FUSED_FFT_LEN.
 #include "cm2_fft.h"
 
 #include <hipcub/hipcub.hpp>
@@ -753,146 +751,6 @@ __global__ __launch_bounds__(256) void k_reg_unpack(int64_t npairs, const uint64
     }
 }
 
-// ------------------------------------------------------------------------------------
-// Real-input variant for long bands (halo up to 2048): ONE segment of L = 8192 real samples
-// per workgroup, transformed as M = 4096 complex points z[n] = x[2n] + i x[2n+1].  Its LDS
-// footprint (66 KB) lets TWO workgroups share a CU, so one can compute while the other
-// waits on HBM -- the pair kernel above (135 KB) runs alone on its CU.
-//
-// With Z = FFT_M(z) in digit-reversed order, for every pair (k, k' = M-k), w = e^{-2 pi i k/L}:
-//     S = Z_k + conj(Z_k'),  P = i w (Z_k - conj(Z_k'))       X_k = S - P,  X_k' = conj(S + P)
-//     U = h_k X_k,  V = h_k' X_k'                              (h = H / 4M, real spectrum)
-//     S2 = U + conj(V),  Q = i conj(w) (U - conj(V))           Z'_k = S2 + Q,  Z'_k' = conj(S2 - Q)
-// and y[2n] + i y[2n+1] = sum_k Z'_k e^{+2 pi i k n / M}  (checked against numpy in
-// tests; k = 0 pairs with the Nyquist bin M and k = M/2 with itself through the same formulas).
-struct SegDesc {
-    int64_t start, len, lo, hi;
-    int32_t blk, pad;
-};
-
-constexpr int kRealM = 4096, kRealL = 8192, kRealT = 256;
-
-template <bool INDIRECT>
-__global__ __launch_bounds__(kRealT) void k_overlap_save_real(
-    const SegDesc *__restrict__ segs, int nsegs, int halo, const double2 *__restrict__ WM,
-    const double2 *__restrict__ WL, const double *__restrict__ Hs,
-    const uint32_t *__restrict__ idx, const double *__restrict__ v, double *__restrict__ out)
-{
-    constexpr int M = kRealM, L = kRealL, T = kRealT, MP = M + M / 32;
-    extern __shared__ double lds[];
-    double *pre = lds;
-    double *pim = lds + MP;
-    const int per_xcd = (nsegs + 7) / 8;
-    const int seg_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (seg_id >= nsegs) return;
-    const SegDesc sd = segs[seg_id];
-    const double *hs = Hs + (int64_t)sd.blk * (M + 1);
-
-    constexpr int PER = L / T;                             // 32 samples per thread
-    double val[PER];
-    if (INDIRECT) {
-        uint32_t kk[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int64_t t = sd.start - halo + threadIdx.x + u * T;
-            kk[u] = (t >= sd.lo && t < sd.hi) ? idx[t] : kInvalidSample;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) val[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
-    } else {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int64_t t = sd.start - halo + threadIdx.x + u * T;
-            val[u] = (t >= sd.lo && t < sd.hi) ? v[t] : 0.0;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int j = threadIdx.x + u * T;
-        ((j & 1) ? pim : pre)[padi(j >> 1)] = val[u];
-    }
-    __syncthreads();
-    radix_pass<16, M, false, true, false, T>(pre, pim, M, WM, nullptr);
-    __syncthreads();
-    radix_pass<16, M, false, true, false, T>(pre, pim, M / 16, WM, nullptr);
-    __syncthreads();
-    radix_pass<16, M, false, false, false, T>(pre, pim, 16, WM, nullptr);
-    __syncthreads();
-    // untangle the real spectrum, apply the band's spectrum, re-tangle; slots = the 2048
-    // addresses whose top frequency digit is < 8 (k < M/2), plus k = M/2 (address 8)
-    for (int c = threadIdx.x; c <= M / 2; c += T) {
-        const int a = (c == M / 2) ? 8 : (((c >> 3) << 4) | (c & 7));
-        const int k = (a >> 8) + 16 * ((a >> 4) & 15) + 256 * (a & 15);
-        const int kp = (M - k) & (M - 1);
-        const int ap = 256 * (kp & 15) + 16 * ((kp >> 4) & 15) + (kp >> 8);
-        const double2 w = WL[k];
-        const double ar = pre[padi(a)], ai = pim[padi(a)];
-        const double br = pre[padi(ap)], bi = pim[padi(ap)];
-        const double sr = ar + br, si = ai - bi;            // S  = A + conj(B)
-        const double dr = ar - br, di = ai + bi;            // Dd = A - conj(B)
-        const double pr = -(w.x * di + w.y * dr);           // P  = i w Dd
-        const double pi_ = w.x * dr - w.y * di;
-        const double hk = hs[k], hkp = hs[M - k];
-        const double ur = hk * (sr - pr), ui = hk * (si - pi_);          // U = h_k (S - P)
-        const double vr = hkp * (sr + pr), vi = -hkp * (si + pi_);       // V = h_k' conj(S + P)
-        const double s2r = ur + vr, s2i = ui - vi;          // S2 = U + conj(V)
-        const double d2r = ur - vr, d2i = ui + vi;          // D2 = U - conj(V)
-        const double qr = -(w.x * d2i - w.y * d2r);         // Q  = i conj(w) D2
-        const double qi = w.x * d2r + w.y * d2i;
-        pre[padi(a)] = s2r + qr;                            // Z'_k  = S2 + Q
-        pim[padi(a)] = s2i + qi;
-        if (ap != a) {
-            pre[padi(ap)] = s2r - qr;                       // Z'_k' = conj(S2 - Q)
-            pim[padi(ap)] = -(s2i - qi);
-        }
-    }
-    __syncthreads();
-    radix_pass<16, M, true, false, false, T>(pre, pim, 16, WM, nullptr);
-    __syncthreads();
-    radix_pass<16, M, true, true, false, T>(pre, pim, M / 16, WM, nullptr);
-    __syncthreads();
-    radix_pass<16, M, true, true, false, T>(pre, pim, M, WM, nullptr);
-    __syncthreads();
-    if (INDIRECT) {
-        uint32_t ks[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int j = threadIdx.x + u * T;
-            ks[u] = j < sd.len ? idx[sd.start + j] : kInvalidSample;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int jj = halo + threadIdx.x + u * T;
-            if (ks[u] != kInvalidSample) out[ks[u]] = ((jj & 1) ? pim : pre)[padi(jj >> 1)];
-        }
-    } else {
-        for (int j = threadIdx.x; j < sd.len; j += T) {
-            const int jj = halo + j;
-            out[sd.start + j] = ((jj & 1) ? pim : pre)[padi(jj >> 1)];
-        }
-    }
-}
-
-// Hs[b][k] = (a0 + 2 sum_j a_j cos(2 pi j k / L)) / (4 M),  k = 0..M  (natural order)
-__global__ __launch_bounds__(256) void k_spectrum_real(int nb, int64_t lambda,
-                                                        const double *__restrict__ bands,
-                                                        double *__restrict__ Hs)
-{
-    constexpr int M = kRealM, L = kRealL;
-    const int64_t total = (int64_t)nb * (M + 1);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t b = e / (M + 1), k = e - b * (M + 1);
-        const double *band = bands + b * lambda;
-        double acc = 0.0;
-        for (int64_t j = lambda - 1; j >= 1; --j) {
-            const int64_t m = (j * k) % L;
-            acc += band[j] * cospi(2.0 * (double)m / (double)L);
-        }
-        Hs[e] = (band[0] + 2.0 * acc) / (4.0 * M);
-    }
-}
-
 // keys of the per-pair gather lists: (pair << 32) | position in the tile-ordered TOD, value =
 // offset q in the pair's union window (0xFFFF for slots past the window of a pair without a
 // second segment).  A stable sort by key orders every pair's entries by address.
@@ -981,18 +839,12 @@ struct FusedOS {
     uint64_t list_plan = 0;              // id of the tile plan the lists were built for
     uint32_t *d_lst_k = nullptr;
     uint16_t *d_lst_q = nullptr;
-    // real-input variant (one segment of 8192 reals per workgroup, two workgroups per CU)
-    bool real_variant = false;
-    int64_t nsegs = 0;
-    SegDesc *d_segs = nullptr;
-    double2 *d_WM = nullptr, *d_WL = nullptr;
-    double *d_Hs = nullptr;
 };
 
 void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
-    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm, f->d_segs, f->d_WM, f->d_WL, f->d_Hs,
+    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm,
                     f->d_lst_k, f->d_lst_q, f->d_Hperm_reg, f->d_W_reg, f->d_pairs_reg, f->d_l1_k, f->d_l2_k, f->d_ls_k,
                     f->d_l1_q, f->d_l2_q, f->d_ls_q};
     for (void *q : ptrs)
@@ -1034,25 +886,9 @@ static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStr
 }
 
 template <bool INDIRECT>
-static int launch_real(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
-                       hipStream_t stream)
-{
-    constexpr size_t lds = sizeof(double) * 2 * (size_t)(kRealM + kRealM / 32);
-    static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_real<INDIRECT>, lds, granted));
-    if (f->nsegs == 0) return 0;
-    const int grid = (int)(((f->nsegs + 7) / 8) * 8);
-    k_overlap_save_real<INDIRECT><<<grid, kRealT, lds, stream>>>(
-        f->d_segs, (int)f->nsegs, f->halo, f->d_WM, f->d_WL, f->d_Hs, d_idx, d_v, d_out);
-    CM2_LAUNCH_OK();
-    return 0;
-}
-
-template <bool INDIRECT>
 static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
                     hipStream_t stream)
 {
-    if (f->real_variant) return launch_real<INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->npairs == 0) return 0;
     if (INDIRECT && f->d_l1_k) return launch_reg<true>(f, d_v, d_out, stream);
     if (!INDIRECT && f->reg_variant && f->reg_time_order) return launch_reg<false>(f, d_v, d_out, stream);
@@ -1074,7 +910,7 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
     f->d_lst_q = nullptr;
     f->list_plan = 0;
     const char *e = getenv("CM2_OS_LISTS");
-    if (f->real_variant || f->npairs == 0 || (e && atoi(e) == 0)) {
+    if (f->npairs == 0 || (e && atoi(e) == 0)) {
         if (f->d_l1_k) {                                     // lists of another tile index
             void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
                              (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
@@ -1183,42 +1019,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
         f->N = f->halo <= 128 ? 512 : (f->halo <= 512 ? 2048 : 8192);
     }
     const int64_t nb = (int64_t)off.size() - 1;
-    // CM2_FUSED_VARIANT=real selects the real-input transform (one segment of 8192 samples per
-    // workgroup, two workgroups per CU) for long bands; measured slower than the pair kernel
-    // (1.13 vs 0.90 ms at 1e8 samples): the FFT is bound by LDS + fp64 issue, not by occupancy
     const char *variant = getenv("CM2_FUSED_VARIANT");
-    if (f->N == 8192 && variant && strcmp(variant, "real") == 0) {
-        f->real_variant = true;
-        f->hop = kRealL - 2 * (int64_t)f->halo;
-        std::vector<SegDesc> segs;
-        for (int64_t b = 0; b < nb; ++b)
-            for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += f->hop) {
-                SegDesc sd;
-                sd.start = s0;
-                sd.len = (off[b + 1] - s0 < f->hop) ? off[b + 1] - s0 : f->hop;
-                sd.lo = off[b]; sd.hi = off[b + 1]; sd.blk = (int32_t)b; sd.pad = 0;
-                segs.push_back(sd);
-            }
-        f->nsegs = (int64_t)segs.size();
-        CM2_HIP(hipMalloc(&f->d_segs, sizeof(SegDesc) * (segs.size() ? segs.size() : 1)));
-        if (!segs.empty())
-            CM2_HIP(hipMemcpy(f->d_segs, segs.data(), sizeof(SegDesc) * segs.size(),
-                              hipMemcpyHostToDevice));
-        CM2_HIP(hipMalloc(&f->d_WM, sizeof(double2) * kRealM));
-        CM2_HIP(hipMalloc(&f->d_WL, sizeof(double2) * kRealL));
-        CM2_HIP(hipMalloc(&f->d_Hs, sizeof(double) * nb * (kRealM + 1)));
-        k_twiddles<<<(kRealM + 255) / 256, 256, 0, stream>>>(kRealM, f->d_WM);
-        CM2_LAUNCH_OK();
-        k_twiddles<<<(kRealL + 255) / 256, 256, 0, stream>>>(kRealL, f->d_WL);
-        CM2_LAUNCH_OK();
-        k_spectrum_real<<<grid_for(nb * (kRealM + 1)), kBlock, 0, stream>>>((int)nb, lambda, d_bands,
-                                                                             f->d_Hs);
-        CM2_LAUNCH_OK();
-        CM2_HIP(hipStreamSynchronize(stream));
-        guard.f = nullptr;
-        *out = f;
-        return 0;
-    }
     f->R1 = 16; f->R2 = 16; f->R3 = f->N / 256;
     f->hop = f->N - 2 * (int64_t)f->halo;
     // register-resident pair kernel for the tile-order path (fixed geometry: hop 4096, halo

@@ -343,15 +343,16 @@ def test_toeplitz_fft_matches_direct(cm, oracle, lam, sizes):
     assert np.abs(out[sizes[0]:]).max() < 1e-13
 
 
-def test_toeplitz_real_input_fft_variant(cm, oracle, monkeypatch):
-    """The alternative long-band kernel (8192 reals as 4096 complex points, untangled in LDS)."""
-    monkeypatch.setenv("CM2_FUSED_VARIANT", "real")
+def test_toeplitz_long_band_pair_and_register_kernels(cm, oracle, monkeypatch):
+    """The two long-band overlap-save kernels on the time order (LDS-resident pair kernel on
+    request, register-resident kernel by default) against the direct band sum."""
     rng = np.random.default_rng(77)
     lam, sizes = 2048, [21000, 9000, 4098]
     k = np.arange(lam)
     bands = [(1.0 + 0.2 * b) * np.exp(-k / 400.0) * np.cos(k / 700.0) for b in range(3)]
     v = rng.standard_normal(sum(sizes))
     ref = oracle.blocklo_mult(sizes, bands, True, v)
+    monkeypatch.setenv("CM2_FUSED_VARIANT", "pair")
     Nr = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
     assert rel_l2(Nr * v, ref) < 1e-12
     monkeypatch.delenv("CM2_FUSED_VARIANT")
