@@ -34,7 +34,23 @@ def host_only(fn, k=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(k): fn()
     t1 = time.perf_counter(); torch.cuda.synchronize(); return 1e3 * (t1 - t0) / k
+def direct_fresh_out():
+    o = D.empty(pol * npix)
+    _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)
+    _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st)
+    _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(o), st)
+    return o
+op = A._compiled()[0]
+w0, w1 = op._work if op._work is not None else (None, None)
+def direct_op_buffers():
+    a, b = op._work
+    _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(a), st)
+    _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(a), D.ptr(b), st)
+    _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(b), D.ptr(out), st)
+A * x
 res = {"operator_ms": timed(lambda: A * x), "direct_calls_ms": timed(direct),
+       "direct_fresh_out_ms": timed(direct_fresh_out), "direct_op_buffers_ms": timed(direct_op_buffers),
+       "op_mult_ms": timed(lambda: op._mult(x)),
        "operator_host_ms": host_only(lambda: A * x), "direct_host_ms": host_only(direct)}
 for name, fn in (("P", lambda: _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st)),
                  ("N", lambda: _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st)),
