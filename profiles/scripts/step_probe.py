@@ -56,4 +56,7 @@ for name, fn in (("P", lambda: _hip.call("cm2_P_tiles_apply", T.h, D.ptr(x), D.p
                  ("N", lambda: _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st)),
                  ("Pt", lambda: _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st))):
     res[name + "_alone_ms"] = timed(fn)
+res["operator_again_ms"] = timed(lambda: A * x)
+res["op_mult_again_ms"] = timed(lambda: op._mult(x))
+res["operator_third_ms"] = timed(lambda: A * x)
 print(json.dumps({k: round(v, 4) for k, v in res.items()}))
