@@ -14,8 +14,8 @@ That is what h5py's default ("earliest") file format produces for the reference'
 ``create_dataset`` calls (IOfiles.py:214-300), including ``chunks=True``.
 
 ``read_file(path)`` returns nested dicts (groups) of NumPy arrays in native byte order.
-``write_file(path, tree)`` writes nested dicts of arrays with contiguous layout; an array's
-dtype byte order is kept (the reference stores big-endian ``STD_I32BE`` / ``IEEE_F64BE``).
+``write_file(path, tree)`` writes nested dicts of arrays with contiguous layout (or chunked,
+for arrays wrapped in ``Chunked``); an array's dtype byte order is kept (the reference stores big-endian ``STD_I32BE`` / ``IEEE_F64BE``).
 Written files are checked against this reader and, structurally, against the reference's own
 h5py-written test files; h5py itself is not available here to read them back.
 """
@@ -23,7 +23,7 @@ import struct
 
 import numpy as np
 
-__all__ = ["read_file", "write_file", "Hdf5FormatError"]
+__all__ = ["read_file", "write_file", "Chunked", "Hdf5FormatError"]
 
 _SIG = b"\x89HDF\r\n\x1a\n"
 _UNDEF = 0xFFFFFFFFFFFFFFFF
@@ -31,6 +31,14 @@ _UNDEF = 0xFFFFFFFFFFFFFFFF
 
 class Hdf5FormatError(RuntimeError):
     pass
+
+
+class Chunked(object):
+    """Marks an array of the tree given to :func:`write_file` for chunked storage:
+    ``{"Eigenvectors": Chunked(z, (4096, 8))}``."""
+
+    def __init__(self, array, chunks):
+        self.array, self.chunks = np.asarray(array), tuple(chunks)
 
 
 # =============================================================================== reader ===
@@ -297,21 +305,55 @@ class _Writer(object):
         body = b"".join(msgs)
         return self.alloc(struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body)
 
-    def dataset(self, arr):
+    def dataset(self, arr, chunks=None):
         arr = np.asarray(arr)
         if arr.dtype.kind not in "iuf":
             raise Hdf5FormatError("only integer and float datasets can be written")
         if not arr.flags.c_contiguous:                   # (ascontiguousarray would make 0-d arrays 1-d)
             arr = np.array(arr, order="C")
-        nbytes = arr.nbytes
-        daddr = self.alloc(memoryview(arr.reshape(-1).view(np.uint8))) if nbytes else _UNDEF
         space = struct.pack("<BBB5x", 1, arr.ndim, 0) + b"".join(struct.pack("<Q", s) for s in arr.shape)
         # fill value: version 2, late allocation, written if set, defined with size 0 -- the
         # message h5py's create_dataset leaves (reference test files, data/testcase_block_diag_*)
         fill = struct.pack("<BBBBI", 2, 2, 2, 1, 0)
-        layout = struct.pack("<BBQQ", 3, 1, daddr, nbytes)
+        if chunks is None or arr.ndim == 0 or arr.size == 0:
+            nbytes = arr.nbytes
+            daddr = self.alloc(memoryview(arr.reshape(-1).view(np.uint8))) if nbytes else _UNDEF
+            layout = struct.pack("<BBQQ", 3, 1, daddr, nbytes)
+        else:
+            layout = self._chunked(arr, tuple(int(c) for c in chunks))
         return self.header([_msg(0x01, space), _msg(0x03, _dtype_msg(arr.dtype), flags=1),
                             _msg(0x05, fill, flags=1), _msg(0x08, layout, flags=1)])
+
+    def _chunked(self, arr, chunks):
+        """Chunked, unfiltered storage (what ``create_dataset(..., chunks=True)`` of the
+        reference's Ritz writer, IOfiles.py:232, produces): every chunk stored whole (edge chunks
+        padded), indexed by ONE leaf node of a v1 B-tree of type 1."""
+        rank = arr.ndim
+        if len(chunks) != rank or any(c < 1 for c in chunks):
+            raise Hdf5FormatError("chunk shape must have one positive entry per dimension")
+        grid = [-(-s // c) for s, c in zip(arr.shape, chunks)]
+        nchunks = int(np.prod(grid))
+        if nchunks > 64:
+            raise Hdf5FormatError("at most 64 chunks per dataset are written (one B-tree leaf)")
+        esz = arr.dtype.itemsize
+        csize = int(np.prod(chunks)) * esz
+        keys = []
+        for idx in np.ndindex(*grid):
+            off = [i * c for i, c in zip(idx, chunks)]
+            block = np.zeros(chunks, dtype=arr.dtype)
+            sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(off, chunks, arr.shape))
+            block[tuple(slice(0, x.stop - x.start) for x in sl)] = arr[sl]
+            keys.append((off, self.alloc(block.tobytes())))
+        node = bytearray(b"TREE" + struct.pack("<BBHQQ", 1, 0, nchunks, _UNDEF, _UNDEF))
+        for off, addr in keys:
+            node += struct.pack("<II", csize, 0) + b"".join(struct.pack("<Q", o) for o in off)
+            node += struct.pack("<Q", 0) + struct.pack("<Q", addr)
+        node += struct.pack("<II", 0, 0) + b"".join(struct.pack("<Q", s) for s in arr.shape)
+        node += struct.pack("<Q", 0)
+        node += b"\0" * (24 + 65 * (8 + 8 * (rank + 1)) + 64 * 8 - len(node))
+        bt = self.alloc(bytes(node))
+        return struct.pack("<BBB", 3, 2, rank + 1) + struct.pack("<Q", bt) + \
+            b"".join(struct.pack("<I", c) for c in chunks) + struct.pack("<I", esz)
 
     def group(self, tree):
         """-> (object header address, B-tree address, heap address)"""
@@ -321,7 +363,12 @@ class _Writer(object):
         children = {}
         for name in names:
             node = tree[name]
-            children[name] = self.group(node) if isinstance(node, dict) else (self.dataset(node),)
+            if isinstance(node, dict):
+                children[name] = self.group(node)
+            elif isinstance(node, Chunked):
+                children[name] = (self.dataset(node.array, chunks=node.chunks),)
+            else:
+                children[name] = (self.dataset(node),)
         # local heap: empty string at offset 0, then the names, 8-byte aligned
         heap = bytearray(8)
         offs = {}

@@ -94,6 +94,19 @@ def test_hdf5_lite_round_trip_groups_scalars_and_many_links(tmp_path):
             assert a.shape == np.asarray(b).shape and a.dtype == np.asarray(b).dtype.newbyteorder("=")
             np.testing.assert_array_equal(a, b)
     same(g, tree)
+    # chunked, unfiltered datasets (the reference's Ritz writer passes chunks=True): chunk grid
+    # with padded edge chunks, 1-d and 2-d, big- and little-endian
+    big = rng.standard_normal((37, 10))
+    ctree = {"Ritz_eigenvectors": {"Eigenvectors": h5.Chunked(big, (16, 4)),
+                                   "n_eigenvectors": np.array(10, dtype=">i4")},
+             "v": h5.Chunked(np.arange(23, dtype=">i4"), (5,))}
+    pc = str(tmp_path / "chunked.h5")
+    h5.write_file(pc, ctree)
+    gc = h5.read_file(pc)
+    np.testing.assert_array_equal(gc["Ritz_eigenvectors"]["Eigenvectors"], big)
+    np.testing.assert_array_equal(gc["v"], np.arange(23))
+    with pytest.raises(h5.Hdf5FormatError):
+        h5.write_file(str(tmp_path / "bad2.h5"), {"x": h5.Chunked(np.zeros(1000), (1,))})
     with pytest.raises(h5.Hdf5FormatError):
         h5._Reader(b"not an hdf5 file at all")
     with pytest.raises(h5.Hdf5FormatError):
