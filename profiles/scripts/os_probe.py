@@ -14,7 +14,7 @@ P = SparseLO(npix, nt, pix, pol=1)
 T = L._sparse_tiles(P, tile_pixels=int(os.environ.get("PROBE_TP", "1536")))
 rng = np.random.default_rng(0)
 N = BlockLO(nt // nb, [toeplitz_band(lam, rng) for _ in range(nb)], offdiag=True, method=3)
-a = torch.rand(T.nvalid, generator=g, device=dev, dtype=torch.float64); b = torch.empty_like(a)
+a = torch.rand(T.nvalid + 8, generator=g, device=dev, dtype=torch.float64); b = torch.empty_like(a)
 def run():
     _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(a), D.ptr(b), D.stream())
 run(); torch.cuda.synchronize()
@@ -22,5 +22,5 @@ evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tru
 for x, y in evs:
     x.record(); run(); y.record()
 torch.cuda.synchronize()
-print(json.dumps({"stagger": os.environ.get("CM2_OS_STAGGER", "0"), "tile_pixels": T.tile_pixels,
+print(json.dumps({"probe": os.environ.get("CM2_OS_PROBE", "0"), "tile_pixels": T.tile_pixels,
                   "ms": round(float(np.median([x.elapsed_time(y) for x, y in evs])), 4)}))
