@@ -5,26 +5,30 @@ order: ``obspix2mask`` and ``reorganize_map`` (utilities/healpy_functions.py:22-
 solution vector ``[I0,Q0,U0, I1,...]`` over the observed pixels and full-sky HEALPix maps
 runs on the GPU (cm2_cutsky_to_fullsky / cm2_fullsky_to_cutsky).
 
-healpy is not a dependency: ``nside2npix`` is ``12 * nside**2`` (HEALPix definition) and
-writing FITS files (the ``fname`` arguments, ``hp.write_map``) is not provided.
+healpy is not a dependency: ``nside2npix`` is ``12 * nside**2`` (HEALPix definition) and the
+``fname`` arguments write the maps with :func:`cosmomap2_amd.utilities.healpix_fits.write_map`
+(the FITS binary table ``hp.write_map`` produces; ``read_map`` reads such files back).
 """
 from .. import _hip
 from .. import device as D
 
 torch = D.torch
 
-__all__ = ["obspix2mask", "reorganize_map", "full2cutskymap", "nside2npix"]
+from .healpix_fits import read_map, write_map                # noqa: F401  (hp.read_map / hp.write_map)
+
+__all__ = ["obspix2mask", "reorganize_map", "full2cutskymap", "nside2npix", "read_map", "write_map"]
 
 
 def nside2npix(nside):
     return 12 * int(nside) * int(nside)
 
 
-def _no_fits(fname):
+def _write_fits(fname, maps):
+    """hp.write_map(fname, maps) of the reference (:46, :103)."""
     if fname is not None:
-        raise NotImplementedError(
-            "writing HEALPix FITS files needs healpy (hp.write_map), which this package does "
-            "not depend on; call hp.write_map(%r, maps) on the returned maps" % (fname,))
+        from .healpix_fits import write_map
+        host = [D.to_host(m) if D.is_tensor(m) else m for m in maps]
+        write_map(fname, host[0] if len(host) == 1 else host)
 
 
 def _i64(a):
@@ -32,20 +36,20 @@ def _i64(a):
 
 
 def obspix2mask(obspix, nside, fname=None):
-    """Binary full-sky mask, 1 on the observed pixels (reference :22-45)."""
-    _no_fits(fname)
+    """Binary full-sky mask, 1 on the observed pixels (reference :22-45); with ``fname`` it is
+    also written as a HEALPix FITS file (:46)."""
     n = int(_i64(obspix).numel())
     ones = D.empty(n)
     ones.fill_(1.0)
     mask = reorganize_map(ones, obspix, n, nside, 1)[0]
+    _write_fits(fname, [mask])
     return mask if D.is_tensor(obspix) else D.to_host(mask)
 
 
 def reorganize_map(mapin, obspix, npix, nside, pol, fname=None):
     """Solution vector -> list of ``pol`` full-sky HEALPix maps (I / Q,U / I,Q,U), zero
     outside the observed pixels (reference :47-102).  NumPy in, NumPy out; HBM tensor in,
-    HBM tensors out."""
-    _no_fits(fname)
+    HBM tensors out.  With ``fname`` the maps are also written as a HEALPix FITS file (:103)."""
     if pol not in (1, 2, 3):
         raise RuntimeError("No valid polarization key set!\t=>\tpol=%r" % (pol,))
     D.require_gpu()
@@ -60,6 +64,7 @@ def reorganize_map(mapin, obspix, npix, nside, pol, fname=None):
     _hip.call("cm2_cutsky_to_fullsky", int(pol), npix, D.ptr(op), D.ptr(x), nfull, D.ptr(full),
               D.stream())
     maps = [full[k * nfull:(k + 1) * nfull] for k in range(pol)]
+    _write_fits(fname, maps)
     if D.is_tensor(mapin):
         return maps
     return [D.to_host(m) for m in maps]

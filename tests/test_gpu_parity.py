@@ -5,6 +5,8 @@ from the reference's own code.  Integer/index results and every deterministic
 fixed-order kernel are compared BIT FOR BIT; reductions whose summation tree differs
 from the BLAS/NumPy one are compared at 1e-12 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1353,8 +1355,22 @@ def test_map_reorganisation(cm, oracle, golden, pol):
     np.testing.assert_array_equal(back.cpu().numpy(), x)
     with pytest.raises(Exception):                        # pixel id outside the sky
         cm.U.reorganize_map(x, obs2 + nfull, obs2.size, nside, pol)
-    with pytest.raises(NotImplementedError):              # FITS output needs healpy
-        cm.U.reorganize_map(x, obs2, obs2.size, nside, pol, fname="map.fits")
+    # fname: the maps also go to a HEALPix FITS file (hp.write_map of the reference, :103, :46)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fn = os.path.join(tmp, "map.fits")
+        maps = cm.U.reorganize_map(x, obs2, obs2.size, nside, pol, fname=fn)
+        got = cm.U.read_map(fn, field=None)
+        assert len(got) == pol
+        for a, b in zip(got, maps):
+            np.testing.assert_array_equal(a, b.astype(np.float32).astype(np.float64))
+        # ... and read back they give the cut-sky vector again (to the file's float32)
+        back = cm.U.full2cutskymap(got, pol, obs2.size, obs2)
+        back = back[0] if pol == 1 else back
+        np.testing.assert_allclose(back, x, rtol=1e-6, atol=1e-7)
+        fm = os.path.join(tmp, "mask.fits")
+        mask = cm.U.obspix2mask(obs2, nside, fname=fm)
+        np.testing.assert_array_equal(cm.U.read_map(fm), mask)
 
 
 def test_reference_api_surface(cm, oracle):
