@@ -22,5 +22,5 @@ evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tru
 for x, y in evs:
     x.record(); run(); y.record()
 torch.cuda.synchronize()
-print(json.dumps({"probe": os.environ.get("CM2_OS_PROBE", "0"), "tile_pixels": T.tile_pixels,
+print(json.dumps({ "tile_pixels": T.tile_pixels,
                   "ms": round(float(np.median([x.elapsed_time(y) for x, y in evs])), 4)}))

@@ -252,6 +252,24 @@ def test_pointing_errors(cm):
     # all samples flagged, empty pixels
     P = cm.I.SparseLO(70, 20, np.full(20, -1, dtype=np.int32))
     assert not (P * np.ones(70)).any() and not (P.T * np.ones(20)).any()
+    # the tile plan is a C entry point of its own: it validates the pixel range itself
+    import ctypes
+    from cosmomap2_amd import _hip, device as D
+    bad = D.i32(np.array([0, 3, 12, 5] * 64, dtype=np.int32))
+    h = ctypes.c_void_p()
+    with pytest.raises(_hip.HipError, match="outside"):
+        _hip.call("cm2_tiles_create", ctypes.byref(h), D.ptr(bad), None, None, bad.numel(), 10, 1,
+                  64, 4096, D.stream())
+    assert not h.value
+    # a tile plan of a pointing without valid samples still gives P^T = 0 through both orders
+    from cosmomap2_amd.interfaces import linearoperators as L
+    T = L._sparse_tiles(P, tile_pixels=64, slice_samples=4096)
+    out = D.empty(70)
+    for fixed in (True, False):
+        T.set_pt_order(fixed)
+        out.fill_(5.0)
+        _hip.call("cm2_Pt_tiles_apply", T.h, None, D.ptr(out), D.stream())
+        assert not out.cpu().numpy().any()
 
 
 def test_device_resident_vectors(cm, oracle):
