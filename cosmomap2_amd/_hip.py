@@ -69,6 +69,7 @@ PROTOTYPES = {
     "cm2_small_matvec": [_int, _vp, _vp, _vp, _vp],
     "cm2_gemm_atbt": [_i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "cm2_transpose": [_i64, _i64, _vp, _vp, _vp],
+    "cm2_panel_gemm": [_i64, _int, _int, _vp, _vp, _vp, _int, _vp],
     "cm2_cos_sin_2phi": [_i64, _vp, _vp, _vp, _vp],
     "cm2_m2_finish": [_int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp, _vp],

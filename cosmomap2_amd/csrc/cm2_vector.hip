@@ -581,6 +581,107 @@ extern "C" int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const 
     return 0;
 }
 
+// ------------------------------------------- out (+)= P W  (tall panel x small) ------
+// out[n x R] (+)= P[n x 32] W[32 x R], R = 16 or 32, all row-major: the products of the
+// deflation build -- Ritz vectors Z = V U and, through the Arnoldi relation A V_m = P_{m+1} H,
+// A Z = P (H U) -- with the basis kept in 32-column panels.  fp64 MFMA 16x16x4 per 16-row block:
+// lane (m, k) reads the column pair (8 s + 2 k, 8 s + 2 k + 1) of row i0 + m with one 16-byte load
+// (four loads = the lane's share of the 4-KB block) and feeds .x / .y to two MFMAs whose B
+// operands are the matching even / odd rows of W, held in registers.  One pass over P and out:
+// HBM-bound.
+template <int CT>
+__global__ __launch_bounds__(256) void k_panel_gemm_mfma(int64_t n, const double *__restrict__ P,
+                                                          const double *__restrict__ W,
+                                                          double *__restrict__ out, int accumulate)
+{
+    constexpr int R = 16 * CT;
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, k = lane >> 4;
+    // B operands: wv[s][e][ct] = W[8 s + 2 k + e][16 ct + m]
+    double wv[4][2][CT];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wv[s_][e][ct] = W[(8 * s_ + 2 * k + e) * R + 16 * ct + m];
+    const int64_t nblk = (n + 15) / 16;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t i0 = blk * 16;
+        const int64_t row = i0 + m < n ? i0 + m : n - 1;
+        double2 a[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+            a[s_] = *reinterpret_cast<const double2 *>(P + row * 32 + 8 * s_ + 2 * k);
+        double4_t acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            acc[ct] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (accumulate) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r_ = i0 + k + 4 * j;
+                    acc[ct][j] = r_ < n ? out[r_ * R + 16 * ct + m] : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_].x, wv[s_][0][ct], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_].y, wv[s_][1][ct], acc[ct], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r_ = i0 + k + 4 * j;
+                if (r_ < n) out[r_ * R + 16 * ct + m] = acc[ct][j];
+            }
+    }
+}
+
+// any panel width / output width (small cases, tests)
+__global__ __launch_bounds__(256) void k_panel_gemm_scalar(int64_t n, int rin, int rout,
+                                                            const double *__restrict__ P,
+                                                            const double *__restrict__ W,
+                                                            double *__restrict__ out, int accumulate)
+{
+    const int64_t total = n * rout;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / rout;
+        const int c = (int)(e - i * rout);
+        double acc = accumulate ? out[e] : 0.0;
+        for (int l = 0; l < rin; ++l) acc += P[i * rin + l] * W[l * rout + c];
+        out[e] = acc;
+    }
+}
+
+extern "C" int cm2_panel_gemm(int64_t n, int rin, int rout, const double *d_P, const double *d_W,
+                              double *d_out, int accumulate, void *stream_)
+{
+    CM2_CHECK(n >= 0 && rin >= 1 && rin <= 256 && rout >= 1 && rout <= 256,
+              "cm2_panel_gemm: bad shape n=%lld rin=%d rout=%d", (long long)n, rin, rout);
+    if (n == 0) return 0;
+    CM2_CHECK(d_P && d_W && d_out && d_P != d_out, "cm2_panel_gemm: NULL or aliased argument");
+    hipStream_t stream = as_stream(stream_);
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_P) & 15) == 0;
+    if (rin == 32 && (rout == 16 || rout == 32) && aligned) {
+        const int64_t nblk = (n + 15) / 16;
+        const int g = (int)(nblk / 4 + 1 < kNumCU * 8 ? nblk / 4 + 1 : kNumCU * 8);
+        if (rout == 16) k_panel_gemm_mfma<1><<<g, kBlock, 0, stream>>>(n, d_P, d_W, d_out, accumulate);
+        else k_panel_gemm_mfma<2><<<g, kBlock, 0, stream>>>(n, d_P, d_W, d_out, accumulate);
+    } else {
+        k_panel_gemm_scalar<<<grid_for(n * rout), kBlock, 0, stream>>>(n, rin, rout, d_P, d_W, d_out,
+                                                                    accumulate);
+    }
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
 // --------------------------------------------------- out = M v  (r x r) -------
 __global__ __launch_bounds__(256) void k_small_matvec(int r, const double *__restrict__ M,
                                                        const double *__restrict__ v,

@@ -159,7 +159,8 @@ def run_krypy_arnoldi(A, x0, M, tol, maxiter=None):
     x0d = D.f64(np.asarray(x0).reshape(-1) if not D.is_tensor(x0) else x0).reshape(-1)
     n = x0d.numel()
     nmax = n if maxiter is None else int(maxiter)
-    V, H, k_done = _arnoldi_M(A, x0d, M, nmax)
+    Vb, _Pb, H, k_done = _arnoldi_M(A, x0d, M, nmax)
+    V = Vb.vecs
     Vh = np.column_stack([D.to_host(v) for v in V])
     # k completed steps give V (n x (k+1)) and H ((k+1) x k); when the Krylov space is exhausted
     # (invariant subspace) there is no (k+1)-th vector and A V_k = V_k H_k holds with the square H
@@ -210,8 +211,9 @@ class _BasisPanels(object):
 
 
 def _arnoldi_M(A, x0d, M, nmax):
-    """Device-resident Arnoldi in the M inner product: returns (list of V vectors in HBM,
-    Hessenberg matrix (nmax+1 x nmax, NumPy), number of completed steps).
+    """Device-resident Arnoldi in the M inner product: returns (V basis, P basis -- both as
+    _BasisPanels, the same object when M is None --, Hessenberg matrix (nmax+1 x nmax, NumPy),
+    number of completed steps); A V_m = P_{m+1} H[:m+1, :m] and V^T P = I.
 
     Orthogonalisation is block classical Gram-Schmidt applied twice ("twice is enough";
     map-making spectra are tightly clustered, the new direction is soon tiny and a single
@@ -252,10 +254,26 @@ def _arnoldi_M(A, x0d, M, nmax):
         Pb.append(D.scaled(1.0 / nrm, Av))
         if M is not None:
             Vb.append(D.scaled(1.0 / nrm, MAv))
-    return Vb.vecs, H, k_done
+    return Vb, Pb, H, k_done
 
 
-def ritz_deflation_basis(A, M, x0, r, maxiter):
+def _panels_times(basis, W):
+    """sum over the 32-column panels of ``basis`` of panel x (its 32 rows of W): the n x r product
+    of the whole basis with the (number of vectors x r) matrix W, one pass over every panel
+    (cm2_panel_gemm, fp64 MFMA)."""
+    W = np.asarray(W, dtype=np.float64)
+    rout = int(W.shape[1])
+    out = D.empty(basis.n * rout).reshape(basis.n, rout)
+    for i, pnl in enumerate(basis.panels):
+        Wp = np.zeros((_PANEL, rout))
+        rows = W[i * _PANEL:(i + 1) * _PANEL]
+        Wp[:rows.shape[0]] = rows
+        _hip.call("cm2_panel_gemm", basis.n, _PANEL, rout, D.ptr(pnl), D.ptr(D.f64(Wp)), D.ptr(out),
+                  1 if i else 0, D.stream())
+    return out
+
+
+def ritz_deflation_basis(A, M, x0, r, maxiter, with_AZ=False):
     """
     Deflation basis for the two-level preconditioner without leaving HBM: ``maxiter`` steps
     of the M-inner-product Arnoldi of :func:`run_krypy_arnoldi` on ``A`` (preconditioner
@@ -263,23 +281,29 @@ def ritz_deflation_basis(A, M, x0, r, maxiter):
     Ritz values (the production recipe of src/test_M2_precond_onto_real_data.py:90-94 with a
     fixed rank instead of a threshold -- BASELINE config C4 asks for dim 32).
     Returns ``(Z, theta)``: Z as an (n x r) row-major float64 tensor, theta the r Ritz values.
+
+    ``with_AZ=True`` returns ``(Z, theta, AZ)`` with ``A Z`` taken from the Arnoldi relation
+    ``A V_m = P_{m+1} H`` -- ``A Z = P_{m+1} (H U_sel)``, one pass over the stored basis -- instead
+    of the r further applications of ``A`` the reference spends on it (``Az[:, i] = A * Z[:, i]``,
+    src/test_M2_precond_onto_real_data.py:98-101; :func:`apply_to_columns` does that).  The two
+    agree to the rounding of the recurrence (tested to 1e-10).
     """
     D.require_gpu()
     x0d = D.f64(x0).reshape(-1)
-    n = x0d.numel()
-    V, H, m = _arnoldi_M(A, x0d, M, int(maxiter))
+    Vb, Pb, H, m = _arnoldi_M(A, x0d, M, int(maxiter))
     if m < r:
         raise RuntimeError("Arnoldi stopped after %d steps, cannot extract %d Ritz vectors" % (m, r))
     Hm = H[:m, :m]
     theta, U = np.linalg.eigh(0.5 * (Hm + Hm.T))
     sel = np.argsort(theta)[:r]
-    # Z = V U_sel: the m basis vectors as a row-major n x m panel, one pass per Ritz vector
-    Vmat = _transpose(D.torch.stack(V[:m], dim=0))             # n x m, row-major
-    Zt = D.empty(r * n).reshape(r, n)
-    for jcol, e in enumerate(sel):
-        _hip.call("cm2_Z_apply", n, m, D.ptr(Vmat), D.ptr(D.f64(np.ascontiguousarray(U[:, e]))),
-                  D.ptr(Zt[jcol]), D.stream())
-    return _transpose(Zt), theta[sel]
+    Usel = U[:, sel]                                           # m x r
+    Z = _panels_times(Vb, Usel)                                # Z = V_m U_sel
+    if not with_AZ:
+        return Z, theta[sel]
+    G = H[:m + 1, :m].dot(Usel)                                # (m+1) x r
+    if len(Pb.vecs) < m + 1:                                   # Krylov space exhausted: no P_{m+1}
+        G = G[:m]
+    return Z, theta[sel], _panels_times(Pb, G)
 
 
 def find_ritz_eigenvalues(h, v, threshold=1.e-2, eigenvalues=False, filename=None):

@@ -254,6 +254,13 @@ int cm2_gemm_atbt(int64_t m, int64_t n, int64_t k, const double *d_A, const doub
  * contiguous map vectors (cols x n) and the row-major n x r panel that DeflationLO streams
  * (the reference keeps Z as a list of column views, linearoperators.py:1059-1062). */
 int cm2_transpose(int64_t rows, int64_t cols, const double *d_in, double *d_out, void *stream);
+/* d_out[n x rout] (+)= d_P[n x rin] d_W[rin x rout], all row-major, accumulate != 0 adds to d_out:
+ * the tall-panel products of the deflation build -- Ritz vectors Z = V y (build_Z,
+ * deflationlib.py:183) and A Z = P_{m+1} (H y) through the Arnoldi relation instead of r more
+ * applications of A (src/test_M2_precond_onto_real_data.py:98-101); fp64 MFMA for rin = 32,
+ * rout = 16 / 32. */
+int cm2_panel_gemm(int64_t n, int rin, int rout, const double *d_P, const double *d_W,
+                   double *d_out, int accumulate, void *stream);
 /* out[r] = M[r x r] (row-major) v  -- E^-1 held as an explicit small matrix */
 int cm2_small_matvec(int r, const double *d_M, const double *d_v, double *d_out, void *stream);
 /* fused second half of M2 r = M_BD (r - AZ y) + Z y  given y = E^-1 Z^T r:

@@ -1268,8 +1268,10 @@ def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
         # BASELINE C4: two-level preconditioner, Arnoldi-built deflation space of dimension 32;
         # its solution must be the M_BD one (1e-6) in no more iterations
         r = two_level_rank
-        Z, theta = cm.I.ritz_deflation_basis(A, M, b, r, 96)
-        AZ = cm.I.apply_to_columns(A, Z)
+        Z, theta, AZ = cm.I.ritz_deflation_basis(A, M, b, r, 96, with_AZ=True)
+        AZx = cm.I.apply_to_columns(A, Z)              # the reference's r applications of A
+        assert float((AZ - AZx).norm() / AZx.norm()) < 1e-9
+        del AZx
         E = cm.I.CoarseLO(Z, AZ, r, apply='eig')
         M2 = cm.I.TwoLevelPreconditionerLO(M, cm.I.DeflationLO(Z), cm.I.DeflationLO(AZ), E)
         its2 = []

@@ -147,6 +147,24 @@ def test_solve_restarted_from_ritz_checkpoint_is_bit_identical(cm, oracle, tmp_p
     AZ = cm.I.apply_to_columns(A, Z)
     for j in (0, r - 1):
         assert cm.torch.equal(AZ[:, j].contiguous(), A * Z[:, j].contiguous())
+    # ... and so does the Arnoldi relation A V_m = P_{m+1} H, to the rounding of the recurrence
+    Zk, thk, AZk = cm.I.ritz_deflation_basis(A, M, bd, r, 30, with_AZ=True)
+    assert cm.torch.equal(Zk, Z) and np.array_equal(thk, theta)
+    assert float((AZk - AZ).norm() / AZ.norm()) < 1e-10
+
+
+@pytest.mark.parametrize("n,rin,rout", [(1000, 32, 32), (4099, 32, 16), (517, 5, 3), (33, 32, 32)])
+def test_panel_gemm(cm, n, rin, rout):
+    """cm2_panel_gemm: out (+)= P W for a tall row-major panel (fp64 MFMA for 32-column panels)."""
+    from cosmomap2_amd import _hip, device as D
+    rng = np.random.default_rng(n)
+    P, W, O = rng.standard_normal((n, rin)), rng.standard_normal((rin, rout)), rng.standard_normal((n, rout))
+    dP, dW, dO = D.f64(P), D.f64(W), D.f64(O.copy())
+    _hip.call("cm2_panel_gemm", n, rin, rout, D.ptr(dP), D.ptr(dW), D.ptr(dO), 0, D.stream())
+    np.testing.assert_allclose(dO.cpu().numpy(), P.dot(W), rtol=1e-13, atol=1e-13)
+    dO = D.f64(O.copy())
+    _hip.call("cm2_panel_gemm", n, rin, rout, D.ptr(dP), D.ptr(dW), D.ptr(dO), 1, D.stream())
+    np.testing.assert_allclose(dO.cpu().numpy(), O + P.dot(W), rtol=1e-13, atol=1e-13)
 
 
 # -------------------------------------------------------------- 8f row 3 -----------
