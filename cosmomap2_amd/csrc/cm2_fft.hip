@@ -728,9 +728,12 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
 #pragma unroll
             for (int u = 16; u < C; ++u) { ks[u] = lks[u * kRegT]; qs[u] = lqs[u * kRegT]; }
             __syncthreads();
+            double rv[C];                     // all LDS reads first: one wait, not one per store
+#pragma unroll
+            for (int u = 0; u < C; ++u) rv[u] = buf[padi((int)qs[u])];
 #pragma unroll
             for (int u = 0; u < C; ++u)
-                if (ks[u] != kInvalidSample) out[ks[u]] = buf[padi((int)qs[u])];
+                if (ks[u] != kInvalidSample) out[ks[u]] = rv[u];
             return;
         }
         __syncthreads();
