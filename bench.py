@@ -211,7 +211,7 @@ def main():
         P = SparseLO(npix_c, nt, pix, pol=pol, angle_processed=ces)
         Mbd = BlockDiagonalPreconditionerLO(ces, npix_c, pol=pol)
         sync()
-        tm["pixel_major_plan_and_M_BD"] = time.time() - t0
+        tm["pointing_operator_and_M_BD"] = time.time() - t0
         A_local = P.T * N * P
         A = ShardedLO(A_local) if world > 1 else A_local
         n = pol * npix_c

@@ -885,6 +885,25 @@ __global__ __launch_bounds__(256) void k_spectrum_perm(int nb, int64_t lambda, i
     }
 }
 
+// the same spectrum in the index order of another factorisation: dst[b][a(k; R1,R2,R3)] =
+// src[b][a(k; S1,S2,S3)] (a permutation instead of a second O(N lambda) cosine sum per block)
+__global__ __launch_bounds__(256) void k_spectrum_reperm(int nb, int N, int R1, int R2, int R3,
+                                                          int S1, int S2, int S3,
+                                                          const double *__restrict__ src,
+                                                          double *__restrict__ dst)
+{
+    const int64_t total = (int64_t)nb * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N;
+        const int a = (int)(e - b * N);
+        const int d1 = a / (R2 * R3), d2 = (a / R3) % R2, d3 = a % R3;
+        const int k = d1 + R1 * d2 + R1 * R2 * d3;
+        const int s1 = k % S1, s2 = (k / S1) % S2, s3 = k / (S1 * S2);
+        dst[e] = src[b * N + s1 * (S2 * S3) + s2 * S3 + s3];
+    }
+}
+
 }  // namespace
 
 namespace cm2 {
@@ -1131,9 +1150,12 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * nb * f->N));
     k_twiddles<<<(f->N + 255) / 256, 256, 0, stream>>>(f->N, f->d_W);
     CM2_LAUNCH_OK();
-    k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, f->R1,
-                                                               f->R2, f->R3, d_bands, f->d_Hperm);
-    CM2_LAUNCH_OK();
+    const bool share_spectrum = f->reg_variant && f->N == kRegN;   // same transform length
+    if (!share_spectrum) {
+        k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, f->R1,
+                                                                   f->R2, f->R3, d_bands, f->d_Hperm);
+        CM2_LAUNCH_OK();
+    }
     if (f->reg_variant) {
         std::vector<PairDesc> rp;
         for (int64_t b = 0; b < nb; ++b) {
@@ -1159,6 +1181,11 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
         k_spectrum_perm<<<grid_for(nb * kRegN), kBlock, 0, stream>>>((int)nb, lambda, kRegN, 32, 16, 16,
                                                                     d_bands, f->d_Hperm_reg);
         CM2_LAUNCH_OK();
+        if (share_spectrum) {
+            k_spectrum_reperm<<<grid_for(nb * f->N), kBlock, 0, stream>>>(
+                (int)nb, f->N, f->R1, f->R2, f->R3, 32, 16, 16, f->d_Hperm_reg, f->d_Hperm);
+            CM2_LAUNCH_OK();
+        }
         CM2_HIP(hipMalloc(&f->d_W_reg, sizeof(double2) * kRegN));
         k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W_reg);
         CM2_LAUNCH_OK();

@@ -41,6 +41,7 @@ struct cm2_pointing {
     uint32_t *d_sell_t = nullptr;     // [sell_len]
     double *d_sell_cos = nullptr, *d_sell_sin = nullptr, *d_sell_w = nullptr;
     bool has_w = false;
+    bool sell_built = false;          // the pixel-major plan is built by its first user
 };
 
 // ---------------------------------------------------------------- plan build ---
@@ -314,6 +315,27 @@ static void free_plan(cm2_pointing *p)
     delete p;
 }
 
+// one pass over the pixel stream: samples outside [-1, npix) and unflagged samples
+__global__ __launch_bounds__(256) void k_check_pix(const int32_t *__restrict__ pix, int64_t nt,
+                                                    int64_t npix, unsigned long long *__restrict__ cnt)
+{
+    unsigned long long bad = 0, valid = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const int32_t p = pix[i];
+        bad += (p < -1 || p >= npix) ? 1 : 0;
+        valid += (p >= 0 && p < npix) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bad += __shfl_down(bad, o);
+        valid += __shfl_down(valid, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicAdd(cnt, bad);
+        if (valid) atomicAdd(cnt + 1, valid);
+    }
+}
+
 extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
                                    const double *d_cos, const double *d_sin, int64_t nt,
                                    int64_t npix, int pol, void *stream_)
@@ -325,24 +347,66 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
               "No valid polarization key set! pol=%d (possible values 1 (I), 2 (QU), 3 (IQU))", pol);
     CM2_CHECK(d_pix != nullptr || nt == 0, "cm2_pointing_create: d_pix is NULL");
     CM2_CHECK(pol == 1 || (d_cos && d_sin), "cm2_pointing_create: cos/sin required for pol=%d", pol);
+    CM2_CHECK(nt >= 0 && nt < (int64_t)0xFFFFFFFF, "nt=%lld out of range (must fit uint32)",
+              (long long)nt);
+    CM2_CHECK(npix > 0 && npix < (int64_t)0x7FFFFFFF, "npix=%lld out of range", (long long)npix);
     hipStream_t stream = as_stream(stream_);
-
-    PixIndex ix;
-    if (int rc = build_pixindex(ix, d_pix, nt, npix, stream)) {
-        ix.release();
-        return rc;
+    // The time-order P needs nothing but the three streams; the pixel-major (sliced-ELL) copy
+    // behind the exact P^T and the fused P^T diag(w) P costs a sort and 12-20 B per sample and is
+    // built by the first call that needs it (an operator that only ever runs on the tile order
+    // never pays for it).  The pixel ids are checked here, so that a bad stream fails at
+    // construction like the reference's index error would.
+    unsigned long long h_cnt[2] = {0, 0};
+    if (nt > 0) {
+        DevTemp<unsigned long long> d_cnt;
+        CM2_HIP(d_cnt.alloc(2));
+        CM2_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(h_cnt), stream));
+        k_check_pix<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, d_cnt.p);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
     }
+    CM2_CHECK(h_cnt[0] == 0, "%llu samples have a pixel id outside [-1, npix=%lld)", h_cnt[0],
+              (long long)npix);
     cm2_pointing *p = new cm2_pointing();
     p->nt = nt; p->npix = npix; p->pol = pol;
     p->d_pix = d_pix; p->d_cos = d_cos; p->d_sin = d_sin;
-    p->nvalid = ix.nvalid;
+    p->nvalid = (int64_t)h_cnt[1];
     p->nslots = ((npix + 63) / 64) * 64;
     p->nslices = p->nslots / 64;
+    *out = p;
+    return 0;
+}
 
-    struct PlanGuard {             // frees the half-built plan and the pixel index on early return
+static int ensure_sell(const cm2_pointing *cp, hipStream_t stream)
+{
+    if (cp->sell_built) return 0;
+    cm2_pointing *p = const_cast<cm2_pointing *>(cp);
+    const int64_t nt = p->nt, npix = p->npix;
+    const int pol = p->pol;
+    const double *d_cos = p->d_cos, *d_sin = p->d_sin;
+    PixIndex ix;
+    if (int rc = build_pixindex(ix, p->d_pix, nt, npix, stream)) {
+        ix.release();
+        return rc;
+    }
+    struct PlanGuard {             // frees the half-built arrays and the pixel index on early return
         cm2_pointing *plan;
         PixIndex *ix;
-        ~PlanGuard() { if (plan) free_plan(plan); ix->release(); }
+        ~PlanGuard()
+        {
+            if (plan) {
+                void *ptrs[] = {plan->d_sell_pix, plan->d_sell_cnt, plan->d_slice_ptr, plan->d_sell_t,
+                                plan->d_sell_cos, plan->d_sell_sin};
+                for (void *q : ptrs)
+                    if (q) (void)hipFree(q);
+                plan->d_sell_pix = plan->d_sell_cnt = nullptr;
+                plan->d_slice_ptr = nullptr;
+                plan->d_sell_t = nullptr;
+                plan->d_sell_cos = plan->d_sell_sin = nullptr;
+            }
+            ix->release();
+        }
     } guard{p, &ix};
     DevTemp<int32_t> cnt_in, ids_in;
     DevTemp<int64_t> d_len;
@@ -395,8 +459,8 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
 #undef CM2_FILL
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    guard.plan = nullptr;          // success: the caller owns the plan (the index is still released)
-    *out = p;
+    guard.plan = nullptr;          // success (the index is still released)
+    p->sell_built = true;
     return 0;
 }
 
@@ -409,6 +473,7 @@ extern "C" int cm2_pointing_destroy(cm2_pointing *p)
 extern "C" int cm2_pointing_info(const cm2_pointing *p, int64_t *h_info)
 {
     CM2_CHECK(p && h_info, "cm2_pointing_info: NULL argument");
+    if (int rc = ensure_sell(p, nullptr)) return rc;      // reports the pixel-major plan's sizes
     h_info[0] = p->nt; h_info[1] = p->npix; h_info[2] = p->pol;
     h_info[3] = p->nvalid; h_info[4] = p->sell_len; h_info[5] = p->nslices;
     return 0;
@@ -434,6 +499,7 @@ extern "C" int cm2_Pt_apply(const cm2_pointing *p, const double *d_v, double *d_
 {
     CM2_CHECK(p && d_out && (d_v || p->nt == 0), "cm2_Pt_apply: NULL argument");
     hipStream_t stream = as_stream(stream_);
+    if (int rc = ensure_sell(p, stream)) return rc;
     const int g = (int)((p->nslots + kBlock - 1) / kBlock);
 #define CM2_PT(POL)                                                                          \
     k_Pt_sell<POL><<<g, kBlock, 0, stream>>>(p->nslots, p->d_sell_pix, p->d_sell_cnt,        \
@@ -449,6 +515,7 @@ extern "C" int cm2_pointing_set_weights(cm2_pointing *p, const double *d_w, void
 {
     CM2_CHECK(p != nullptr, "cm2_pointing_set_weights: NULL plan");
     hipStream_t stream = as_stream(stream_);
+    if (int rc = ensure_sell(p, stream)) return rc;
     const int64_t L = p->sell_len > 0 ? p->sell_len : 1;
     if (!p->d_sell_w) CM2_HIP(hipMalloc(&p->d_sell_w, sizeof(double) * L));
     if (p->sell_len > 0) {
