@@ -22,7 +22,7 @@ import shutil
 import sys
 
 HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles_fixed", "k_Pt_tiles<", "k_PtNP_sell", "k_P_time",
-       "k_Pt_sell", "k_Zt_partial_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs",
+       "k_Pt_sell", "k_Zt_partial_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs", "k_panel_gemm_mfma",
        "k_bdprecond", "k_dot_partial", "k_pcg_update_xr", "k_pcg_update_p"]
 
 
@@ -58,6 +58,7 @@ def main(src, tag):
            "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix,
            "k_Zt_partial_wide": zb + 8.0 * n, "k_Z_apply": zb + 16.0 * n,
            "k_m2_finish_wide": 2 * zb + 16.0 * n + 56.0 * npix, "k_gemm_tn_mfma_pairs": 2 * zb,
+           "k_panel_gemm_mfma": 8.0 * n * 32 + 2 * zb,      # one 32-column panel in, r columns updated
            "k_bdprecond": 16.0 * n + 56.0 * npix, "k_dot_partial": 16.0 * n,
            "k_pcg_update_xr": 40.0 * n, "k_pcg_update_p": 24.0 * n}
     table = {}
