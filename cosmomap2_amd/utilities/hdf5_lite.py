@@ -19,6 +19,7 @@ for arrays wrapped in ``Chunked``); an array's dtype byte order is kept (the ref
 Written files are checked against this reader and, structurally, against the reference's own
 h5py-written test files; h5py itself is not available here to read them back.
 """
+import mmap
 import struct
 
 import numpy as np
@@ -92,7 +93,9 @@ class _Reader(object):
         if self.d[h:h + 4] != b"HEAP":
             raise Hdf5FormatError("local heap signature missing")
         seg = self.u64(h + 24) + self.base
-        end = self.d.index(b"\0", seg + off)
+        end = self.d.find(b"\0", seg + off)
+        if end < 0:
+            raise Hdf5FormatError("unterminated link name in the local heap")
         return self.d[seg + off:end].decode("ascii")
 
     def group_entries(self, btree_addr, heap_addr):
@@ -250,8 +253,15 @@ class _Reader(object):
 def read_file(path):
     """The whole file as nested dicts: groups -> dicts, datasets -> NumPy arrays (scalar
     datasets -> 0-d arrays)."""
+    # the file is mapped, not read: every dataset is copied once, from the page cache into its own
+    # array (a 600 MB Ritz-vector checkpoint is not held twice); the mapping goes with `data`
     with open(path, "rb") as f:
-        data = f.read()
+        try:
+            data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        except (ValueError, OSError):               # empty file, or a file system without mmap
+            data = f.read()
+    if len(data) < 64:
+        raise Hdf5FormatError("not an HDF5 file (too short)")
     return _Reader(data).obj(struct.unpack_from("<Q", data, 24 + (4 if data[8] == 1 else 0) + 40)[0])
 
 
