@@ -537,11 +537,12 @@ __device__ __forceinline__ void reg_walk(int t, G gen, F f)
 // LISTS: the TODs are in the tile-bucketed order and reached through the three address-sorted
 // lists of the pair; otherwise they are in time order and entry e of a walk is simply sample
 // (window start + e) -- the same code path with computed instead of loaded addresses.
-// PIPE (tile order only): the list entries of the next chunk are requested before the gathers of
-// the current one and the whole result list before the first store, invalid entries are read
-// from address 0 and zeroed by a select instead of a branch: 5 dependent memory round trips per
-// pair instead of 8.
-template <bool LISTS, bool PIPE>
+// On the tile order (LISTS) the walk is software-pipelined: both chunks of the first window list
+// are requested up front, their gathers are issued back to back together with the second list,
+// the first half of the result list is requested behind the last inverse pass; invalid entries
+// are read from address 0 and zeroed by a select instead of a branch: 4 dependent memory round
+// trips per pair (8 with one list chunk -> its gathers at a time).
+template <bool LISTS>
 __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     const PairDesc *__restrict__ pairs, int npairs, const double2 *__restrict__ W,
     const double *__restrict__ Hperm,
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
 
     // ---- load the union window: U[m] = sample (a_start - HALO) + t + 256 m ----
     double U[48];
-    if constexpr (LISTS && PIPE) {
+    if constexpr (LISTS) {
         constexpr int C = 16;
         static_assert(kRegL1 == 2 * C * kRegT && kRegL2 == C * kRegT, "chunking of the window lists");
         const uint32_t *__restrict__ lk1 = l1_k + (int64_t)pair_id * kRegL1 + t;
@@ -603,18 +604,12 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
         for (int m = 0; m < 16; ++m) U[32 + m] = b1[reg_off<1>(m)];
         __syncthreads();
     } else {
-        const uint32_t *__restrict__ lk1 = LISTS ? l1_k + (int64_t)pair_id * kRegL1 : nullptr;
-        const uint16_t *__restrict__ lq1 = LISTS ? l1_q + (int64_t)pair_id * kRegL1 : nullptr;
+        // time order: entry e of a walk is simply sample (window start + e)
         const int64_t w0 = pd.a_start - kRegHalo;         // time of window position 0
         reg_walk<kRegL1>(t, [&](int e, uint32_t &k, int &q) {
-            if (LISTS) {
-                k = lk1[e];
-                q = (int)lq1[e];
-            } else {
-                const int64_t ts = w0 + e;
-                k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
-                q = e;
-            }
+            const int64_t ts = w0 + e;
+            k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
+            q = e;
         }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
             double vv[kRegCh];
 #pragma unroll
@@ -627,17 +622,10 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
         for (int m = 0; m < 32; ++m) U[m] = b1[reg_off<1>(m)];
         __syncthreads();
         if (has_b) {
-            const uint32_t *__restrict__ lk2 = LISTS ? l2_k + (int64_t)pair_id * kRegL2 : nullptr;
-            const uint16_t *__restrict__ lq2 = LISTS ? l2_q + (int64_t)pair_id * kRegL2 : nullptr;
             reg_walk<kRegL2>(t, [&](int e, uint32_t &k, int &q) {
-                if (LISTS) {
-                    k = lk2[e];
-                    q = (int)lq2[e];
-                } else {
-                    const int64_t ts = w0 + kRegL1 + e;
-                    k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
-                    q = e;
-                }
+                const int64_t ts = w0 + kRegL1 + e;
+                k = (ts >= pd.lo && ts < pd.hi) ? (uint32_t)ts : kInvalidSample;
+                q = e;
             }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
                 double vv[kRegCh];
 #pragma unroll
@@ -701,7 +689,7 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     reg_exchange<2, 1, 16>(zi, buf, t);
     // first half of the result list, requested behind the last inverse pass
     uint32_t ks0[16], qs0[16];
-    if constexpr (LISTS && PIPE) {
+    if constexpr (LISTS) {
         const uint32_t *__restrict__ lks = ls_k + (int64_t)pair_id * kRegLS + t;
         const uint16_t *__restrict__ lqs = ls_q + (int64_t)pair_id * kRegLS + t;
 #pragma unroll
@@ -718,7 +706,7 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
             b1[reg_off<1>(m)] = zr[brev<32>(m + 8)];
             b1[reg_off<1>(m + 16)] = zi[brev<32>(m + 8)];
         }
-        if constexpr (LISTS && PIPE) {
+        if constexpr (LISTS) {
             constexpr int C = kRegLS / kRegT;
             const uint32_t *__restrict__ lks = ls_k + (int64_t)pair_id * kRegLS + t;
             const uint16_t *__restrict__ lqs = ls_q + (int64_t)pair_id * kRegLS + t;
@@ -737,18 +725,11 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
             return;
         }
         __syncthreads();
-        const uint32_t *__restrict__ lks = LISTS ? ls_k + (int64_t)pair_id * kRegLS : nullptr;
-        const uint16_t *__restrict__ lqs = LISTS ? ls_q + (int64_t)pair_id * kRegLS : nullptr;
         reg_walk<kRegLS>(t, [&](int e, uint32_t &k, int &q) {
-            if (LISTS) {
-                k = lks[e];
-                q = (int)lqs[e];
-            } else {
-                // result j: segment A for j < 4096, segment B (b_start = a_start + 4096) after
-                const bool ok = e < kRegHop ? e < pd.a_len : e - kRegHop < pd.b_len;
-                k = ok ? (uint32_t)(pd.a_start + e) : kInvalidSample;
-                q = e;
-            }
+            // result j: segment A for j < 4096, segment B (b_start = a_start + 4096) after
+            const bool ok = e < kRegHop ? e < pd.a_len : e - kRegHop < pd.b_len;
+            k = ok ? (uint32_t)(pd.a_start + e) : kInvalidSample;
+            q = e;
         }, [&](const uint32_t (&kk)[kRegCh], const int (&qq)[kRegCh]) {
 #pragma unroll
             for (int u = 0; u < kRegCh; ++u)
@@ -959,15 +940,15 @@ static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, do
     return 0;
 }
 
-template <bool LISTS, bool PIPE = false>
+template <bool LISTS>
 static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
     constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
     static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_reg<LISTS, PIPE>, lds, granted));
+    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_reg<LISTS>, lds, granted));
     if (f->npairs_reg == 0) return 0;
     const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
-    k_overlap_save_reg<LISTS, PIPE><<<grid, kRegT, lds, stream>>>(
+    k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
         f->d_pairs_reg, (int)f->npairs_reg, f->d_W_reg, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
         f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
     CM2_LAUNCH_OK();
@@ -979,11 +960,7 @@ static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, 
                     hipStream_t stream)
 {
     if (f->npairs == 0) return 0;
-    if (INDIRECT && f->d_l1_k) {
-        static const bool pipe = [] { const char *e = getenv("CM2_OS_PIPE"); return !(e && e[0] == '0'); }();
-        return pipe ? launch_reg<true, true>(f, d_v, d_out, stream)
-                    : launch_reg<true, false>(f, d_v, d_out, stream);
-    }
+    if (INDIRECT && f->d_l1_k) return launch_reg<true>(f, d_v, d_out, stream);
     if (!INDIRECT && f->reg_variant && f->reg_time_order) return launch_reg<false>(f, d_v, d_out, stream);
     if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
     if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
