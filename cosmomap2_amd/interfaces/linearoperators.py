@@ -234,6 +234,11 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
                 # keeps the tile (32 / 32 / 36 KB) plus a slice of the bucket (40 KB) in LDS, two
                 # workgroups per CU -- so there should be at least 2 x 256 tiles
                 tile_pixels = {1: 4096, 2: 2048, 3: 1536}[P.pol]
+                if P.pol == 3 and P.ncols >= 1024 * 2048:
+                    # large maps (nside 512: 2.2 ms -> 2.1 ms per matvec): 48 KB tiles still give
+                    # two workgroups per CU four rounds of tiles, and the overlap-save kernel's
+                    # address runs are a third longer
+                    tile_pixels = 2048
                 want = -(-P.ncols // 512)
                 want = max(64, -(-want // 64) * 64)
                 tile_pixels = min(tile_pixels, want)
