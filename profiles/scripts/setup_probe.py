@@ -47,7 +47,6 @@ if os.environ.get("PROBE_CPROFILE"):
     pix = torch.randint(0, npix, (nt,), generator=g, device=dev, dtype=torch.int32)
     phi = 0.3 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
     sync()
-    os.environ["CM2_SYNC_CALLS"] = "1"
     pr = cProfile.Profile(); pr.enable()
     ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi); sync()
     pr.disable()

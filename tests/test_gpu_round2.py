@@ -261,3 +261,26 @@ def test_noise_and_filter_reused_across_pointings(cm, oracle):
                 del P
     finally:
         L.set_pointing_mode("auto")
+
+
+def test_ritz_deflation_basis_with_AZ_on_exhausted_krylov_space(cm):
+    """A Z from the Arnoldi relation when the Krylov space is exhausted before ``maxiter`` (the
+    last basis vector is never stored and H's last sub-diagonal entry is ~0), with and without a
+    preconditioner, against the column-by-column product."""
+    from cosmomap2_amd import device as D
+    rng = np.random.default_rng(5)
+    n = 40
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    # 12 distinct eigenvalues: the Krylov space of any start vector has dimension <= 12
+    lam = np.repeat(np.linspace(0.05, 3.0, 12), 4)[:n]
+    As = (Q * lam).dot(Q.T)
+    As = 0.5 * (As + As.T)
+    b = rng.standard_normal(n)
+    for Ms in (None, np.eye(n) * 0.7):
+        Z, theta, AZ = cm.I.ritz_deflation_basis(As, Ms, b, 4, 30, with_AZ=True)
+        Zh, AZh = D.to_host(Z), D.to_host(AZ)
+        assert Zh.shape == (n, 4) and AZh.shape == (n, 4) and len(theta) == 4
+        np.testing.assert_allclose(AZh, As.dot(Zh), atol=1e-9 * np.abs(AZh).max())
+        # the Ritz pairs of an exhausted space are eigenpairs of M A
+        MAZ = AZh if Ms is None else Ms.dot(AZh)
+        assert np.abs(MAZ - Zh * np.asarray(theta)).max() < 1e-7 * np.abs(Zh).max()
