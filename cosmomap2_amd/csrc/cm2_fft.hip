@@ -1,37 +1,35 @@
-// cm2_fft.hip -- banded-Toeplitz N^-1 by overlap-save with a hand-written fp64 FFT that
-// lives entirely in LDS: one kernel reads the TOD once and writes the filtered TOD once.
+// cm2_fft.hip -- banded-Toeplitz N^-1 by overlap-save with a hand-written fp64 FFT: one kernel
+// reads the TOD once (x 1.5 for the window overlap) and writes the filtered TOD once.
 //
 // Reference semantics: ToeplitzLO.mult, interfaces/linearoperators.py:582-595 (symmetric
 // band, ZERO boundary at both ends of every block), dispatched per block as
 // interfaces/blkop.py:195-206.
 //
-// Algorithm per workgroup (512 threads, one CU):
-//   * two overlap-save segments A, B of the same noise block (each: hop = N - 2*halo new
-//     samples + halo = lambda-1 samples on both sides, zero outside the block) are packed
-//     as ONE complex signal z = A + iB of length N;
-//   * forward complex FFT of length N = R1*R2*R3 (decimation in frequency, three in-place
-//     radix passes through LDS, output in digit-reversed order);
+// Algorithm per workgroup (256 threads, two workgroups per CU):
+//   * two overlap-save segments A, B of the same noise block (each: 4096 new samples + a halo of
+//     2048 >= lambda-1 samples on both sides, zero outside the block) are packed as ONE complex
+//     signal z = A + iB of length N = 8192;
+//   * forward complex FFT of length N = 32*16*16 (decimation in frequency, the signal lives in
+//     registers -- 32 complex points per thread -- and passes exchange it through LDS one plane
+//     at a time, output in digit-reversed order);
 //   * pointwise product with the band's spectrum H.  H is real and even (the band is
 //     symmetric), so  ifft(H fft(A + iB)) = h*A + i h*B : no untangling is needed, and H is
 //     stored pre-permuted in the digit-reversed order and with 1/N folded in;
-//   * inverse FFT (the same three passes backwards, conjugate twiddles);
-//   * the hop samples of A (real part) and B (imaginary part) are written out.
+//   * inverse FFT (the same passes backwards, conjugate twiddles);
+//   * the 4096 results of A (real part) and of B (imaginary part) are written out.
 //
-// LDS: 2 * (N + N/32) doubles (re / im planes, one pad double every 32 to keep the
-// stride-R3 accesses of the last pass conflict-free) = 135 KB for N = 8192.
-// HBM traffic per output sample: N/hop * 8 B read + 8 B write (2 + 1 doubles at
-// lambda = 2048, N = 8192) against the 16 B algorithmic figure; the rocFFT route
-// (pack, 2 x [FFT + real pre/post kernel], spectrum multiply, unpack) moves ~7x that.
+// LDS: N + N/32 doubles (one plane, one pad double every 32) = 66 KB per workgroup.
+// HBM traffic per output sample: 1.5 x 8 B read + 8 B write against the 16 B algorithmic figure
+// (+ 15 B of address / position lists on the tile order); the rocFFT route (pack, 2 x [FFT +
+// real pre/post kernel], spectrum multiply, unpack) moves ~7x that.
 // This translation unit is compiled with FMA contraction ON (results are compared with
 // the direct sum at 1e-12, not bit for bit).
 //
-// Kernels in this file:
-//   k_overlap_save<R1,R2,R3,INDIRECT>  the LDS-resident pair kernel described above (N = 512,
-//                                      2048, 8192; time order, or tile order through idx / lists)
-//   k_overlap_save_reg                 register-resident pair kernel for N = 8192 on the tile
-//                                      order: two workgroups per CU (default for long bands)
-// Environment knobs (read when an operator / its lists are built): CM2_FUSED_VARIANT = pair,
-// CM2_OS_LISTS = 0 (per-sample index instead of address-sorted lists), CM2_FUSED_FFT_LEN.
+// k_overlap_save_reg<LISTS> serves every band length the fused path supports (lambda <= 2049), on
+// the time order (computed addresses) and on the tile-bucketed order of cm2_tiles.hip (three
+// address-sorted lists per segment pair).  The LDS-resident kernels of round 1 (both planes in
+// LDS, one workgroup per CU, transforms of 512 / 2048 / 8192 points) were slower in every case
+//  and are gone.
 #include "cm2_fft.h"
 
 #include <hipcub/hipcub.hpp>
@@ -42,8 +40,6 @@ namespace {
 
 constexpr double kCos32[32] = {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828, 0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304};
 constexpr double kSin32[32] = {0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304, 1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828};
-
-constexpr int kThreads = 512;
 
 __host__ __device__ constexpr int ilog2(int r) { return r <= 1 ? 0 : 1 + ilog2(r >> 1); }
 
@@ -57,296 +53,16 @@ __host__ __device__ constexpr int brev(int m)
 
 __device__ __forceinline__ int padi(int a) { return a + (a >> 5); }
 
-// In-register forward DFT of size R (radix-2 decimation in frequency):
-//   X[m] = sum_l x[l] exp(-2 pi i l m / R)  ends up at position brev<R>(m).
-template <int R>
-__device__ __forceinline__ void dft_regs(double (&re)[R], double (&im)[R])
-{
-#pragma unroll
-    for (int h = R / 2; h >= 1; h >>= 1) {
-#pragma unroll
-        for (int blk = 0; blk < R; blk += 2 * h) {
-#pragma unroll
-            for (int i = 0; i < h; ++i) {
-                const int a = blk + i, b = a + h;
-                const int tw = i * (32 / (2 * h));          // exponent in units of 2 pi / 32
-                const double ar = re[a], ai = im[a], br = re[b], bi = im[b];
-                re[a] = ar + br;
-                im[a] = ai + bi;
-                const double dr = ar - br, di = ai - bi;
-                if (tw == 0) {
-                    re[b] = dr;
-                    im[b] = di;
-                } else if (tw == 8) {                        // times -i
-                    re[b] = di;
-                    im[b] = -dr;
-                } else {                                     // times (c - i s)
-                    const double c = kCos32[tw], s = kSin32[tw];
-                    re[b] = dr * c + di * s;
-                    im[b] = di * c - dr * s;
-                }
-            }
-        }
-    }
-}
-
-// One in-place radix-R pass over the N-point signal held in LDS.
-//   forward: butterfly, then twiddle w_n^{j m};  inverse: conj twiddle (and optional real
-//   scale h[a]), then inverse butterfly.   n = current sub-transform length, s = n / R.
-template <int R, int N, bool INVERSE, bool TWIDDLE, bool SCALE, int T = kThreads>
-__device__ __forceinline__ void radix_pass(double *__restrict__ pre, double *__restrict__ pim,
-                                           int n, const double2 *__restrict__ W,
-                                           const double *__restrict__ hperm)
-{
-    const int s = n / R;
-    for (int beta = threadIdx.x; beta < N / R; beta += T) {
-        const int g = beta / s, j = beta - g * s;
-        const int base = g * n + j;
-        double xr[R], xi[R];
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            const int a = base + m * s;
-            xr[m] = pre[padi(a)];
-            xi[m] = pim[padi(a)];
-            if (SCALE) {
-                const double h = hperm[a];
-                xr[m] *= h;
-                xi[m] *= h;
-            }
-        }
-        // twiddles w^m, w = exp(-2 pi i (N/n) j / N): one table load, powers by a running
-        // product so that only one of them is live at a time (register pressure; the rounding
-        // error grows linearly, ~R ulp, far below the 1e-12 budget)
-        double2 w1 = double2{1.0, 0.0};
-        if (TWIDDLE) w1 = W[((N / n) * j) & (N - 1)];
-        if (!INVERSE) {
-            dft_regs<R>(xr, xi);
-            double cr = 1.0, ci = 0.0;
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                double yr = xr[brev<R>(m)], yi = xi[brev<R>(m)];
-                if (TWIDDLE && m > 0) {
-                    const double nr = cr * w1.x - ci * w1.y;
-                    ci = cr * w1.y + ci * w1.x;
-                    cr = nr;
-                    const double tr = yr * cr - yi * ci;
-                    yi = yr * ci + yi * cr;
-                    yr = tr;
-                }
-                const int a = base + m * s;
-                pre[padi(a)] = yr;
-                pim[padi(a)] = yi;
-            }
-        } else {
-            if (TWIDDLE) {
-                double cr = 1.0, ci = 0.0;
-#pragma unroll
-                for (int m = 1; m < R; ++m) {
-                    const double nr = cr * w1.x - ci * w1.y;
-                    ci = cr * w1.y + ci * w1.x;
-                    cr = nr;
-                    const double tr = xr[m] * cr + xi[m] * ci;            // times conj(w^m)
-                    xi[m] = xi[m] * cr - xr[m] * ci;
-                    xr[m] = tr;
-                }
-            }
-            // inverse DFT = swap(DFT(swap(x))): run the forward network on (im, re)
-            dft_regs<R>(xi, xr);
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int a = base + m * s;
-                pre[padi(a)] = xr[brev<R>(m)];
-                pim[padi(a)] = xi[brev<R>(m)];
-            }
-        }
-    }
-}
-
-// The innermost pass (sub-transforms of length R, contiguous in LDS) of the forward FFT,
-// the spectrum product and the first pass of the inverse FFT, all in registers: one LDS
-// round trip instead of two.  hperm is in the digit-reversed (address) order.
-template <int R, int N>
-__device__ __forceinline__ void middle_pass(double *__restrict__ pre, double *__restrict__ pim,
-                                            const double *__restrict__ hperm)
-{
-    for (int beta = threadIdx.x; beta < N / R; beta += kThreads) {
-        const int base = beta * R;
-        double xr[R], xi[R], yr[R], yi[R];
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            xr[m] = pre[padi(base + m)];
-            xi[m] = pim[padi(base + m)];
-        }
-        dft_regs<R>(xr, xi);                       // X[k] sits at position brev(k)
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double h = hperm[base + k];
-            yr[k] = xr[brev<R>(k)] * h;
-            yi[k] = xi[brev<R>(k)] * h;
-        }
-        dft_regs<R>(yi, yr);                       // inverse = swap . forward . swap
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            pre[padi(base + m)] = yr[brev<R>(m)];
-            pim[padi(base + m)] = yi[brev<R>(m)];
-        }
-    }
-}
-
 struct PairDesc {          // one workgroup's work: two segments of one noise block
     int64_t a_start, a_len, b_start, b_len, lo, hi;
     int32_t blk, pad;
 };
 
-// INDIRECT: input and output TODs are in the tile-bucketed order of cm2_tiles.hip and are
-// reached through idx[t] (position of time sample t, 0xFFFFFFFF = flagged -> reads 0, not
-// written).  Because that order is a stable partition, a segment's samples form one short
-// sequential run per pixel tile; consecutive segments are mapped to the SAME XCD (blockIdx
-// is dealt round-robin over the 8 XCDs) so that the cache lines shared by neighbouring
-// segments -- run ends and the 2*halo overlap -- are served / merged by one L2.
-template <int R1, int R2, int R3, bool INDIRECT>
-__global__ __launch_bounds__(kThreads) void k_overlap_save(
-    const PairDesc *__restrict__ pairs, int npairs, int halo, const double2 *__restrict__ W,
-    const double *__restrict__ Hperm, const uint32_t *__restrict__ idx,
-    const uint32_t *__restrict__ lst_k, const uint16_t *__restrict__ lst_q,
-    const double *__restrict__ v, double *__restrict__ out)
-{
-    constexpr int N = R1 * R2 * R3;
-    extern __shared__ double lds[];
-    double *pre = lds;
-    double *pim = lds + (N + N / 32);
-    const int per_xcd = (npairs + 7) / 8;
-    const int pair_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (pair_id >= npairs) return;
-    const PairDesc pd = pairs[pair_id];
-    const double *hperm = Hperm + (int64_t)pd.blk * N;
-
-    // all of this thread's loads are issued before the first LDS write (one HBM round trip)
-    constexpr int PER = N / kThreads;
-    if (INDIRECT) {
-        // the two windows overlap by 2*halo: walk their UNION once (N + hop positions) so that
-        // every TOD entry costs one scattered 8-byte gather, and drop it in one or both planes
-        constexpr int PER2 = 2 * PER;
-        const int hop = N - 2 * halo;
-        const bool has_b = pd.b_len > 0;
-        const int qmax = has_b ? N + hop : N;
-        // (k, q) = (position in the tile-ordered TOD, offset in the union window).  With the
-        // per-pair lists (sorted by k at setup) neighbouring lanes read neighbouring
-        // addresses -- the window's samples of one tile are one contiguous run -- so a wave
-        // touches a handful of cache lines instead of 64; without lists q is the lane's own
-        // time offset and k = idx[t] (one line per lane: the texture-address unit, at about
-        // one lane per clock and CU, then bounds the kernel).
-        const int qm = N + hop;
-        const int64_t ebase = (int64_t)pair_id * qm;
-        uint32_t kk[PER2];
-        int qq[PER2];
-        double vv[PER2];
-#pragma unroll
-        for (int u = 0; u < PER2; ++u) {
-            const int e = threadIdx.x + u * kThreads;
-            if (lst_k) {
-                kk[u] = e < qm ? lst_k[ebase + e] : kInvalidSample;
-                qq[u] = e < qm ? (int)lst_q[ebase + e] : 0xFFFF;
-            } else {
-                const int64_t t = pd.a_start - halo + e;
-                kk[u] = (e < qmax && t >= pd.lo && t < pd.hi) ? idx[t] : kInvalidSample;
-                qq[u] = e < qmax ? e : 0xFFFF;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PER2; ++u) vv[u] = (kk[u] != kInvalidSample) ? v[kk[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < PER2; ++u) {
-            const int q = qq[u];
-            if (q < N) {
-                pre[padi(q)] = vv[u];
-                if (!has_b) pim[padi(q)] = 0.0;
-            }
-            if (has_b && q >= hop && q < qmax) pim[padi(q - hop)] = vv[u];
-        }
-    } else {
-        double va[PER], vb[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int j = threadIdx.x + u * kThreads;
-            const int64_t ta = pd.a_start - halo + j;
-            const int64_t tb = pd.b_start - halo + j;
-            va[u] = (ta >= pd.lo && ta < pd.hi) ? v[ta] : 0.0;
-            vb[u] = (pd.b_len > 0 && tb >= pd.lo && tb < pd.hi) ? v[tb] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int j = threadIdx.x + u * kThreads;
-            pre[padi(j)] = va[u];
-            pim[padi(j)] = vb[u];
-        }
-    }
-    __syncthreads();
-    radix_pass<R1, N, false, true, false>(pre, pim, N, W, nullptr);
-    __syncthreads();
-    radix_pass<R2, N, false, true, false>(pre, pim, N / R1, W, nullptr);
-    __syncthreads();
-    middle_pass<R3, N>(pre, pim, hperm);
-    __syncthreads();
-    radix_pass<R2, N, true, true, false>(pre, pim, N / R1, W, nullptr);
-    __syncthreads();
-    radix_pass<R1, N, true, true, false>(pre, pim, N, W, nullptr);
-    __syncthreads();
-    if (INDIRECT) {
-        if (lst_k) {
-            constexpr int PER2 = 2 * PER;
-            const int hop = N - 2 * halo;
-            const int qm = N + hop;
-            const int64_t ebase = (int64_t)pair_id * qm;
-            uint32_t kk[PER2];
-            int qq[PER2];
-#pragma unroll
-            for (int u = 0; u < PER2; ++u) {
-                const int e = threadIdx.x + u * kThreads;
-                kk[u] = e < qm ? lst_k[ebase + e] : kInvalidSample;
-                qq[u] = e < qm ? (int)lst_q[ebase + e] : 0xFFFF;
-            }
-#pragma unroll
-            for (int u = 0; u < PER2; ++u) {
-                if (kk[u] == kInvalidSample) continue;
-                const int ja = qq[u] - halo, jb = qq[u] - hop - halo;
-                if (ja >= 0 && ja < pd.a_len) out[kk[u]] = pre[padi(qq[u])];
-                else if (jb >= 0 && jb < pd.b_len) out[kk[u]] = pim[padi(qq[u] - hop)];
-            }
-        } else {
-            // all index loads first (one round trip), then the scattered stores
-            uint32_t ka[PER], kb[PER];
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int j = threadIdx.x + u * kThreads;
-                ka[u] = j < pd.a_len ? idx[pd.a_start + j] : kInvalidSample;
-                kb[u] = j < pd.b_len ? idx[pd.b_start + j] : kInvalidSample;
-            }
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int j = threadIdx.x + u * kThreads;
-                if (ka[u] != kInvalidSample) out[ka[u]] = pre[padi(halo + j)];
-                if (kb[u] != kInvalidSample) out[kb[u]] = pim[padi(halo + j)];
-            }
-        }
-    } else {
-        for (int j = threadIdx.x; j < pd.a_len; j += kThreads)
-            out[pd.a_start + j] = pre[padi(halo + j)];
-        for (int j = threadIdx.x; j < pd.b_len; j += kThreads)
-            out[pd.b_start + j] = pim[padi(halo + j)];
-    }
-}
-
 // ------------------------------------------------------------------------------------
-// Register-resident variant of the pair kernel for N = 8192 (long bands).
-//
-// The pair kernel above keeps both planes of the complex signal in LDS (135 KB): one
-// workgroup per CU, so a CU alternates between ~12 us of FFT passes and ~17 us of dependent
-// memory round trips (list -> gather, list -> scatter) and nothing overlaps.  Here the signal
-// lives in registers -- 256 threads x 32 complex points -- and LDS is only the exchange
-// buffer between passes, ONE plane at a time (66 KB): two workgroups share a CU and one
-// computes while the other waits on HBM.  Same mathematics as radix_pass / middle_pass with
-// (R1, R2, R3) = (32, 16, 16); Hperm is laid out for that factorisation.
+// The signal lives in registers -- 256 threads x 32 complex points -- and LDS is only the
+// exchange buffer between passes, ONE plane at a time (66 KB): two workgroups share a CU and
+// one computes while the other waits on HBM.  (R1, R2, R3) = (32, 16, 16); Hperm is laid out
+// for that factorisation.
 //
 // Layouts (position a of the N-point signal held by thread t in slot m):
 //   P1: a = t + 256 m                      radix-32 pass over stride 256  (n = N)
@@ -802,39 +518,6 @@ __global__ __launch_bounds__(256) void k_reg_unpack(int64_t npairs, const uint64
     }
 }
 
-// keys of the per-pair gather lists: (pair << 32) | position in the tile-ordered TOD, value =
-// offset q in the pair's union window (0xFFFF for slots past the window of a pair without a
-// second segment).  A stable sort by key orders every pair's entries by address.
-__global__ __launch_bounds__(256) void k_list_keys(const PairDesc *__restrict__ pairs, int npairs,
-                                                    int N, int halo,
-                                                    const uint32_t *__restrict__ idx,
-                                                    uint64_t *__restrict__ keys,
-                                                    uint16_t *__restrict__ vals)
-{
-    const int hop = N - 2 * halo, qm = N + hop;
-    const int64_t total = (int64_t)npairs * qm;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t p = e / qm;
-        const int q = (int)(e - p * qm);
-        const PairDesc pd = pairs[p];
-        const int qmax = pd.b_len > 0 ? qm : N;
-        const int64_t t = pd.a_start - halo + q;
-        const uint32_t k = (q < qmax && t >= pd.lo && t < pd.hi) ? idx[t] : kInvalidSample;
-        keys[e] = ((uint64_t)p << 32) | (uint64_t)k;
-        vals[e] = q < qmax ? (uint16_t)q : (uint16_t)0xFFFF;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_list_unpack(int64_t total,
-                                                      const uint64_t *__restrict__ keys,
-                                                      uint32_t *__restrict__ lst_k)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
-        lst_k[e] = (uint32_t)(keys[e] & 0xFFFFFFFFull);
-}
-
 // W[t] = exp(-2 pi i t / N)
 __global__ void k_twiddles(int N, double2 *__restrict__ W)
 {
@@ -866,79 +549,46 @@ __global__ __launch_bounds__(256) void k_spectrum_perm(int nb, int64_t lambda, i
     }
 }
 
-// the same spectrum in the index order of another factorisation: dst[b][a(k; R1,R2,R3)] =
-// src[b][a(k; S1,S2,S3)] (a permutation instead of a second O(N lambda) cosine sum per block)
-__global__ __launch_bounds__(256) void k_spectrum_reperm(int nb, int N, int R1, int R2, int R3,
-                                                          int S1, int S2, int S3,
-                                                          const double *__restrict__ src,
-                                                          double *__restrict__ dst)
-{
-    const int64_t total = (int64_t)nb * N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t b = e / N;
-        const int a = (int)(e - b * N);
-        const int d1 = a / (R2 * R3), d2 = (a / R3) % R2, d3 = a % R3;
-        const int k = d1 + R1 * d2 + R1 * R2 * d3;
-        const int s1 = k % S1, s2 = (k / S1) % S2, s3 = k / (S1 * S2);
-        dst[e] = src[b * N + s1 * (S2 * S3) + s2 * S3 + s3];
-    }
-}
-
 }  // namespace
 
 namespace cm2 {
 
 struct FusedOS {
-    int N = 0, R1 = 0, R2 = 0, R3 = 0, halo = 0;
-    int64_t hop = 0, npairs = 0;
+    int halo = 0;
+    int64_t npairs = 0;
     PairDesc *d_pairs = nullptr;
-    double2 *d_W = nullptr;
-    double *d_Hperm = nullptr;
-    size_t lds_bytes = 0;
-    // register-resident pair kernel (N = 8192, two workgroups per CU): spectrum laid out for
-    // the (32, 16, 16) factorisation
-    bool reg_variant = false, reg_time_order = false;
-    int64_t npairs_reg = 0;
-    PairDesc *d_pairs_reg = nullptr;
-    double *d_Hperm_reg = nullptr;
-    double2 *d_W_reg = nullptr;          // exp(-2 pi i t / 8192): f->d_W belongs to f->N
+    double *d_Hperm = nullptr;           // spectrum of every block in the (32, 16, 16) digit order
+    double2 *d_W = nullptr;              // exp(-2 pi i t / 8192)
+    // address-sorted lists of the tile-order path, built for one tile plan at a time
+    uint64_t list_plan = 0;              // id of the tile plan the lists were built for
     uint32_t *d_l1_k = nullptr, *d_l2_k = nullptr, *d_ls_k = nullptr;
     uint16_t *d_l1_q = nullptr, *d_l2_q = nullptr, *d_ls_q = nullptr;
-    // address-sorted gather lists of the tile-order path, built for one tile index at a time
-    uint64_t list_plan = 0;              // id of the tile plan the lists were built for
-    uint32_t *d_lst_k = nullptr;
-    uint16_t *d_lst_q = nullptr;
 };
+
+static void free_lists(FusedOS *f)
+{
+    void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
+                     (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
+    for (void **q : ptrs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    f->list_plan = 0;
+}
 
 void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
-    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm,
-                    f->d_lst_k, f->d_lst_q, f->d_Hperm_reg, f->d_W_reg, f->d_pairs_reg, f->d_l1_k, f->d_l2_k, f->d_ls_k,
-                    f->d_l1_q, f->d_l2_q, f->d_ls_q};
+    free_lists(f);
+    void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete f;
 }
 
-bool fused_os_supported(int64_t lambda) { return lambda >= 1 && lambda - 1 <= 2048; }
+bool fused_os_supported(int64_t lambda) { return lambda >= 1 && lambda - 1 <= kRegHalo; }
 
-int64_t fused_os_length(const FusedOS *f) { return f ? f->N : 0; }
-
-template <int R1, int R2, int R3, bool INDIRECT>
-static int launch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
-                  hipStream_t stream)
-{
-    static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save<R1, R2, R3, INDIRECT>, f->lds_bytes, granted));
-    const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
-    k_overlap_save<R1, R2, R3, INDIRECT><<<grid, kThreads, f->lds_bytes, stream>>>(
-        f->d_pairs, (int)f->npairs, f->halo, f->d_W, f->d_Hperm, d_idx,
-        INDIRECT ? f->d_lst_k : nullptr, INDIRECT ? f->d_lst_q : nullptr, d_v, d_out);
-    CM2_LAUNCH_OK();
-    return 0;
-}
+int64_t fused_os_length(const FusedOS *f) { return f ? kRegN : 0; }
 
 template <bool LISTS>
 static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
@@ -946,116 +596,60 @@ static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStr
     constexpr size_t lds = sizeof(double) * (size_t)(kRegN + kRegN / 32);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_overlap_save_reg<LISTS>, lds, granted));
-    if (f->npairs_reg == 0) return 0;
-    const int grid = (int)(((f->npairs_reg + 7) / 8) * 8);
+    if (f->npairs == 0) return 0;
+    const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
-        f->d_pairs_reg, (int)f->npairs_reg, f->d_W_reg, f->d_Hperm_reg, f->d_l1_k, f->d_l1_q,
+        f->d_pairs, (int)f->npairs, f->d_W, f->d_Hperm, f->d_l1_k, f->d_l1_q,
         f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
 
-template <bool INDIRECT>
-static int dispatch(const FusedOS *f, const uint32_t *d_idx, const double *d_v, double *d_out,
-                    hipStream_t stream)
-{
-    if (f->npairs == 0) return 0;
-    if (INDIRECT && f->d_l1_k) return launch_reg<true>(f, d_v, d_out, stream);
-    if (!INDIRECT && f->reg_variant && f->reg_time_order) return launch_reg<false>(f, d_v, d_out, stream);
-    if (f->N == 8192) return launch<16, 16, 32, INDIRECT>(f, d_idx, d_v, d_out, stream);
-    if (f->N == 2048) return launch<16, 16, 8, INDIRECT>(f, d_idx, d_v, d_out, stream);
-    return launch<16, 16, 2, INDIRECT>(f, d_idx, d_v, d_out, stream);
-}
-
 int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
-    return dispatch<false>(f, nullptr, d_v, d_out, stream);
+    return launch_reg<false>(f, d_v, d_out, stream);
 }
 
+// the three address-sorted lists of every pair for the tile plan whose index is d_idx
 static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipStream_t stream)
 {
-    if (f->d_lst_k) (void)hipFree(f->d_lst_k);
-    if (f->d_lst_q) (void)hipFree(f->d_lst_q);
-    f->d_lst_k = nullptr;
-    f->d_lst_q = nullptr;
-    f->list_plan = 0;
-    const char *e = getenv("CM2_OS_LISTS");
-    if (f->npairs == 0 || (e && atoi(e) == 0)) {
-        if (f->d_l1_k) {                                     // lists of another tile index
-            void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
-                             (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
-            for (void **q : ptrs) {
-                if (*q) (void)hipFree(*q);
-                *q = nullptr;
-            }
-        }
-        f->list_plan = plan_id;                              // per-sample index mode
-        return 0;
-    }
-    if (f->reg_variant) {
-        void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
-                         (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
-        for (void **q : ptrs) {
-            if (*q) (void)hipFree(*q);
-            *q = nullptr;
-        }
-        constexpr int64_t PER = kRegL1 + kRegL2 + kRegLS;
-        const int64_t total = f->npairs_reg * PER;
-        DevTemp<uint64_t> keys_in, keys_out;
-        DevTemp<uint16_t> vals_in, vals_out;
-        DevTemp<char> d_temp;
-        CM2_HIP(keys_in.alloc(total));
-        CM2_HIP(keys_out.alloc(total));
-        CM2_HIP(vals_in.alloc(total));
-        CM2_HIP(vals_out.alloc(total));
-        k_reg_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs_reg, (int)f->npairs_reg, d_idx, keys_in,
-                                                          vals_in);
-        CM2_LAUNCH_OK();
-        int end_bit = 33;
-        while (((int64_t)1 << (end_bit - 32)) <= 3 * f->npairs_reg && end_bit < 64) ++end_bit;
-        size_t tb = 0;
-        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                   vals_out.p, total, 0, end_bit, stream));
-        CM2_HIP(d_temp.alloc(tb + 16));
-        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                   vals_out.p, total, 0, end_bit, stream));
-        CM2_HIP(hipMalloc(&f->d_l1_k, sizeof(uint32_t) * f->npairs_reg * kRegL1));
-        CM2_HIP(hipMalloc(&f->d_l2_k, sizeof(uint32_t) * f->npairs_reg * kRegL2));
-        CM2_HIP(hipMalloc(&f->d_ls_k, sizeof(uint32_t) * f->npairs_reg * kRegLS));
-        CM2_HIP(hipMalloc(&f->d_l1_q, sizeof(uint16_t) * f->npairs_reg * kRegL1));
-        CM2_HIP(hipMalloc(&f->d_l2_q, sizeof(uint16_t) * f->npairs_reg * kRegL2));
-        CM2_HIP(hipMalloc(&f->d_ls_q, sizeof(uint16_t) * f->npairs_reg * kRegLS));
-        k_reg_unpack<<<grid_for(total), kBlock, 0, stream>>>(f->npairs_reg, keys_out, vals_out, f->d_l1_k,
-                                                            f->d_l1_q, f->d_l2_k, f->d_l2_q,
-                                                            f->d_ls_k, f->d_ls_q);
-        CM2_LAUNCH_OK();
-        CM2_HIP(hipStreamSynchronize(stream));
+    free_lists(f);
+    if (f->npairs == 0) {
         f->list_plan = plan_id;
         return 0;
     }
-    const int64_t qm = f->N + f->hop, total = f->npairs * qm;
+    constexpr int64_t PER = kRegL1 + kRegL2 + kRegLS;
+    const int64_t total = f->npairs * PER;
     DevTemp<uint64_t> keys_in, keys_out;
-    DevTemp<uint16_t> vals_in;
+    DevTemp<uint16_t> vals_in, vals_out;
     DevTemp<char> d_temp;
     CM2_HIP(keys_in.alloc(total));
     CM2_HIP(keys_out.alloc(total));
     CM2_HIP(vals_in.alloc(total));
-    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
-    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
-    k_list_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs, (int)f->npairs, f->N, f->halo,
-                                                       d_idx, keys_in, vals_in);
+    CM2_HIP(vals_out.alloc(total));
+    k_reg_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs, (int)f->npairs, d_idx, keys_in, vals_in);
     CM2_LAUNCH_OK();
     int end_bit = 33;
-    while (((int64_t)1 << (end_bit - 32)) <= f->npairs && end_bit < 64) ++end_bit;
+    while (((int64_t)1 << (end_bit - 32)) <= 3 * f->npairs && end_bit < 64) ++end_bit;
     size_t tb = 0;
     CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               f->d_lst_q, total, 0, end_bit, stream));
+                                               vals_out.p, total, 0, end_bit, stream));
     CM2_HIP(d_temp.alloc(tb + 16));
     CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               f->d_lst_q, total, 0, end_bit, stream));
-    k_list_unpack<<<grid_for(total), kBlock, 0, stream>>>(total, keys_out, f->d_lst_k);
+                                               vals_out.p, total, 0, end_bit, stream));
+    struct Guard { FusedOS *f; ~Guard() { if (f) free_lists(f); } } guard{f};     // early returns
+    CM2_HIP(hipMalloc(&f->d_l1_k, sizeof(uint32_t) * f->npairs * kRegL1));
+    CM2_HIP(hipMalloc(&f->d_l2_k, sizeof(uint32_t) * f->npairs * kRegL2));
+    CM2_HIP(hipMalloc(&f->d_ls_k, sizeof(uint32_t) * f->npairs * kRegLS));
+    CM2_HIP(hipMalloc(&f->d_l1_q, sizeof(uint16_t) * f->npairs * kRegL1));
+    CM2_HIP(hipMalloc(&f->d_l2_q, sizeof(uint16_t) * f->npairs * kRegL2));
+    CM2_HIP(hipMalloc(&f->d_ls_q, sizeof(uint16_t) * f->npairs * kRegLS));
+    k_reg_unpack<<<grid_for(total), kBlock, 0, stream>>>(f->npairs, keys_out, vals_out, f->d_l1_k,
+                                                        f->d_l1_q, f->d_l2_k, f->d_l2_q,
+                                                        f->d_ls_k, f->d_ls_q);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
+    guard.f = nullptr;
     f->list_plan = plan_id;
     return 0;
 }
@@ -1065,54 +659,33 @@ int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, 
 {
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
     // again to a later plan of the same size)
-    if (f->list_plan != plan_id)
+    if (f->list_plan != plan_id || (f->npairs > 0 && !f->d_l1_k))
         if (int rc = build_lists(f, d_idx, plan_id, stream)) return rc;
-    return dispatch<true>(f, d_idx, d_v, d_out, stream);
+    return launch_reg<true>(f, d_v, d_out, stream);
 }
 
 int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
                     const std::vector<int64_t> &off, hipStream_t stream)
 {
+    CM2_CHECK(out != nullptr, "fused_os_create: out is NULL");
     *out = nullptr;
     CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
               (long long)lambda);
     FusedOS *f = new FusedOS();
     struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};   // early returns
     f->halo = (int)(lambda - 1);
-    int64_t forced = 0;
-    if (const char *e = getenv("CM2_FUSED_FFT_LEN")) forced = atoll(e);
-    if (forced == 512 || forced == 2048 || forced == 8192) {
-        CM2_CHECK(forced > 2 * f->halo, "CM2_FUSED_FFT_LEN=%lld too short for lambda=%lld",
-                  (long long)forced, (long long)lambda);
-        f->N = (int)forced;
-    } else {
-        f->N = f->halo <= 128 ? 512 : (f->halo <= 512 ? 2048 : 8192);
-    }
     const int64_t nb = (int64_t)off.size() - 1;
-    const char *variant = getenv("CM2_FUSED_VARIANT");
-    f->R1 = 16; f->R2 = 16; f->R3 = f->N / 256;
-    f->hop = f->N - 2 * (int64_t)f->halo;
-    // register-resident pair kernel for the tile-order path (fixed geometry: hop 4096, halo
-    // 2048); CM2_FUSED_VARIANT=pair keeps the LDS-resident pair kernel everywhere
-    // (it serves every band the fused path supports: on the tile order the short-FFT pair
-    // kernels gather windows of a few hundred samples, one or two per pixel tile, and take
-    // 1.3 - 3.2 ms at 1e8 samples where this kernel takes 0.9 ms whatever lambda is)
-    f->reg_variant = !(variant && strcmp(variant, "pair") == 0);
-    // the time order as well (1e8 samples, lambda 32 / 128 / 512: 0.80 ms against 1.24 / 2.06 /
-    // 0.90 ms of the short-FFT pair kernels); CM2_REG_TIME_ORDER=0 keeps those for N < 8192
-    const char *reg_time = getenv("CM2_REG_TIME_ORDER");
-    f->reg_time_order = f->N == kRegN || !(reg_time && atoi(reg_time) == 0);
-    f->lds_bytes = sizeof(double) * 2 * (size_t)(f->N + f->N / 32);
+    // segment pairs: fixed geometry (hop 4096, halo 2048 whatever lambda is)
     std::vector<PairDesc> pairs;
     for (int64_t b = 0; b < nb; ++b) {
-        for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += 2 * f->hop) {
+        for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += 2 * kRegHop) {
             PairDesc pd;
             pd.lo = off[b]; pd.hi = off[b + 1]; pd.blk = (int32_t)b; pd.pad = 0;
             pd.a_start = s0;
-            pd.a_len = (off[b + 1] - s0 < f->hop) ? off[b + 1] - s0 : f->hop;
-            pd.b_start = s0 + f->hop;
+            pd.a_len = (off[b + 1] - s0 < kRegHop) ? off[b + 1] - s0 : kRegHop;
+            pd.b_start = s0 + kRegHop;
             pd.b_len = pd.b_start < off[b + 1]
-                           ? ((off[b + 1] - pd.b_start < f->hop) ? off[b + 1] - pd.b_start : f->hop)
+                           ? ((off[b + 1] - pd.b_start < kRegHop) ? off[b + 1] - pd.b_start : kRegHop)
                            : 0;
             if (pd.b_len == 0) pd.b_start = s0;
             pairs.push_back(pd);
@@ -1123,50 +696,15 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     if (!pairs.empty())
         CM2_HIP(hipMemcpy(f->d_pairs, pairs.data(), sizeof(PairDesc) * pairs.size(),
                           hipMemcpyHostToDevice));
-    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * f->N));
-    CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * nb * f->N));
-    k_twiddles<<<(f->N + 255) / 256, 256, 0, stream>>>(f->N, f->d_W);
-    CM2_LAUNCH_OK();
-    const bool share_spectrum = f->reg_variant && f->N == kRegN;   // same transform length
-    if (!share_spectrum) {
-        k_spectrum_perm<<<grid_for(nb * f->N), kBlock, 0, stream>>>((int)nb, lambda, f->N, f->R1,
-                                                                   f->R2, f->R3, d_bands, f->d_Hperm);
-        CM2_LAUNCH_OK();
-    }
-    if (f->reg_variant) {
-        std::vector<PairDesc> rp;
-        for (int64_t b = 0; b < nb; ++b) {
-            for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += 2 * kRegHop) {
-                PairDesc pd;
-                pd.lo = off[b]; pd.hi = off[b + 1]; pd.blk = (int32_t)b; pd.pad = 0;
-                pd.a_start = s0;
-                pd.a_len = (off[b + 1] - s0 < kRegHop) ? off[b + 1] - s0 : kRegHop;
-                pd.b_start = s0 + kRegHop;
-                pd.b_len = pd.b_start < off[b + 1]
-                               ? ((off[b + 1] - pd.b_start < kRegHop) ? off[b + 1] - pd.b_start : kRegHop)
-                               : 0;
-                if (pd.b_len == 0) pd.b_start = s0;
-                rp.push_back(pd);
-            }
-        }
-        f->npairs_reg = (int64_t)rp.size();
-        CM2_HIP(hipMalloc(&f->d_pairs_reg, sizeof(PairDesc) * (rp.size() ? rp.size() : 1)));
-        if (!rp.empty())
-            CM2_HIP(hipMemcpy(f->d_pairs_reg, rp.data(), sizeof(PairDesc) * rp.size(),
-                              hipMemcpyHostToDevice));
-        CM2_HIP(hipMalloc(&f->d_Hperm_reg, sizeof(double) * nb * kRegN));
+    CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * (nb > 0 ? nb : 1) * kRegN));
+    if (nb > 0) {
         k_spectrum_perm<<<grid_for(nb * kRegN), kBlock, 0, stream>>>((int)nb, lambda, kRegN, 32, 16, 16,
-                                                                    d_bands, f->d_Hperm_reg);
-        CM2_LAUNCH_OK();
-        if (share_spectrum) {
-            k_spectrum_reperm<<<grid_for(nb * f->N), kBlock, 0, stream>>>(
-                (int)nb, f->N, f->R1, f->R2, f->R3, 32, 16, 16, f->d_Hperm_reg, f->d_Hperm);
-            CM2_LAUNCH_OK();
-        }
-        CM2_HIP(hipMalloc(&f->d_W_reg, sizeof(double2) * kRegN));
-        k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W_reg);
+                                                                    d_bands, f->d_Hperm);
         CM2_LAUNCH_OK();
     }
+    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * kRegN));
+    k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W);
+    CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
     guard.f = nullptr;
     *out = f;

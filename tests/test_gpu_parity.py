@@ -346,10 +346,10 @@ def test_toeplitz_fft_matches_direct(cm, oracle, lam, sizes):
     np.testing.assert_array_equal(Nd * v, ref)
     assert rel_l2(Nf * v, ref) < 1e-12
     assert Nf.noise_info()["method"] == 2 and Nf.noise_info()["fft_len"] > 2 * (lam - 1)
-    # hand-written LDS FFT (one kernel), all three transform lengths
+    # hand-written register FFT (one kernel, 8192 points whatever the band length is)
     Nk = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
     assert Nk.noise_info()["method"] == 3
-    assert Nk.noise_info()["fft_len"] == (512 if lam <= 129 else 2048 if lam <= 513 else 8192)
+    assert Nk.noise_info()["fft_len"] == 8192
     assert rel_l2(Nk * v, ref) < 1e-12
     ek = np.zeros(sum(sizes))
     ek[sizes[0] - 1] = 1.0
@@ -363,21 +363,18 @@ def test_toeplitz_fft_matches_direct(cm, oracle, lam, sizes):
     assert np.abs(out[sizes[0]:]).max() < 1e-13
 
 
-def test_toeplitz_long_band_pair_and_register_kernels(cm, oracle, monkeypatch):
-    """The two long-band overlap-save kernels on the time order (LDS-resident pair kernel on
-    request, register-resident kernel by default) against the direct band sum."""
+def test_toeplitz_long_band_register_kernel_on_time_order(cm, oracle):
+    """The overlap-save kernel on the time order with the longest bands it serves, ragged blocks
+    (one barely longer than a window's hop), against the direct band sum."""
     rng = np.random.default_rng(77)
-    lam, sizes = 2048, [21000, 9000, 4098]
-    k = np.arange(lam)
-    bands = [(1.0 + 0.2 * b) * np.exp(-k / 400.0) * np.cos(k / 700.0) for b in range(3)]
-    v = rng.standard_normal(sum(sizes))
-    ref = oracle.blocklo_mult(sizes, bands, True, v)
-    monkeypatch.setenv("CM2_FUSED_VARIANT", "pair")
-    Nr = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
-    assert rel_l2(Nr * v, ref) < 1e-12
-    monkeypatch.delenv("CM2_FUSED_VARIANT")
-    Np = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
-    assert rel_l2(Np * v, ref) < 1e-12
+    sizes = [21000, 9000, 4098]
+    for lam in (2048, 2049):
+        k = np.arange(lam)
+        bands = [(1.0 + 0.2 * b) * np.exp(-k / 400.0) * np.cos(k / 700.0) for b in range(3)]
+        v = rng.standard_normal(sum(sizes))
+        ref = oracle.blocklo_mult(sizes, bands, True, v)
+        Np = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+        assert rel_l2(Np * v, ref) < 1e-12
 
 
 @pytest.mark.parametrize("method", [1, 2, 3])
@@ -1166,19 +1163,14 @@ def test_pcg_with_filter_as_noise_operator(cm, oracle):
         assert rel_l2(A * xs, b) < 1e-7
 
 
-@pytest.mark.parametrize("variant", ["pair", "reg"])
-@pytest.mark.parametrize("mode", ["0", "1"])
 @pytest.mark.parametrize("tp,lam", [(2048, 40), (64, 40), (1024, 300), (2048, 1500), (512, 2049)])
-def test_overlap_save_on_tile_order_list_modes(cm, oracle, monkeypatch, mode, tp, lam, variant):
-    """The ways the fused overlap-save kernels reach the tile-ordered TOD (per-sample index;
-    address-sorted lists per segment pair with the LDS-resident pair kernel; the three lists of
-    the register-resident kernel, used for the long bands) give the same result, with flagged
-    samples, ragged blocks whose last pair ends mid-window, a block shorter than one window,
-    and tiles so small (64 pixels) that every sample is its own address run."""
+def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
+    """The overlap-save kernel reaching the tile-ordered TOD through its three address-sorted
+    lists per segment pair, for short and long bands, with flagged samples, ragged blocks whose
+    last pair ends mid-window, a block shorter than one window, and tiles so small (64 pixels)
+    that every sample is its own address run."""
     from types import SimpleNamespace
     from cosmomap2_amd.interfaces import linearoperators as L
-    monkeypatch.setenv("CM2_OS_LISTS", mode)
-    monkeypatch.setenv("CM2_FUSED_VARIANT", variant)
     pol, nt, npix, nblk = 3, 240000, 70000, 5
     d, pairs, phi, t, diag = make_problem(oracle, 900 + lam, nt, npix, nblk, pol, flag_frac=0.07)
     c, s = np.cos(2 * phi), np.sin(2 * phi)
