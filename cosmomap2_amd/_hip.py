@@ -64,6 +64,7 @@ PROTOTYPES = {
     "cm2_pcg_update_xr": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cm2_Zt_apply": [_i64, _int, _vp, _vp, _vp, _vp, _vp],
     "cm2_Z_apply": [_i64, _int, _vp, _vp, _vp, _vp],
+    "cm2_Z_axpy": [_i64, _int, _vp, _vp, _dbl, _vp, _vp],
     "cm2_gemm_tn_work_doubles": [_int, _int],
     "cm2_gemm_tn": [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "cm2_small_matvec": [_int, _vp, _vp, _vp, _vp],

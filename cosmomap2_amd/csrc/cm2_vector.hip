@@ -209,14 +209,16 @@ __global__ __launch_bounds__(256) void k_Zt_partial(int64_t n, int r, int rp, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_Zt_final(int nblk, int r, int rp,
-                                                   const double *__restrict__ partial,
-                                                   double *__restrict__ out)
+// 1024 threads: with 1024 workgroup partials and r = 32 a thread adds 32 values (256 threads:
+// 128 dependent-latency loads, 38 us -- a third of the pass over Z it follows)
+__global__ __launch_bounds__(1024) void k_Zt_final(int nblk, int r, int rp,
+                                                    const double *__restrict__ partial,
+                                                    double *__restrict__ out)
 {
-    __shared__ double lds[256];
+    __shared__ double lds[1024];
     const int col = threadIdx.x % rp;
     const int q = threadIdx.x / rp;
-    const int qn = 256 / rp;
+    const int qn = 1024 / rp;
     double acc = 0.0;
     if (col < r)
         for (int b = q; b < nblk; b += qn) acc += partial[(int64_t)b * r + col];
@@ -305,7 +307,7 @@ extern "C" int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d
         else if (r == 32) k_Zt_partial_wide<16><<<nblk, kBlock, 0, stream>>>(n, rows, d_Z, d_x, d_work);
         else k_Zt_partial_wide<32><<<nblk, kBlock, 0, stream>>>(n, rows, d_Z, d_x, d_work);
         CM2_LAUNCH_OK();
-        k_Zt_final<<<1, kBlock, 0, stream>>>(nblk, r, rp, d_work, d_out);
+        k_Zt_final<<<1, 1024, 0, stream>>>(nblk, r, rp, d_work, d_out);
         CM2_LAUNCH_OK();
         return 0;
     }
@@ -318,7 +320,7 @@ extern "C" int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d
     if (nblk < 1) nblk = 1;
     k_Zt_partial<<<nblk, kBlock, 0, stream>>>(n, r, rp, rows, d_Z, d_x, d_work);
     CM2_LAUNCH_OK();
-    k_Zt_final<<<1, kBlock, 0, stream>>>(nblk, r, rp, d_work, d_out);
+    k_Zt_final<<<1, 1024, 0, stream>>>(nblk, r, rp, d_work, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -348,6 +350,78 @@ extern "C" int cm2_Z_apply(int64_t n, int r, const double *d_Z, const double *d_
     CM2_CHECK(r >= 1 && r <= 256, "cm2_Z_apply: deflation rank r=%d out of range [1,256]", r);
     CM2_CHECK(d_Z && d_y && d_out, "cm2_Z_apply: NULL argument");
     k_Z_apply<<<grid_for(n), kBlock, 0, as_stream(stream_)>>>(n, r, d_Z, d_y, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------- w += alpha Z y ----------
+// The update of the Arnoldi orthogonalisation (w -= V h for a 32-column panel of the basis) and
+// any other place where the term order of DeflationLO.mult is not asked for: LPR = r / 2 lanes
+// read one row with 16-byte loads, a fixed butterfly adds their partial products, 8 rows per
+// lane group in flight.  Streams the panel at HBM speed (k_Z_apply above walks a 256-byte row
+// per thread with 8-byte loads: 4.5 TB/s, plus a vector pass for the axpy).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_Z_axpy_wide(int64_t n, const double *__restrict__ Z,
+                                                      const double *__restrict__ y, double alpha,
+                                                      double *__restrict__ w)
+{
+    constexpr int R = 2 * LPR, RPW = 64 / LPR, RSTEP = 4 * RPW, U = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rg = lane / LPR;
+    const double y0 = y[2 * sub], y1 = y[2 * sub + 1];
+    const int64_t stride = (int64_t)gridDim.x * RSTEP * U;
+    for (int64_t base = (int64_t)blockIdx.x * RSTEP * U; base < n; base += stride) {
+        double2 z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = base + u * RSTEP + wave * RPW + rg;
+            if (i >= n) i = n - 1;
+            z[u] = *reinterpret_cast<const double2 *>(Z + i * R + 2 * sub);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double p = z[u].x * y0 + z[u].y * y1;
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            const int64_t i = base + u * RSTEP + wave * RPW + rg;
+            if (sub == 0 && i < n) w[i] += alpha * p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_Z_axpy(int64_t n, int r, const double *__restrict__ Z,
+                                                 const double *__restrict__ y, double alpha,
+                                                 double *__restrict__ w)
+{
+    __shared__ double ys[256];
+    if (threadIdx.x < r) ys[threadIdx.x] = y[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double *zr = Z + i * r;
+        double acc = 0.0;
+        for (int k = 0; k < r; ++k) acc += zr[k] * ys[k];
+        w[i] += alpha * acc;
+    }
+}
+
+extern "C" int cm2_Z_axpy(int64_t n, int r, const double *d_Z, const double *d_y, double alpha,
+                          double *d_w, void *stream_)
+{
+    CM2_CHECK(r >= 1 && r <= 256, "cm2_Z_axpy: r=%d out of range [1,256]", r);
+    CM2_CHECK(d_Z && d_y && d_w && d_Z != d_w, "cm2_Z_axpy: NULL or aliased argument");
+    if (n <= 0) return 0;
+    hipStream_t stream = as_stream(stream_);
+    if ((r == 16 || r == 32 || r == 64) && (reinterpret_cast<uintptr_t>(d_Z) & 15) == 0) {
+        const int rows_per_blk = 4 * (128 / r) * 8;
+        const int64_t nblk = (n + rows_per_blk - 1) / rows_per_blk;
+        const int g = (int)(nblk < kNumCU * 16 ? nblk : kNumCU * 16);
+        if (r == 16) k_Z_axpy_wide<8><<<g, kBlock, 0, stream>>>(n, d_Z, d_y, alpha, d_w);
+        else if (r == 32) k_Z_axpy_wide<16><<<g, kBlock, 0, stream>>>(n, d_Z, d_y, alpha, d_w);
+        else k_Z_axpy_wide<32><<<g, kBlock, 0, stream>>>(n, d_Z, d_y, alpha, d_w);
+    } else {
+        k_Z_axpy<<<grid_for(n), kBlock, 0, stream>>>(n, r, d_Z, d_y, alpha, d_w);
+    }
     CM2_LAUNCH_OK();
     return 0;
 }

@@ -204,10 +204,8 @@ class _BasisPanels(object):
     def subtract(self, w, coeff_dev):
         """w -= sum_j coeff_j v_j."""
         for i, pnl in enumerate(self.panels):
-            corr = D.empty(self.n)
-            _hip.call("cm2_Z_apply", self.n, _PANEL, D.ptr(pnl),
-                      D.ptr(coeff_dev[i * _PANEL:(i + 1) * _PANEL]), D.ptr(corr), D.stream())
-            _hip.call("cm2_axpy", self.n, -1.0, D.ptr(corr), D.ptr(w), D.stream())
+            _hip.call("cm2_Z_axpy", self.n, _PANEL, D.ptr(pnl),
+                      D.ptr(coeff_dev[i * _PANEL:(i + 1) * _PANEL]), -1.0, D.ptr(w), D.stream())
 
 
 def _arnoldi_M(A, x0d, M, nmax):

@@ -240,7 +240,14 @@ int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d_pq, const 
 int cm2_Zt_apply(int64_t n, int r, const double *d_Z, const double *d_x, double *d_out,
                  double *d_work, void *stream);                 /* out[r] = Z^T x  (:1051-1056) */
 int cm2_Z_apply(int64_t n, int r, const double *d_Z, const double *d_y, double *d_out,
-                void *stream);                                  /* out[n] = Z y    (:1041-1050) */
+                void *stream);
+
+/* w += alpha * Z y for a row-major n x r panel Z: the update step of the Arnoldi
+ * orthogonalisation (w -= V h, interfaces/deflationlib.py:88-93 -- the reference's loop of r
+ * axpy calls) in one pass over the panel; the order of the r terms is a fixed tree, not the
+ * k = 0..r-1 order of cm2_Z_apply. */
+int cm2_Z_axpy(int64_t n, int r, const double *d_Z, const double *d_y, double alpha,
+               double *d_w, void *stream);                                  /* out[n] = Z y    (:1041-1050) */
 /* E[r1 x r2] (row-major) = Z1^T Z2, fp64 MFMA panels when r1,r2 are multiples of
  * 16 (CoarseLO.__init__: dgemm(Z, Az.T), :1019).  d_work >= cm2_gemm_tn_work_doubles(r1,r2). */
 int64_t cm2_gemm_tn_work_doubles(int r1, int r2);

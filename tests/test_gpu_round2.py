@@ -284,3 +284,15 @@ def test_ritz_deflation_basis_with_AZ_on_exhausted_krylov_space(cm):
         # the Ritz pairs of an exhausted space are eigenpairs of M A
         MAZ = AZh if Ms is None else Ms.dot(AZh)
         assert np.abs(MAZ - Zh * np.asarray(theta)).max() < 1e-7 * np.abs(Zh).max()
+
+
+@pytest.mark.parametrize("n,r", [(5000, 32), (4099, 16), (777, 64), (1000, 5), (3, 32)])
+def test_Z_axpy(cm, n, r):
+    """cm2_Z_axpy: w += alpha Z y in one pass over a row-major panel (wide loads for r = 16, 32,
+    64; the Arnoldi orthogonalisation's update) against NumPy."""
+    from cosmomap2_amd import _hip, device as D
+    rng = np.random.default_rng(n + r)
+    Z, y, w = rng.standard_normal((n, r)), rng.standard_normal(r), rng.standard_normal(n)
+    dZ, dy, dw = D.f64(Z), D.f64(y), D.f64(w.copy())
+    _hip.call("cm2_Z_axpy", n, r, D.ptr(dZ), D.ptr(dy), -0.75, D.ptr(dw), D.stream())
+    np.testing.assert_allclose(dw.cpu().numpy(), w - 0.75 * Z.dot(y), rtol=1e-13, atol=1e-13)
