@@ -504,15 +504,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn_scalar(int64_t n, int r1, int r
     }
 }
 
+// 16 entries of E per workgroup, 16 threads per entry (each adds every 16th partial matrix, then
+// the 16 sums are added in order): 512 partials in 32 dependent loads instead of 512
 __global__ __launch_bounds__(256) void k_gemm_tn_final(int nparts, int rr,
                                                         const double *__restrict__ work,
                                                         double *__restrict__ E)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rr) return;
+    __shared__ double lds[256];
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
     double acc = 0.0;
-    for (int p = 0; p < nparts; ++p) acc += work[(int64_t)p * rr + e];
-    E[e] = acc;
+    if (e < rr)
+        for (int p = q; p < nparts; p += 16) acc += work[(int64_t)p * rr + e];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && e < rr) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += lds[16 * k + el];
+        E[e] = s;
+    }
 }
 
 // The same contraction for R = 32 h (h = 1, 2) with 16-byte loads: lane (m, k) reads the column
@@ -650,7 +660,7 @@ extern "C" int cm2_gemm_tn(int64_t n, int r1, int r2, const double *d_Z1, const 
         k_gemm_tn_scalar<<<nparts, kBlock, 0, stream>>>(n, r1, r2, d_Z1, d_Z2, d_work);
     }
     CM2_LAUNCH_OK();
-    k_gemm_tn_final<<<(rr + kBlock - 1) / kBlock, kBlock, 0, stream>>>(nparts, rr, d_work, d_E);
+    k_gemm_tn_final<<<(rr + 15) / 16, kBlock, 0, stream>>>(nparts, rr, d_work, d_E);
     CM2_LAUNCH_OK();
     return 0;
 }
