@@ -142,6 +142,13 @@ def multiply(d, x):
     return d * x
 
 
+def dot_dev(x, y):
+    """Device dot product left in HBM (a 1-element tensor; no synchronisation)."""
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    _hip.call("cm2_dot", x.numel(), ptr(x), ptr(y), ptr(out), ptr(reduce_work()), stream())
+    return out
+
+
 def dot(x, y):
     """Device dot product -> python float (synchronises)."""
     out = torch.empty(1, dtype=torch.float64, device=x.device)

@@ -233,22 +233,29 @@ def _arnoldi_M(A, x0d, M, nmax):
         Vb.append(D.scaled(1.0 / nrm, Mv))
     H = np.zeros((nmax + 1, nmax))
     k_done = 0
+    hmax = 0.0                                         # largest |H| entry seen so far
     for k in range(nmax):
         Av = _apply(A, Vb.vecs[k]).clone()
-        for _sweep in range(2):
-            h = Vb.dots(Av)                            # duals V: <v_j, Av> = <p_j, Av>_M
-            H[:k + 1, k] += D.to_host(h)[:k + 1]
-            Pb.subtract(Av, h)
-        if M is None:
+        h = Vb.dots(Av)                                # duals V: <v_j, Av> = <p_j, Av>_M
+        Pb.subtract(Av, h)
+        h2 = Vb.dots(Av)                               # second sweep on the corrected vector
+        Pb.subtract(Av, h2)
+        hk = h + h2                                    # stays in HBM: the column is fetched with
+        if M is None:                                  # the norm below, one synchronisation a step
             MAv = Av
-            nrm = _norm(Av)
+            ss = D.dot_dev(Av, Av)
         else:
             MAv = _apply(M, Av)
-            nrm = math.sqrt(abs(D.dot(Av, MAv)))
+            ss = D.dot_dev(Av, MAv)
+        col = D.to_host(D.torch.cat([hk[:k + 1], ss]))
+        H[:k + 1, k] = col[:k + 1]
+        nrm = math.sqrt(abs(float(col[k + 1])))
         H[k + 1, k] = nrm
         k_done = k + 1
-        if nrm <= 1e-10 * max(abs(H[:k + 1, :k + 1]).max(), 1e-300):   # Krylov space exhausted
+        hmax = max(hmax, float(np.abs(col[:k + 1]).max()))
+        if nrm <= 1e-10 * max(hmax, 1e-300):           # Krylov space exhausted
             break
+        hmax = max(hmax, nrm)
         Pb.append(D.scaled(1.0 / nrm, Av))
         if M is not None:
             Vb.append(D.scaled(1.0 / nrm, MAv))
