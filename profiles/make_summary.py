@@ -22,13 +22,15 @@ import shutil
 import sys
 
 HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles_fixed", "k_Pt_tiles<", "k_PtNP_sell", "k_P_time",
-       "k_Pt_sell", "k_Zt_partial_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs", "k_panel_gemm_mfma",
+       "k_Pt_sell", "k_Zt_partial_wide", "k_Z_axpy_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs", "k_panel_gemm_mfma",
        "k_bdprecond", "k_dot_partial", "k_pcg_update_xr", "k_pcg_update_p"]
 
 
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
     bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+    if not bench.get("commit"):                      # the GPU box has no .git: the caller knows
+        bench["commit"] = os.environ.get("CM2_PROFILE_COMMIT")
     json.dump(bench, open(os.path.join(here, tag + "_bench_c4.json"), "w"), indent=1)
     newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
     ks = newest(os.path.join(src, "kt", "**", "*_kernel_stats.csv"))
@@ -56,7 +58,7 @@ def main(src, tag):
            "k_Pt_tiles_fixed": 28.0 * nt + 24 * npix, "k_Pt_tiles<": 28.0 * nt + 24 * npix,
            "k_PtNP_sell": 28.0 * nt + 48 * npix,
            "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix,
-           "k_Zt_partial_wide": zb + 8.0 * n, "k_Z_apply": zb + 16.0 * n,
+           "k_Zt_partial_wide": zb + 8.0 * n, "k_Z_axpy_wide": zb + 16.0 * n, "k_Z_apply": zb + 16.0 * n,
            "k_m2_finish_wide": 2 * zb + 16.0 * n + 56.0 * npix, "k_gemm_tn_mfma_pairs": 2 * zb,
            "k_panel_gemm_mfma": 8.0 * n * 32 + 2 * zb,      # one 32-column panel in, r columns updated
            "k_bdprecond": 16.0 * n + 56.0 * npix, "k_dot_partial": 16.0 * n,
