@@ -235,6 +235,7 @@ constexpr int kRegHop = 4096, kRegHalo = 2048;
 #endif
 constexpr int kRegCh = CM2_REG_CH;
 constexpr int kRegL1 = kRegN, kRegL2 = kRegHop, kRegLS = 2 * kRegHop;     // list lengths per pair
+constexpr int kRegPer = kRegL1 + kRegL2 + kRegLS;                          // list entries per pair
 
 // walk LEN (address, position) entries, kRegCh per thread at a time: gen(e, k, q) yields entry e
 template <int LEN, class G, class F>
@@ -262,9 +263,7 @@ template <bool LISTS>
 __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     const PairDesc *__restrict__ pairs, int npairs, const double2 *__restrict__ W,
     const double *__restrict__ Hperm,
-    const uint32_t *__restrict__ l1_k, const uint16_t *__restrict__ l1_q,
-    const uint32_t *__restrict__ l2_k, const uint16_t *__restrict__ l2_q,
-    const uint32_t *__restrict__ ls_k, const uint16_t *__restrict__ ls_q,
+    const uint32_t *__restrict__ lst_k, const uint16_t *__restrict__ lst_q,
     const double *__restrict__ v, double *__restrict__ out)
 {
     constexpr int N = kRegN;
@@ -283,10 +282,11 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     if constexpr (LISTS) {
         constexpr int C = 16;
         static_assert(kRegL1 == 2 * C * kRegT && kRegL2 == C * kRegT, "chunking of the window lists");
-        const uint32_t *__restrict__ lk1 = l1_k + (int64_t)pair_id * kRegL1 + t;
-        const uint16_t *__restrict__ lq1 = l1_q + (int64_t)pair_id * kRegL1 + t;
-        const uint32_t *__restrict__ lk2 = l2_k + (int64_t)pair_id * kRegL2 + t;
-        const uint16_t *__restrict__ lq2 = l2_q + (int64_t)pair_id * kRegL2 + t;
+        // the pair's three lists lie one behind the other: window part 1, part 2, results
+        const uint32_t *__restrict__ lk1 = lst_k + (int64_t)pair_id * kRegPer + t;
+        const uint16_t *__restrict__ lq1 = lst_q + (int64_t)pair_id * kRegPer + t;
+        const uint32_t *__restrict__ lk2 = lk1 + kRegL1;
+        const uint16_t *__restrict__ lq2 = lq1 + kRegL1;
         uint32_t ka[C], kb[C], kc[C];
         uint32_t qa[C], qb[C], qc[C];
         double vv[C], vw[C];
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     // first half of the result list, requested behind the last inverse pass
     uint32_t ks0[16], qs0[16];
     if constexpr (LISTS) {
-        const uint32_t *__restrict__ lks = ls_k + (int64_t)pair_id * kRegLS + t;
-        const uint16_t *__restrict__ lqs = ls_q + (int64_t)pair_id * kRegLS + t;
+        const uint32_t *__restrict__ lks = lst_k + (int64_t)pair_id * kRegPer + kRegL1 + kRegL2 + t;
+        const uint16_t *__restrict__ lqs = lst_q + (int64_t)pair_id * kRegPer + kRegL1 + kRegL2 + t;
 #pragma unroll
         for (int u = 0; u < 16; ++u) { ks0[u] = lks[u * kRegT]; qs0[u] = lqs[u * kRegT]; }
         __builtin_amdgcn_sched_barrier(0);
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
         }
         if constexpr (LISTS) {
             constexpr int C = kRegLS / kRegT;
-            const uint32_t *__restrict__ lks = ls_k + (int64_t)pair_id * kRegLS + t;
-            const uint16_t *__restrict__ lqs = ls_q + (int64_t)pair_id * kRegLS + t;
+            const uint32_t *__restrict__ lks = lst_k + (int64_t)pair_id * kRegPer + kRegL1 + kRegL2 + t;
+            const uint16_t *__restrict__ lqs = lst_q + (int64_t)pair_id * kRegPer + kRegL1 + kRegL2 + t;
             uint32_t ks[C], qs[C];
 #pragma unroll
             for (int u = 0; u < 16; ++u) { ks[u] = ks0[u]; qs[u] = qs0[u]; }
@@ -454,69 +454,50 @@ __global__ __launch_bounds__(kRegT, 2) void k_overlap_save_reg(
     }
 }
 
-// keys of the three lists of the register-resident kernel, 20480 entries per pair:
-//   [0, 8192)      U[q], q = e              -> list 0, value q
-//   [8192, 12288)  U[q], q = e              -> list 1, value q - 8192
-//   [12288, 20480) results R[j], j = e - 12288 (A: j < 4096, B: j - 4096) -> list 2, value j
-// key = ((3 pair + list) << 32) | address; a stable sort orders every list by address.
-__global__ __launch_bounds__(256) void k_reg_keys(const PairDesc *__restrict__ pairs, int npairs,
-                                                   const uint32_t *__restrict__ idx,
-                                                   uint64_t *__restrict__ keys,
+// entries of the three lists of pairs [p0, p0 + np), 20480 per pair, in the order they are stored:
+//   [0, 8192)      U[q], q = e              -> value q
+//   [8192, 12288)  U[q], q = e              -> value q - 8192
+//   [12288, 20480) results R[j], j = e - 12288 (A: j < 4096, B: j - 4096) -> value j
+// key = address in the tile order (0xFFFFFFFF: no sample); a segmented sort then orders every
+// list by address.
+__global__ __launch_bounds__(256) void k_reg_keys(const PairDesc *__restrict__ pairs, int64_t p0,
+                                                   int64_t np, const uint32_t *__restrict__ idx,
+                                                   uint32_t *__restrict__ keys,
                                                    uint16_t *__restrict__ vals)
 {
-    constexpr int PER = kRegL1 + kRegL2 + kRegLS;
-    const int64_t total = (int64_t)npairs * PER;
+    const int64_t total = np * kRegPer;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const int64_t p = g / PER;
-        const int e = (int)(g - p * PER);
-        const PairDesc pd = pairs[p];
+        const int64_t p = g / kRegPer;
+        const int e = (int)(g - p * kRegPer);
+        const PairDesc pd = pairs[p0 + p];
         uint32_t k = kInvalidSample;
-        int list, val;
+        int val;
         if (e < kRegL1 + kRegL2) {
-            list = e < kRegL1 ? 0 : 1;
             val = e < kRegL1 ? e : e - kRegL1;
             const int64_t ts = pd.a_start - kRegHalo + e;
-            if (ts >= pd.lo && ts < pd.hi && (list == 0 || pd.b_len > 0)) k = idx[ts];
+            if (ts >= pd.lo && ts < pd.hi && (e < kRegL1 || pd.b_len > 0)) k = idx[ts];
         } else {
-            list = 2;
             val = e - (kRegL1 + kRegL2);
             const int ja = val, jb = val - kRegHop;
             if (ja < pd.a_len && ja < kRegHop) k = idx[pd.a_start + ja];
             else if (jb >= 0 && jb < pd.b_len) k = idx[pd.b_start + jb];
         }
-        keys[g] = ((uint64_t)(3 * p + list) << 32) | (uint64_t)k;
+        keys[g] = k;
         vals[g] = (uint16_t)val;
     }
 }
 
-// split the sorted (key, value) stream into the three per-pair lists
-__global__ __launch_bounds__(256) void k_reg_unpack(int64_t npairs, const uint64_t *__restrict__ keys,
-                                                     const uint16_t *__restrict__ vals,
-                                                     uint32_t *__restrict__ l1_k, uint16_t *__restrict__ l1_q,
-                                                     uint32_t *__restrict__ l2_k, uint16_t *__restrict__ l2_q,
-                                                     uint32_t *__restrict__ ls_k, uint16_t *__restrict__ ls_q)
-{
-    constexpr int PER = kRegL1 + kRegL2 + kRegLS;
-    const int64_t total = npairs * PER;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const int64_t p = g / PER;
-        const int e = (int)(g - p * PER);
-        const uint32_t k = (uint32_t)(keys[g] & 0xFFFFFFFFull);
-        const uint16_t q = vals[g];
-        if (e < kRegL1) {
-            l1_k[p * kRegL1 + e] = k;
-            l1_q[p * kRegL1 + e] = q;
-        } else if (e < kRegL1 + kRegL2) {
-            l2_k[p * kRegL2 + (e - kRegL1)] = k;
-            l2_q[p * kRegL2 + (e - kRegL1)] = q;
-        } else {
-            ls_k[p * kRegLS + (e - kRegL1 - kRegL2)] = k;
-            ls_q[p * kRegLS + (e - kRegL1 - kRegL2)] = q;
-        }
+// first (end = 0) / one-past-last (end = 1) entry of list s % 3 of pair s / 3, relative to the
+// chunk being sorted (both offset iterators of the segmented sort must have one type)
+struct ListOffset {
+    int end;
+    __host__ __device__ int operator()(int s) const
+    {
+        const int l = s % 3 + end;
+        return (s / 3) * kRegPer + (l == 0 ? 0 : (l == 1 ? kRegL1 : (l == 2 ? kRegL1 + kRegL2 : kRegPer)));
     }
-}
+};
 
 // W[t] = exp(-2 pi i t / N)
 __global__ void k_twiddles(int N, double2 *__restrict__ W)
@@ -561,18 +542,16 @@ struct FusedOS {
     double2 *d_W = nullptr;              // exp(-2 pi i t / 8192)
     // address-sorted lists of the tile-order path, built for one tile plan at a time
     uint64_t list_plan = 0;              // id of the tile plan the lists were built for
-    uint32_t *d_l1_k = nullptr, *d_l2_k = nullptr, *d_ls_k = nullptr;
-    uint16_t *d_l1_q = nullptr, *d_l2_q = nullptr, *d_ls_q = nullptr;
+    uint32_t *d_lst_k = nullptr;         // [npairs][20480] addresses: window part 1 | part 2 | results
+    uint16_t *d_lst_q = nullptr;         // positions in the window / result window
 };
 
 static void free_lists(FusedOS *f)
 {
-    void **ptrs[] = {(void **)&f->d_l1_k, (void **)&f->d_l2_k, (void **)&f->d_ls_k,
-                     (void **)&f->d_l1_q, (void **)&f->d_l2_q, (void **)&f->d_ls_q};
-    for (void **q : ptrs) {
-        if (*q) (void)hipFree(*q);
-        *q = nullptr;
-    }
+    if (f->d_lst_k) (void)hipFree(f->d_lst_k);
+    if (f->d_lst_q) (void)hipFree(f->d_lst_q);
+    f->d_lst_k = nullptr;
+    f->d_lst_q = nullptr;
     f->list_plan = 0;
 }
 
@@ -599,8 +578,7 @@ static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStr
     if (f->npairs == 0) return 0;
     const int grid = (int)(((f->npairs + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_overlap_save_reg<LISTS><<<grid, kRegT, lds, stream>>>(
-        f->d_pairs, (int)f->npairs, f->d_W, f->d_Hperm, f->d_l1_k, f->d_l1_q,
-        f->d_l2_k, f->d_l2_q, f->d_ls_k, f->d_ls_q, d_v, d_out);
+        f->d_pairs, (int)f->npairs, f->d_W, f->d_Hperm, f->d_lst_k, f->d_lst_q, d_v, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -618,36 +596,37 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
         f->list_plan = plan_id;
         return 0;
     }
-    constexpr int64_t PER = kRegL1 + kRegL2 + kRegLS;
-    const int64_t total = f->npairs * PER;
-    DevTemp<uint64_t> keys_in, keys_out;
-    DevTemp<uint16_t> vals_in, vals_out;
-    DevTemp<char> d_temp;
-    CM2_HIP(keys_in.alloc(total));
-    CM2_HIP(keys_out.alloc(total));
-    CM2_HIP(vals_in.alloc(total));
-    CM2_HIP(vals_out.alloc(total));
-    k_reg_keys<<<grid_for(total), kBlock, 0, stream>>>(f->d_pairs, (int)f->npairs, d_idx, keys_in, vals_in);
-    CM2_LAUNCH_OK();
-    int end_bit = 33;
-    while (((int64_t)1 << (end_bit - 32)) <= 3 * f->npairs && end_bit < 64) ++end_bit;
-    size_t tb = 0;
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               vals_out.p, total, 0, end_bit, stream));
-    CM2_HIP(d_temp.alloc(tb + 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               vals_out.p, total, 0, end_bit, stream));
+    const int64_t total = f->npairs * kRegPer;
     struct Guard { FusedOS *f; ~Guard() { if (f) free_lists(f); } } guard{f};     // early returns
-    CM2_HIP(hipMalloc(&f->d_l1_k, sizeof(uint32_t) * f->npairs * kRegL1));
-    CM2_HIP(hipMalloc(&f->d_l2_k, sizeof(uint32_t) * f->npairs * kRegL2));
-    CM2_HIP(hipMalloc(&f->d_ls_k, sizeof(uint32_t) * f->npairs * kRegLS));
-    CM2_HIP(hipMalloc(&f->d_l1_q, sizeof(uint16_t) * f->npairs * kRegL1));
-    CM2_HIP(hipMalloc(&f->d_l2_q, sizeof(uint16_t) * f->npairs * kRegL2));
-    CM2_HIP(hipMalloc(&f->d_ls_q, sizeof(uint16_t) * f->npairs * kRegLS));
-    k_reg_unpack<<<grid_for(total), kBlock, 0, stream>>>(f->npairs, keys_out, vals_out, f->d_l1_k,
-                                                        f->d_l1_q, f->d_l2_k, f->d_l2_q,
-                                                        f->d_ls_k, f->d_ls_q);
-    CM2_LAUNCH_OK();
+    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
+    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    // One segment per list, 32-bit keys: every segment (4096 or 8192 entries) is sorted inside one
+    // workgroup -- 4 ms at 1e8 samples where a global sort on (pair, list, address) keys took 12.
+    // hipCUB counts items in int: pairs go through in chunks of at most 2^30 entries.
+    const int64_t chunk_pairs = ((int64_t)1 << 30) / kRegPer;
+    const int64_t cp_max = f->npairs < chunk_pairs ? f->npairs : chunk_pairs;
+    DevTemp<uint32_t> keys_in;
+    DevTemp<uint16_t> vals_in;
+    DevTemp<char> d_temp;
+    CM2_HIP(keys_in.alloc(cp_max * kRegPer));
+    CM2_HIP(vals_in.alloc(cp_max * kRegPer));
+    hipcub::CountingInputIterator<int> seg_id(0);
+    using OffsetIt = hipcub::TransformInputIterator<int, ListOffset, hipcub::CountingInputIterator<int>>;
+    OffsetIt seg_begin(seg_id, ListOffset{0}), seg_end(seg_id, ListOffset{1});
+    size_t tb = 0;
+    CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
+        nullptr, tb, keys_in.p, f->d_lst_k, vals_in.p, f->d_lst_q, (int)(cp_max * kRegPer),
+        (int)(3 * cp_max), seg_begin, seg_end, 0, 32, stream));
+    CM2_HIP(d_temp.alloc(tb + 16));
+    for (int64_t p0 = 0; p0 < f->npairs; p0 += chunk_pairs) {
+        const int64_t np = f->npairs - p0 < chunk_pairs ? f->npairs - p0 : chunk_pairs;
+        k_reg_keys<<<grid_for(np * kRegPer), kBlock, 0, stream>>>(f->d_pairs, p0, np, d_idx, keys_in, vals_in);
+        CM2_LAUNCH_OK();
+        size_t tbc = tb;
+        CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
+            d_temp.p, tbc, keys_in.p, f->d_lst_k + p0 * kRegPer, vals_in.p, f->d_lst_q + p0 * kRegPer,
+            (int)(np * kRegPer), (int)(3 * np), seg_begin, seg_end, 0, 32, stream));
+    }
     CM2_HIP(hipStreamSynchronize(stream));
     guard.f = nullptr;
     f->list_plan = plan_id;
@@ -659,7 +638,7 @@ int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, 
 {
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
     // again to a later plan of the same size)
-    if (f->list_plan != plan_id || (f->npairs > 0 && !f->d_l1_k))
+    if (f->list_plan != plan_id || (f->npairs > 0 && !f->d_lst_k))
         if (int rc = build_lists(f, d_idx, plan_id, stream)) return rc;
     return launch_reg<true>(f, d_v, d_out, stream);
 }
