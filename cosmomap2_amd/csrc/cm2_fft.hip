@@ -603,7 +603,9 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
     // One segment per list, 32-bit keys: every segment (4096 or 8192 entries) is sorted inside one
     // workgroup -- 4 ms at 1e8 samples where a global sort on (pair, list, address) keys took 12.
     // hipCUB counts items in int: pairs go through in chunks of at most 2^30 entries.
-    const int64_t chunk_pairs = ((int64_t)1 << 30) / kRegPer;
+    int64_t chunk_pairs = ((int64_t)1 << 30) / kRegPer;
+    if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS"))      // test hook: force several chunks
+        if (atoll(e) > 0 && atoll(e) < chunk_pairs) chunk_pairs = atoll(e);
     const int64_t cp_max = f->npairs < chunk_pairs ? f->npairs : chunk_pairs;
     DevTemp<uint32_t> keys_in;
     DevTemp<uint16_t> vals_in;

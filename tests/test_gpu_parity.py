@@ -1186,6 +1186,29 @@ def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
     assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12
 
 
+def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
+    """The address lists are sorted in chunks of at most 2^30 entries (hipCUB counts in int);
+    with the chunk forced down to 3 segment pairs the operator must not change."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    pol, nt, npix, nblk, lam = 3, 240000, 70000, 5, 300
+    d, pairs, phi, t, diag = make_problem(oracle, 1234, nt, npix, nblk, pol, flag_frac=0.05)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    sizes = [100000, 60000, 70000, 7000, 3000]
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
+    x = np.random.default_rng(1).standard_normal(pol * npix)
+    outs = []
+    for chunk in (None, "3"):
+        if chunk:
+            monkeypatch.setenv("CM2_OS_LIST_CHUNK_PAIRS", chunk)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        L._sparse_tiles(P, tile_pixels=1024, slice_samples=4096)
+        Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+        outs.append(np.asarray(L._TiledNormalLO(P, Nf) * x))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
     """Size-independent properties of P^T N^-1 P at a BASELINE configuration's full size
     (generated in HBM).  No oracle run at this size (the direct band sum is 2e11 multiply-adds
