@@ -284,7 +284,8 @@ def main():
                      "local_matvec_ms": round(1e3 * el_local / args.steps, 4),
                      "exposed_allreduce_ms": round(ms_per_step - 1e3 * el_local / args.steps, 4),
                      "allreduce_bytes": 8 * n,
-                     "allreduce_chunks": int(os.environ.get("CM2_ALLREDUCE_CHUNKS", "4"))}
+                     "allreduce_chunks": (int(os.environ["CM2_ALLREDUCE_CHUNKS"]) if os.environ.get("CM2_ALLREDUCE_CHUNKS")
+                                          else (4 if nt >= 40_000_000 else 2 if nt >= 15_000_000 else 1))}
 
     # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
     def ev_time(fn, reps):

@@ -117,13 +117,22 @@ class ShardedLO(lp.LinearOperator):
         = one all-reduce after the matvec)."""
         import os
         dist = torch.distributed
-        chunks = int(os.environ.get("CM2_ALLREDUCE_CHUNKS", "4"))
-        if chunks <= 1 or not (dist.is_available() and dist.is_initialized()) \
+        if not (dist.is_available() and dist.is_initialized()) \
                 or dist.get_world_size(self.group) == 1:
             return None
         plan = getattr(self.local_op, "_compiled", None)
         ops = plan() if plan is not None else [self.local_op]
         if len(ops) != 1 or not hasattr(ops[0], "reduced_matvec"):
+            return None
+        if os.environ.get("CM2_ALLREDUCE_CHUNKS"):
+            chunks = int(os.environ["CM2_ALLREDUCE_CHUNKS"])
+        else:
+            # a chunk's all-reduce hides behind the back-projection of the next chunk: worth it
+            # while that takes longer than a small collective's latency (P^T of 1e8 samples:
+            # 0.4 ms); a strongly scaled shard (1e7 samples: 0.05 ms) sends the map in one piece
+            nloc = int(getattr(getattr(ops[0], "P", None), "nrows", 0))
+            chunks = 4 if nloc >= 40_000_000 else (2 if nloc >= 15_000_000 else 1)
+        if chunks <= 1:
             return None
         group = self.group
         return ops[0].reduced_matvec(
