@@ -260,3 +260,94 @@ def test_healpix_fits_reader_on_the_reference_map():
     np.testing.assert_allclose([I.sum(), Q.sum(), U.sum()], G["sums"], rtol=1e-12)
     np.testing.assert_allclose([(I * I).sum(), (Q * Q).sum(), (U * U).sum()], G["sumsq"], rtol=1e-12)
     np.testing.assert_array_equal(hf.read_map(REF_FITS), I)
+
+
+def test_hdf5_round_trip_fuzz(tmp_path):
+    """write_file -> read_file gives back random trees: nested groups (more children than one
+    symbol-table node holds), either byte order, int / float dtypes, scalars, empty and
+    multi-dimensional arrays, contiguous and chunked layout."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+
+    dtypes = st.sampled_from(["<f8", ">f8", "<f4", ">i4", "<i4", ">i8", "<i2", "u1"])
+    shapes = st.one_of(st.just(()), st.tuples(st.integers(0, 40)),
+                       st.tuples(st.integers(1, 9), st.integers(1, 7)),
+                       st.tuples(st.integers(1, 4), st.integers(1, 4), st.integers(1, 3)))
+
+    @st.composite
+    def arrays(draw):
+        dt, shape = np.dtype(draw(dtypes)), draw(shapes)
+        n = int(np.prod(shape)) if shape else 1
+        seed = draw(st.integers(0, 2 ** 31 - 1))
+        rng = np.random.default_rng(seed)
+        if dt.kind == "f":
+            a = rng.standard_normal(n)
+        else:
+            info = np.iinfo(dt)
+            a = rng.integers(max(info.min, -10 ** 9), min(info.max, 10 ** 9), n, endpoint=True)
+        a = a.astype(dt).reshape(shape)
+        if len(shape) >= 1 and n > 0 and draw(st.booleans()):
+            chunks = tuple(draw(st.integers(1, max(1, s))) for s in shape)
+            return h5.Chunked(a, chunks)
+        return a
+
+    names = st.text("abcdefghijklmnopqrstuvwxyz_0123456789", min_size=1, max_size=12)
+    trees = st.recursive(st.dictionaries(names, arrays(), min_size=0, max_size=5),
+                         lambda children: st.dictionaries(names, st.one_of(arrays(), children),
+                                                          min_size=1, max_size=6), max_leaves=25)
+
+    def check(got, want):
+        assert sorted(got) == sorted(want)
+        for k, w in want.items():
+            if isinstance(w, dict):
+                check(got[k], w)
+                continue
+            a = w.array if isinstance(w, h5.Chunked) else w
+            g = got[k]
+            assert g.shape == a.shape and g.dtype == a.dtype.newbyteorder("="), (k, g.dtype, a.dtype)
+            np.testing.assert_array_equal(g, a)
+
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(trees)
+    def run(tree):
+        counter[0] += 1
+        p = str(tmp_path / ("fuzz%d.hdf5" % counter[0]))
+        h5.write_file(p, tree)
+        check(h5.read_file(p), tree)
+        os.remove(p)
+
+    run()
+    # a group with more links than one symbol-table leaf (2 K_leaf = 64) holds
+    big = {"d%03d" % i: np.arange(i % 5, dtype=">i4") for i in range(150)}
+    p = str(tmp_path / "many.hdf5")
+    h5.write_file(p, {"g": big, "x": np.float64(3.5)})
+    back = h5.read_file(p)
+    assert len(back["g"]) == 150 and float(back["x"]) == 3.5
+    for k, v in big.items():
+        np.testing.assert_array_equal(back["g"][k], v)
+
+
+def test_fits_map_round_trip_fuzz(tmp_path):
+    """write_map -> read_map for 1 and 3 maps, float32 / float64 columns, both orderings."""
+    from cosmomap2_amd.utilities import healpix_fits as hf
+    rng = np.random.default_rng(3)
+    k = 0
+    for nside in (1, 2, 8, 32):
+        npix = 12 * nside * nside
+        for nmaps in (1, 3):
+            for dt in (np.float32, np.float64):
+                for nest in (False, True):
+                    maps = [rng.standard_normal(npix).astype(dt) for _ in range(nmaps)]
+                    p = str(tmp_path / ("m%d.fits" % k)); k += 1
+                    hf.write_map(p, maps if nmaps > 1 else maps[0], nest=nest, dtype=dt)
+                    got = hf.read_map(p, field=None, dtype=np.float64, nest=nest, h=True)
+                    hdr = got[-1]
+                    assert hdr["NSIDE"] == nside and hdr["ORDERING"] == ("NESTED" if nest else "RING")
+                    assert hdr["TFIELDS"] == nmaps and len(got) == nmaps + 1
+                    for a, b in zip(got[:-1], maps):
+                        np.testing.assert_array_equal(a, b.astype(np.float64))
+                    with pytest.raises(NotImplementedError):
+                        hf.read_map(p, nest=not nest)
