@@ -296,3 +296,46 @@ def test_Z_axpy(cm, n, r):
     dZ, dy, dw = D.f64(Z), D.f64(y), D.f64(w.copy())
     _hip.call("cm2_Z_axpy", n, r, D.ptr(dZ), D.ptr(dy), -0.75, D.ptr(dw), D.stream())
     np.testing.assert_allclose(dw.cpu().numpy(), w - 0.75 * Z.dot(y), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_tile_path_against_exact_path_random_configurations(cm, oracle, seed):
+    """Randomised configurations of the throughput path (tile order, half angles, fixed-order P^T,
+    overlap-save lists) against the exact path (time-order P, pixel-major P^T, direct or rocFFT
+    Toeplitz): polarisation, map and TOD sizes, ragged noise blocks, band length, flag fraction,
+    tile and slice sizes, and pointings that put a large share of the samples on a few pixels
+    (long runs, tail lists).  Also run-to-run bit equality."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(7000 + seed)
+    pol = int(rng.integers(1, 4))
+    npix = int(rng.integers(64, 6000))
+    nt = int(rng.integers(3000, 90000))
+    nblk = int(rng.integers(1, 6))
+    cuts = np.sort(rng.choice(np.arange(1, nt), size=nblk - 1, replace=False)) if nblk > 1 else np.array([], int)
+    sizes = np.diff(np.concatenate([[0], cuts, [nt]])).astype(int).tolist()
+    lam = int(rng.choice([1, 2, 7, 33, 130, 300, 700]))
+    pairs = rng.integers(0, npix, nt)
+    if rng.random() < 0.4:                                  # hot pixels: runs far longer than a group
+        hot = rng.integers(0, npix, 3)
+        m = rng.random(nt) < rng.uniform(0.2, 0.7)
+        pairs[m] = hot[rng.integers(0, 3, int(m.sum()))]
+    if rng.random() < 0.5:                                  # coherent scan: consecutive pixels
+        pairs = (np.arange(nt) // int(rng.integers(1, 9)) + int(rng.integers(0, npix))) % npix
+    pairs[rng.random(nt) < rng.choice([0.0, 0.02, 0.3])] = -1
+    phi = rng.uniform(0, np.pi) + 0.0785 * np.arange(nt)
+    ang = SimpleNamespace(cos=np.cos(2 * phi), sin=np.sin(2 * phi)) if pol > 1 else None
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=ang)
+    L._sparse_tiles(P, tile_pixels=int(rng.choice([64, 128, 512, 1536, 4096])),
+                    slice_samples=int(rng.choice([256, 1024, 4096])))
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 3.0 + 1.0)) * np.cos(kk / (lam + 2.0)) for b in range(nblk)]
+    Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+    Nd = cm.I.BlockLO(sizes, bands, offdiag=True, method=(1 if lam <= 130 else 2))
+    x = rng.standard_normal(pol * npix)
+    exact = P.T * (Nd * (P * x))
+    A = L._TiledNormalLO(P, Nf)
+    y1, y2 = np.asarray(A * x), np.asarray(A * x)
+    assert np.array_equal(y1, y2)
+    scale = np.linalg.norm(exact)
+    assert np.linalg.norm(y1 - exact) <= 1e-12 * scale + 1e-300, (seed, pol, npix, nt, sizes, lam)
