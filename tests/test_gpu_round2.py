@@ -339,3 +339,50 @@ def test_tile_path_against_exact_path_random_configurations(cm, oracle, seed):
     assert np.array_equal(y1, y2)
     scale = np.linalg.norm(exact)
     assert np.linalg.norm(y1 - exact) <= 1e-12 * scale + 1e-300, (seed, pol, npix, nt, sizes, lam)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tile_path_pcg_iteration_count_random_small_systems(cm, oracle, seed):
+    """The tile-order path forced on small random systems (polarisation, sizes, band, flags,
+    ragged noise blocks drawn per seed): PCG with M_BD must take exactly the oracle's number of
+    iterations and reach its solution."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(8100 + seed)
+    pol = int(rng.integers(1, 4))
+    npix = int(rng.integers(150, 900))
+    nb = int(rng.integers(1, 5))
+    bs = int(rng.integers(6000, 20000))
+    nt = nb * bs
+    lam = int(rng.choice([2, 5, 17, 48]))
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    pairs[rng.random(nt) < rng.choice([0.0, 0.05])] = -1
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.05 * b) * np.where(kk == 0, 1.0, -0.2 * np.exp(-kk / 5.0)) for b in range(nb)]
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    assert n == ro.new_npix and np.array_equal(pairs, po)
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    N = cm.I.BlockLO(bs, bands, offdiag=True, method=3)
+    c, s = ro.cos, ro.sin
+
+    def A_o(x):
+        return oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(
+            bs, bands, True, oracle.sparse_mult(pol, po, c, s, x)))
+    M_o = lambda x: oracle.bd_precond_mult(pol, ro, x)
+    b_o = oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(bs, bands, True, d))
+    L.set_pointing_mode("tiled")
+    try:
+        A = P.T * N * P
+        assert any(isinstance(op, L._TiledNormalLO) for op in A._compiled())
+        b = P.T * (N * d)
+        its_g, its_o = [], []
+        xg, info_g = cm.cg(A, b, M=M, rtol=1e-6, maxiter=400, callback=lambda x: its_g.append(1))
+        xo, info_o = oracle.cg(A_o, b_o, M=M_o, rtol=1e-6, maxiter=400, callback=lambda x: its_o.append(1))
+        assert info_g == 0 and info_o == 0
+        assert len(its_g) == len(its_o), (seed, pol, npix, nt, lam, len(its_g), len(its_o))
+        assert np.linalg.norm(np.asarray(xg) - xo) <= 1e-8 * np.linalg.norm(xo)
+    finally:
+        L.set_pointing_mode("auto")
