@@ -388,19 +388,22 @@ def test_tile_path_pcg_iteration_count_random_small_systems(cm, oracle, seed):
         L.set_pointing_mode("auto")
 
 
-def test_c_host_program_through_the_abi(tmp_path):
-    """tests/c_abi/matvec_demo.c: a plain C99 host (gcc, the HIP runtime's C API, no Python) builds
-    a pointing, applies P and P^T through include/cosmomap2.h and finds them bit-identical to the
-    reference's serial loops."""
+@pytest.mark.parametrize("prog,token", [("matvec_demo", "C-ABI-OK"), ("pcg_demo", "C-PCG-OK")])
+def test_c_host_program_through_the_abi(tmp_path, prog, token):
+    """Plain C99 hosts (gcc, the HIP runtime's C API, no Python) on include/cosmomap2.h:
+    tests/c_abi/matvec_demo.c finds P and P^T bit-identical to the reference's serial loops;
+    tests/c_abi/pcg_demo.c runs the whole hot path -- weights, per-pixel blocks, tile-order
+    P / Toeplitz N^-1 / P^T, M_BD and scipy's PCG recurrence with device scalars -- and checks the
+    true residual of the solution."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "matvec_demo")
+    exe = str(tmp_path / prog)
     libdir = os.path.join(root, "cosmomap2_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
                            "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "tests", "c_abi", "matvec_demo.c"),
+                           os.path.join(root, "tests", "c_abi", prog + ".c"),
                            "-L" + libdir, "-lcosmomap2_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "C-ABI-OK" in res.stdout
+    assert token in res.stdout, res.stdout
