@@ -181,6 +181,80 @@ extern "C" int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d
     return 0;
 }
 
+// ------------------------------------------------------------- PCG driver ------
+// scipy.sparse.linalg.cg's recurrence (the driver the reference calls, e.g.
+// tests/test_2level_preconditioner.py:52) for hosts that are not Python: the operator and the
+// preconditioner are callbacks working on device vectors on `stream`; alpha and beta never leave
+// HBM, one 8-byte copy per iteration brings ||r||^2 to the host for the stopping test.
+extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+                       const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+                       int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters,
+                       int *h_info, void *stream_)
+{
+    CM2_CHECK(n >= 1 && A && d_b && d_x && h_iters && h_info, "cm2_pcg: NULL argument or n < 1");
+    hipStream_t stream = as_stream(stream_);
+    *h_iters = 0;
+    *h_info = 0;
+    DevTemp<double> r, z, p, q, sc, work;
+    CM2_HIP(r.alloc(n));
+    CM2_HIP(p.alloc(n));
+    CM2_HIP(q.alloc(n));
+    if (M) CM2_HIP(z.alloc(n));
+    CM2_HIP(sc.alloc(8));                                  // rho[2], pq, rr, tmp
+    CM2_HIP(work.alloc((size_t)cm2_reduce_work_doubles()));
+    double *rho[2] = {sc.p, sc.p + 1}, *pq = sc.p + 2, *rr = sc.p + 3, *tmp = sc.p + 4;
+    double h = 0.0;
+    auto fetch = [&](const double *d) -> int {
+        CM2_HIP(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+    if (int rc = cm2_dot(n, d_b, d_b, tmp, work, stream)) return rc;
+    if (int rc = fetch(tmp)) return rc;
+    const double bnrm2 = sqrt(h);
+    if (bnrm2 == 0.0) {                                    // x = b = 0
+        CM2_HIP(hipMemcpyAsync(d_x, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        return 0;
+    }
+    if (rtol * bnrm2 > atol) atol = rtol * bnrm2;
+    if (maxiter < 0) maxiter = 10 * n;
+    if (x_is_zero) {
+        CM2_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * n, stream));
+        CM2_HIP(hipMemcpyAsync(r.p, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    } else {                                               // r = b - A x0
+        if (A(A_ctx, d_x, q.p, stream_)) { set_error("cm2_pcg: the operator callback failed"); return 1; }
+        CM2_HIP(hipMemcpyAsync(r.p, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+        if (int rc = cm2_axpy(n, -1.0, q.p, r.p, stream_)) return rc;
+    }
+    if (int rc = cm2_dot(n, r.p, r.p, rr, work, stream)) return rc;
+    if (int rc = fetch(rr)) return rc;
+    int cur = 0;
+    for (int64_t it = 0; it < maxiter; ++it) {
+        if (sqrt(h) < atol) return 0;
+        const double *zz = r.p;
+        if (M) {
+            if (M(M_ctx, r.p, z.p, stream_)) { set_error("cm2_pcg: the preconditioner callback failed"); return 1; }
+            zz = z.p;
+        }
+        if (int rc = cm2_dot(n, r.p, zz, rho[cur], work, stream)) return rc;
+        if (it > 0) {
+            if (int rc = cm2_pcg_update_p(n, rho[cur], rho[1 - cur], zz, p.p, stream_)) return rc;
+        } else {
+            CM2_HIP(hipMemcpyAsync(p.p, zz, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+        }
+        if (A(A_ctx, p.p, q.p, stream_)) { set_error("cm2_pcg: the operator callback failed"); return 1; }
+        if (int rc = cm2_dot(n, p.p, q.p, pq, work, stream)) return rc;
+        if (int rc = cm2_pcg_update_xr(n, rho[cur], pq, p.p, q.p, d_x, r.p, rr, work, stream_)) return rc;
+        cur = 1 - cur;
+        if (int rc = fetch(rr)) return rc;
+        *h_iters = it + 1;
+        if (callback) callback(cb_ctx, it + 1, d_x, sqrt(h));
+    }
+    *h_info = (int)maxiter;                                // not converged within maxiter
+    return 0;
+}
+
 // ------------------------------------------------------------- Z^T x ----------
 // Z row-major [n][r].  Thread (row-lane, column): consecutive threads read
 // consecutive doubles of a row => full-line accesses; per-column partials are

@@ -231,6 +231,21 @@ int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d_pq, const 
                       const double *d_q, double *d_x, double *d_r, double *d_rr,
                       double *d_work, void *stream);
 
+/* The whole solve for hosts that are not Python: scipy.sparse.linalg.cg's recurrence (the driver the
+ * reference calls: tests/test_2level_preconditioner.py:52, src/test_BD_precond_onto_real_data.py:47)
+ * with the operator A and the preconditioner M (may be NULL) as callbacks on device vectors.
+ * A callback computes d_out = Op d_in on `stream` and returns 0 on success.  x_is_zero != 0: d_x is
+ * overwritten with the start vector 0, otherwise d_x holds x0.  Stops when ||r||_2 < max(atol,
+ * rtol ||b||_2), tested before each iteration like scipy does; maxiter < 0 means 10 n.
+ * *h_iters = iterations done, *h_info = 0 (converged) or maxiter.  `callback` (may be NULL) is
+ * called after every iteration with the iteration number, the iterate (device) and ||r||_2. */
+typedef int (*cm2_apply_fn)(void *ctx, const double *d_in, double *d_out, void *stream);
+typedef void (*cm2_iter_fn)(void *ctx, int64_t iteration, const double *d_x, double rnorm);
+int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+            const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+            int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters, int *h_info,
+            void *stream);
+
 /* ------------------------------------------------------------------------- *
  * a10-a12  Deflation space and coarse operator
  *   (DeflationLO linearoperators.py:1029-1065, CoarseLO :946-1027,

@@ -3,7 +3,9 @@
  * (utilities/process_ces.py:480-555), tile-order P / N^-1 / P^T
  * (interfaces/linearoperators.py:463-526, :582-595), the block-diagonal preconditioner (:775-841)
  * and the PCG recurrence of scipy.sparse.linalg.cg with alpha and beta kept in HBM -- every
- * array-sized operation is one call of include/cosmomap2.h.  Solves P^T N^-1 P x = P^T N^-1 d to
+ * array-sized operation is one call of include/cosmomap2.h -- written out here and, second,
+ * through the library's own driver cm2_pcg with the operator and M_BD as C callbacks (same
+ * iteration count, bit-identical solution).  Solves P^T N^-1 P x = P^T N^-1 d to
  * rtol 1e-6 and checks the true residual.  Prints "C-PCG-OK".
  */
 #include <math.h>
@@ -38,6 +40,26 @@ static int apply_A(const normal_op *A, const double *d_x, double *d_y)
     if (cm2_P_tiles_apply(A->T, d_x, A->tb1, NULL)) return 1;
     if (cm2_noise_apply_tiles(A->N, A->T, A->tb1, A->tb2, NULL)) return 1;
     return cm2_Pt_tiles_apply(A->T, A->tb2, d_y, NULL);
+}
+
+static int cb_A(void *ctx, const double *d_in, double *d_out, void *stream)
+{
+    (void)stream;                                    /* this demo runs on the default stream */
+    return apply_A((const normal_op *)ctx, d_in, d_out);
+}
+
+typedef struct {
+    int pol;
+    int64_t npix;
+    const double *w[6], *det;
+    const uint8_t *mask;
+} bd_ctx;
+
+static int cb_M(void *ctx, const double *d_in, double *d_out, void *stream)
+{
+    const bd_ctx *m = (const bd_ctx *)ctx;
+    return cm2_bdprecond_apply(m->pol, m->npix, m->w[0], m->w[1], m->w[2], m->w[3], m->w[4], m->w[5],
+                               m->det, m->mask, d_in, d_out, stream);
 }
 
 int main(void)
@@ -124,6 +146,20 @@ int main(void)
     const double rel = sqrt(h[0]) / (atol / 1e-6);
     if (!(it > 0 && it < 500 && rel < 2e-6)) {
         fprintf(stderr, "PCG failed: %d iterations, true relative residual %.3e\n", it, rel);
+        return 1;
+    }
+    /* the same solve by the library's driver, operator and preconditioner as C callbacks */
+    bd_ctx Mc = {pol, npix, {w[0], w[1], w[2], w[3], w[4], w[5]}, d_det, d_mask};
+    double *x2 = dmalloc(n);
+    int64_t iters2 = 0;
+    int info2 = -1;
+    CHECK_CM2(cm2_pcg(n, cb_A, &A, cb_M, &Mc, b, x2, 1, 1e-6, 0.0, 500, NULL, NULL, &iters2, &info2, NULL));
+    CHECK_CM2(cm2_axpy(n, -1.0, x, x2, NULL));               /* x2 - x */
+    CHECK_CM2(cm2_dot(n, x2, x2, sc + 3, work, NULL));
+    CHECK_HIP(hipMemcpy(h, sc + 3, sizeof(double), hipMemcpyDeviceToHost));
+    if (info2 != 0 || iters2 != it || h[0] != 0.0) {
+        fprintf(stderr, "cm2_pcg: info %d, %lld iterations (loop above: %d), |dx|^2 = %.3e\n", info2,
+                (long long)iters2, it, h[0]);
         return 1;
     }
     CHECK_CM2(cm2_noise_destroy(A.N));

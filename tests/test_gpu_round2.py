@@ -407,3 +407,47 @@ def test_c_host_program_through_the_abi(tmp_path, prog, token):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert token in res.stdout, res.stdout
+
+
+def test_cm2_pcg_driver_equals_python_cg(cm, oracle):
+    """cm2_pcg (the C driver with callbacks) against cosmomap2_amd.cg on the same operators:
+    identical iteration count, bit-identical solution, callback sequence, maxiter / info."""
+    import ctypes
+    from cosmomap2_amd import _hip, device as D
+    A, M, b, n = _system(cm, oracle, 31, 40000, 300, 4, 3)
+    bd = D.f64(b)
+    its = []
+    xs, info = cm.cg(A, bd, M=M, rtol=1e-8, maxiter=200, callback=lambda v: its.append(1))
+    assert info == 0
+    APPLY = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    ITER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double)
+    t = cm.torch
+
+    class Raw(object):                                       # zero-copy view of a library buffer
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False),
+                                             "version": 2}
+
+    def wrap(op):
+        def f(ctx, d_in, d_out, stream):
+            x_in = t.as_tensor(Raw(d_in), device="cuda")
+            t.as_tensor(Raw(d_out), device="cuda").copy_(D.f64(op * x_in))
+            return 0
+        return APPLY(f)
+
+    seen = []
+    cbA, cbM = wrap(A), wrap(M)
+    cbI = ITER(lambda ctx, it, d_x, rn: seen.append((it, rn)))
+    x2 = D.empty(n)
+    iters, inf = ctypes.c_int64(0), ctypes.c_int(-1)
+    _hip.call("cm2_pcg", n, ctypes.cast(cbA, ctypes.c_void_p), None, ctypes.cast(cbM, ctypes.c_void_p), None,
+              D.ptr(bd), D.ptr(x2), 1, 1e-8, 0.0, 200, ctypes.cast(cbI, ctypes.c_void_p), None,
+              ctypes.byref(iters), ctypes.byref(inf), D.stream())
+    assert inf.value == 0 and iters.value == len(its) == len(seen)
+    assert [s[0] for s in seen] == list(range(1, len(its) + 1))
+    assert t.equal(x2, D.f64(xs))
+    # maxiter reached: info = maxiter, like scipy
+    x3 = D.empty(n)
+    _hip.call("cm2_pcg", n, ctypes.cast(cbA, ctypes.c_void_p), None, None, None, D.ptr(bd), D.ptr(x3), 1,
+              1e-14, 0.0, 2, None, None, ctypes.byref(iters), ctypes.byref(inf), D.stream())
+    assert inf.value == 2 and iters.value == 2
