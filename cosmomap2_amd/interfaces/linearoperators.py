@@ -230,18 +230,21 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
             if os.environ.get("CM2_PT_ORDER", "fixed") == "atomic":
                 tile_pixels = {1: 4096, 2: 2048, 3: 2048}[P.pol]   # 32 / 32 / 48 KB of LDS per tile
             else:
-                # fixed-order P^T: one workgroup owns a tile from its first sample to its last and
-                # keeps the tile (32 / 32 / 36 KB) plus a slice of the bucket (40 KB) in LDS, two
-                # workgroups per CU -- so there should be at least 2 x 256 tiles
-                tile_pixels = {1: 4096, 2: 2048, 3: 1536}[P.pol]
-                if P.pol == 3 and P.ncols >= 1024 * 2048:
-                    # large maps (nside 512: 2.2 ms -> 2.1 ms per matvec): 48 KB tiles still give
-                    # two workgroups per CU four rounds of tiles, and the overlap-save kernel's
-                    # address runs are a third longer
-                    tile_pixels = 2048
-                want = -(-P.ncols // 512)
-                want = max(64, -(-want // 64) * 64)
-                tile_pixels = min(tile_pixels, want)
+                # fixed-order P^T: one workgroup (512 threads) owns a tile from its first sample to
+                # its last and keeps the tile plus a 12 KB slice of the bucket in LDS, two workgroups
+                # per CU: the chip takes 512 tiles at a time, so the number of tiles should be just
+                # under a multiple of 512 (nside 256, IQU: 615 tiles of 1280 pixels cost P^T 0.53 ms
+                # where 512 tiles of 1536 pixels cost 0.40; 384 tiles of 2048 pixels 0.52).  Largest
+                # tile (longest address runs for the overlap-save kernel) that leaves 512 k tiles and
+                # stays within 32 / 32 / 48 KB of LDS for I / QU / IQU.
+                tp_max = {1: 4096, 2: 2048, 3: 2048}[P.pol]
+                k = 1
+                while True:
+                    tile_pixels = -(-P.ncols // (512 * k))
+                    tile_pixels = max(64, -(-tile_pixels // 64) * 64)
+                    if tile_pixels <= tp_max:
+                        break
+                    k += 1
             if os.environ.get("CM2_TILE_PIXELS"):
                 tile_pixels = int(os.environ["CM2_TILE_PIXELS"])
             while tile_pixels > 64 and tile_pixels // 2 >= P.ncols:
