@@ -31,6 +31,8 @@ PROTOTYPES = {
     "cm2_tiles_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _vp],
     "cm2_tiles_destroy": [_vp],
     "cm2_tiles_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_tiles_pixel_range": [_vp, _i64, _i64, ctypes.POINTER(_i64)],
+    "cm2_tiles_group_tiles": [_vp, _int, ctypes.POINTER(_i64)],
     "cm2_tiles_set_pt_order": [_vp, _int],
     "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],

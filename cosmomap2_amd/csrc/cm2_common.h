@@ -74,6 +74,7 @@ struct DevTemp {
     ~DevTemp() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * (count ? count : 1)); }
     T *keep() { T *q = p; p = nullptr; return q; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
     operator T *() const { return p; }
 };
 

@@ -8,7 +8,10 @@
 struct cm2_tiles {
     int64_t nt = 0, npix = 0, nvalid = 0;
     int pol = 0;
-    int tp = 0;                  // pixels per tile
+    int tp = 0;                  // pixels per tile (the largest width when the tiles are balanced)
+    bool balanced = false;       // tiles re-cut to equal sample counts (uneven hit map)
+    std::vector<int64_t> tile_p0;   // [ntiles+1] first pixel of every tile (host)
+    int64_t *d_tile_p0 = nullptr;
     int64_t ntiles = 0, nitems = 0;
     uint32_t *d_tb_dst = nullptr;   // [nt]
     uint16_t *d_pl = nullptr;       // [nvalid]

@@ -43,8 +43,23 @@ static uint64_t next_plan_id()
 }
 
 // ------------------------------------------------------------------ build -------
+// tile of pixel p: uniform tiles of tp pixels, or (p0 != nullptr) the tile whose pixel range
+// [p0[b], p0[b + 1]) holds p -- tiles of equal sample count for uneven hit maps
+__device__ __forceinline__ uint32_t tile_of(int32_t p, int tp, const int64_t *__restrict__ p0,
+                                            uint32_t ntiles)
+{
+    if (p0 == nullptr) return (uint32_t)(p / tp);
+    uint32_t lo = 0, hi = ntiles;                        // largest b with p0[b] <= p
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p0[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ pix, int64_t nt,
-                                                    int tp, uint32_t ntiles, int64_t npix,
+                                                    int tp, const int64_t *__restrict__ p0,
+                                                    uint32_t ntiles, int64_t npix,
                                                     uint32_t *__restrict__ keys,
                                                     uint32_t *__restrict__ vals,
                                                     unsigned int *__restrict__ bad)
@@ -54,10 +69,21 @@ __global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ p
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
         const int32_t p = pix[i];
         if (p < -1 || p >= npix) b = 1;                  // same rule as cm2_pointing_create
-        keys[i] = (p < 0 || p >= npix) ? ntiles : (uint32_t)(p / tp);
+        keys[i] = (p < 0 || p >= npix) ? ntiles : tile_of(p, tp, p0, ntiles);
         vals[i] = (uint32_t)i;
     }
     if (b) atomicOr(bad, 1u);
+}
+
+// hits of every pixel (flagged / out-of-range samples skipped): input of the balanced tiling
+__global__ __launch_bounds__(256) void k_pix_hist(const int32_t *__restrict__ pix, int64_t nt,
+                                                   int64_t npix, unsigned int *__restrict__ hits)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const int32_t p = pix[i];
+        if (p >= 0 && p < npix) atomicAdd(&hits[p], 1u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict__ keys, int64_t nt,
@@ -90,7 +116,8 @@ __global__ __launch_bounds__(256) void k_unit_circle(int64_t nt, const double *_
 
 template <int POL, bool HALF>
 __global__ __launch_bounds__(256) void k_tile_fill(
-    int64_t nt, int64_t nvalid, int tp, const uint32_t *__restrict__ tb_src,
+    int64_t nt, int64_t nvalid, int tp, const int64_t *__restrict__ p0, uint32_t ntiles,
+    const uint32_t *__restrict__ tb_src,
     const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
     uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb,
     double *__restrict__ stb)
@@ -100,7 +127,8 @@ __global__ __launch_bounds__(256) void k_tile_fill(
         const uint32_t t = tb_src[k];
         if (k < nvalid) {
             tb_dst[t] = (uint32_t)k;
-            uint16_t w = (uint16_t)(pix[t] % tp);
+            const int32_t px = pix[t];
+            uint16_t w = p0 ? (uint16_t)(px - p0[tile_of(px, tp, p0, ntiles)]) : (uint16_t)(px % tp);
             if (POL > 1) {
                 if (HALF) {
                     const double cv = c[t], sv = s[t];
@@ -150,16 +178,15 @@ __device__ __forceinline__ void tile_sample(const uint16_t *__restrict__ pl,
 // one workgroup per work item = (tile, contiguous slice of its bucket)
 template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_P_tiles(
-    int tp, int64_t npix, const int32_t *__restrict__ item_tile,
+    const int64_t *__restrict__ tile_p0, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
     const double *__restrict__ x, double *__restrict__ d_tb)
 {
     extern __shared__ double tile[];                    // tp*POL doubles
     const int b = item_tile[blockIdx.x];
-    const int64_t p0 = (int64_t)b * tp;
-    int64_t np = npix - p0;
-    if (np > tp) np = tp;
+    const int64_t p0 = tile_p0[b];
+    const int64_t np = tile_p0[b + 1] - p0;
     const int64_t nvals = np * POL;
     const double *xs = x + p0 * POL;
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = xs[i];
@@ -184,16 +211,15 @@ __global__ __launch_bounds__(1024) void k_P_tiles(
 // ---------------------------------------------------------------- P^T (TB) ------
 template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_Pt_tiles(
-    int tp, int64_t npix, const int32_t *__restrict__ item_tile,
+    const int64_t *__restrict__ tile_p0, const int32_t *__restrict__ item_tile,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
     const double *__restrict__ v_tb, double *__restrict__ out)
 {
     extern __shared__ double tile[];                    // tp*POL accumulators
     const int b = item_tile[blockIdx.x];
-    const int64_t p0 = (int64_t)b * tp;
-    int64_t np = npix - p0;
-    if (np > tp) np = tp;
+    const int64_t p0 = tile_p0[b];
+    const int64_t np = tile_p0[b + 1] - p0;
     const int64_t nvals = np * POL;
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = 0.0;
     __syncthreads();
@@ -368,7 +394,7 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
     void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
-                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off};
+                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off, t->d_tile_p0};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     cm2::fx_free(t);
@@ -405,32 +431,109 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     CM2_HIP(keys_out.alloc(nt));
     CM2_HIP(vals_in.alloc(nt));
     CM2_HIP(tb_src.alloc(nt));
-    CM2_HIP(d_off.alloc(t->ntiles + 1));
     DevTemp<unsigned int> d_bad;
     CM2_HIP(d_bad.alloc(1));
     CM2_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream));
-    k_tile_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, tile_pixels, (uint32_t)t->ntiles,
-                                                     npix, keys_in, vals_in, d_bad);
-    CM2_LAUNCH_OK();
-    int end_bit = 1;
-    while (((int64_t)1 << end_bit) <= t->ntiles) ++end_bit;
-    size_t tb = 0;
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               tb_src.p, nt, 0, end_bit, stream));
-    CM2_HIP(d_temp.alloc(tb + 16));
-    CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                               tb_src.p, nt, 0, end_bit, stream));
-    k_tile_bounds<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-        keys_out, nt, t->ntiles, d_off);
-    CM2_LAUNCH_OK();
-    std::vector<int64_t> off(t->ntiles + 1);
-    CM2_HIP(hipMemcpyAsync(off.data(), d_off, sizeof(int64_t) * (t->ntiles + 1),
-                           hipMemcpyDeviceToHost, stream));
+    std::vector<int64_t> off;
+    // stable partition of the samples by tile; p0 == nullptr: uniform tiles of tile_pixels
+    auto partition = [&](const int64_t *d_p0) -> int {
+        d_off.release();
+        CM2_HIP(d_off.alloc(t->ntiles + 1));
+        k_tile_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, tile_pixels, d_p0,
+                                                         (uint32_t)t->ntiles, npix, keys_in, vals_in,
+                                                         d_bad);
+        CM2_LAUNCH_OK();
+        int end_bit = 1;
+        while (((int64_t)1 << end_bit) <= t->ntiles) ++end_bit;
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   tb_src.p, nt, 0, end_bit, stream));
+        d_temp.release();
+        CM2_HIP(d_temp.alloc(tb + 16));
+        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                   tb_src.p, nt, 0, end_bit, stream));
+        k_tile_bounds<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            keys_out, nt, t->ntiles, d_off);
+        CM2_LAUNCH_OK();
+        off.assign((size_t)t->ntiles + 1, 0);
+        CM2_HIP(hipMemcpyAsync(off.data(), d_off, sizeof(int64_t) * (t->ntiles + 1),
+                               hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+    if (int rc = partition(nullptr)) return rc;
     unsigned int h_bad = 0;
-    CM2_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, stream));
-    CM2_HIP(hipStreamSynchronize(stream));
+    CM2_HIP(hipMemcpy(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost));
     CM2_CHECK(h_bad == 0, "cm2_tiles_create: a pixel index is outside [-1, npix=%lld)",
               (long long)npix);
+    t->tile_p0.assign((size_t)t->ntiles + 1, 0);
+    for (int64_t b = 0; b <= t->ntiles; ++b)
+        t->tile_p0[(size_t)b] = b * tile_pixels < npix ? b * tile_pixels : npix;
+    // The fixed-order P^T gives every tile to ONE workgroup: a hit map that is far from uniform
+    // (half of the samples on a tenth of the sky: 0.47 -> 1.7 ms) would leave most of the chip
+    // waiting for the heaviest tiles.  When some uniform tile holds over 25 % more than the mean,
+    // the pixel ranges are re-cut to equal sample counts (width <= tile_pixels): every pixel is
+    // still summed by one workgroup in time order, so results do not change by a bit.
+    const char *bal = getenv("CM2_TILE_BALANCE");
+    bool balance = false;
+    {
+        int64_t nmax = 0;
+        for (int64_t b = 0; b < t->ntiles; ++b)
+            if (off[(size_t)b + 1] - off[(size_t)b] > nmax) nmax = off[(size_t)b + 1] - off[(size_t)b];
+        const double mean = (double)off[(size_t)t->ntiles] / (double)(t->ntiles > 0 ? t->ntiles : 1);
+        balance = t->ntiles >= 64 && off[(size_t)t->ntiles] >= (1 << 20) && (double)nmax > 1.25 * mean;
+        if (bal) balance = atoi(bal) != 0 && off[(size_t)t->ntiles] > 0;
+    }
+    DevTemp<int64_t> d_p0;
+    if (balance) {
+        DevTemp<unsigned int> d_hits;
+        CM2_HIP(d_hits.alloc(npix));
+        CM2_HIP(hipMemsetAsync(d_hits, 0, sizeof(unsigned int) * npix, stream));
+        k_pix_hist<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, d_hits);
+        CM2_LAUNCH_OK();
+        std::vector<unsigned int> hits((size_t)npix);
+        CM2_HIP(hipMemcpyAsync(hits.data(), d_hits, sizeof(unsigned int) * npix, hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        // as many tiles as before would have had at equal load, 2 % slack so that rounding does
+        // not spill a 513th tile; a tile ends when the next pixel would exceed the target or the
+        // width tile_pixels (a single pixel heavier than the target is a tile of its own)
+        const int64_t nvalid = off[(size_t)t->ntiles];
+        const int64_t target = (int64_t)(1.02 * (double)nvalid / (double)t->ntiles) + 1;
+        // cuts every rank of a sharded run has in common, whatever its own hit map: the group
+        // boundaries of cm2_tiles_group_tiles (the pieces of the map that are all-reduced while
+        // the next piece is back-projected) -- the uniform tiling's tile boundaries nearest to
+        // eighths of the map, a function of npix and tile_pixels alone
+        const int64_t ntu = (npix + tile_pixels - 1) / tile_pixels;
+        int64_t forced[9];
+        for (int c = 0; c <= 8; ++c) {
+            forced[c] = (ntu * c / 8) * tile_pixels;
+            if (forced[c] > npix || c == 8) forced[c] = npix;
+        }
+        int fc = 1;
+        std::vector<int64_t> p0v(1, 0);
+        int64_t acc = 0, start = 0;
+        for (int64_t p = 0; p < npix; ++p) {
+            const int64_t h = hits[(size_t)p];
+            while (fc < 8 && forced[fc] < p) ++fc;
+            const bool at_cut = fc < 8 && forced[fc] == p;
+            if (p > start && (acc + h > target || p - start >= tile_pixels || at_cut)) {
+                p0v.push_back(p);
+                start = p;
+                acc = 0;
+            }
+            acc += h;
+        }
+        p0v.push_back(npix);
+        t->ntiles = (int64_t)p0v.size() - 1;
+        t->tile_p0 = p0v;
+        CM2_HIP(d_p0.alloc(p0v.size()));
+        CM2_HIP(hipMemcpy(d_p0.p, p0v.data(), sizeof(int64_t) * p0v.size(), hipMemcpyHostToDevice));
+        if (int rc = partition(d_p0.p)) return rc;
+    }
+    t->balanced = balance;
+    CM2_HIP(hipMalloc(&t->d_tile_p0, sizeof(int64_t) * (t->ntiles + 1)));
+    CM2_HIP(hipMemcpy(t->d_tile_p0, t->tile_p0.data(), sizeof(int64_t) * (t->ntiles + 1),
+                      hipMemcpyHostToDevice));
     t->nvalid = off[t->ntiles];
     t->tile_off = off;
     CM2_HIP(hipMalloc(&t->d_tile_off, sizeof(int64_t) * (t->ntiles + 1)));
@@ -467,7 +570,8 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     }
 #define CM2_TF(POL, HALF)                                                                      \
     k_tile_fill<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                               \
-        nt, t->nvalid, tile_pixels, tb_src, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,         \
+        nt, t->nvalid, tile_pixels, balance ? t->d_tile_p0 : nullptr, (uint32_t)t->ntiles, tb_src,  \
+        d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,                                             \
         HALF ? t->d_half : t->d_cos, t->d_sin)
     if (pol == 1) CM2_TF(1, false);
     else if (pol == 2) { if (t->half) CM2_TF(2, true); else CM2_TF(2, false); }
@@ -524,6 +628,48 @@ extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t) { return t ? t->plan_id : 0; }
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid : 0; }
 
+// Tile indices bounding `ngroups` consecutive groups of tiles whose PIXEL boundaries are the same on
+// every rank of a sharded run (ranks with different hit maps may have cut their tiles differently):
+// group g = tiles [h_tiles[g], h_tiles[g + 1]).
+extern "C" int cm2_tiles_group_tiles(const cm2_tiles *t, int ngroups, int64_t *h_tiles)
+{
+    CM2_CHECK(t && h_tiles && ngroups >= 1, "cm2_tiles_group_tiles: bad argument");
+    const int64_t ntu = (t->npix + t->tp - 1) / t->tp;
+    for (int g = 0; g <= ngroups; ++g) {
+        const int c = g == ngroups ? 8 : (ngroups <= 8 ? (8 * g) / ngroups : -1);
+        int64_t pixel;
+        if (ngroups > 8) {                     // finer than eighths: only a uniform tiling has the cuts
+            CM2_CHECK(!t->balanced, "cm2_tiles_group_tiles: at most 8 groups on a balanced tiling");
+            pixel = (ntu * g / ngroups) * t->tp;
+        } else {
+            pixel = (ntu * c / 8) * t->tp;
+        }
+        if (pixel > t->npix || g == ngroups) pixel = t->npix;
+        // the tile that starts at `pixel` (every tiling has a boundary there)
+        int64_t lo = 0, hi = t->ntiles;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (t->tile_p0[(size_t)mid] < pixel) lo = mid + 1; else hi = mid;
+        }
+        CM2_CHECK(t->tile_p0[(size_t)lo] == pixel, "cm2_tiles_group_tiles: no tile boundary at pixel %lld",
+                  (long long)pixel);
+        h_tiles[g] = lo;
+    }
+    return 0;
+}
+
+extern "C" int cm2_tiles_pixel_range(const cm2_tiles *t, int64_t tile_lo, int64_t tile_hi,
+                                     int64_t *h_p0p1)
+{
+    CM2_CHECK(t && h_p0p1, "cm2_tiles_pixel_range: NULL argument");
+    CM2_CHECK(tile_lo >= 0 && tile_lo <= tile_hi && tile_hi <= t->ntiles,
+              "cm2_tiles_pixel_range: tiles [%lld, %lld) outside [0, %lld]", (long long)tile_lo,
+              (long long)tile_hi, (long long)t->ntiles);
+    h_p0p1[0] = t->tile_p0[(size_t)tile_lo];
+    h_p0p1[1] = t->tile_p0[(size_t)tile_hi];
+    return 0;
+}
+
 extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb,
                                  void *stream_)
 {
@@ -533,7 +679,7 @@ extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PT(POL, HALF)                                                                      \
     k_P_tiles<POL, HALF><<<(int)t->nitems, tile_block(true), lds, stream>>>(                       \
-        t->tp, t->npix, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
+        t->d_tile_p0, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
         HALF ? t->d_half : t->d_cos, t->d_sin, d_x, d_tod_tb)
     if (t->pol == 1) CM2_PT(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PT(2, true); else CM2_PT(2, false); }
@@ -556,7 +702,7 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PTT(POL, HALF)                                                                     \
     k_Pt_tiles<POL, HALF><<<(int)t->nitems, tile_block(), lds, stream>>>(                      \
-        t->tp, t->npix, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
+        t->d_tile_p0, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
         HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
     if (t->pol == 1) CM2_PTT(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PTT(2, true); else CM2_PTT(2, false); }
@@ -578,15 +724,14 @@ extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_
     bool fixed = false;
     if (int rc = cm2::fx_plan(t, stream, &fixed)) return rc;
     if (fixed) return cm2::fx_launch(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
-    const int64_t p0 = tile_lo * t->tp;
-    const int64_t p1 = tile_hi * t->tp < t->npix ? tile_hi * t->tp : t->npix;
+    const int64_t p0 = t->tile_p0[(size_t)tile_lo], p1 = t->tile_p0[(size_t)tile_hi];
     CM2_HIP(hipMemsetAsync(d_out + p0 * t->pol, 0, sizeof(double) * (p1 - p0) * t->pol, stream));
     const int64_t i0 = t->tile_item0[(size_t)tile_lo], i1 = t->tile_item0[(size_t)tile_hi];
     if (i1 == i0) return 0;
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PTR(POL, HALF)                                                                     \
     k_Pt_tiles<POL, HALF><<<(int)(i1 - i0), tile_block(), lds, stream>>>(                      \
-        t->tp, t->npix, t->d_item_tile + i0, t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl,    \
+        t->d_tile_p0, t->d_item_tile + i0, t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl,    \
         HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
     if (t->pol == 1) CM2_PTR(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PTR(2, true); else CM2_PTR(2, false); }

@@ -50,7 +50,7 @@ constexpr int kFxMaxLevel = 14;         // pieces of 4: runs up to 60 samples go
 // ------------------------------------------------------------------- kernel --------
 template <int POL, bool HALF, int VPT>
 __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
-    int tp, int64_t npix, int tile0, int S, const int64_t *__restrict__ tile_off,
+    int tp, const int64_t *__restrict__ tile_p0, int tile0, int S, const int64_t *__restrict__ tile_off,
     const int64_t *__restrict__ slice0, const uint2 *__restrict__ meta,
     const uint4 *__restrict__ gent, const double2 *__restrict__ ga,
     const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
@@ -65,9 +65,8 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     double *vbuf = sm + (int64_t)tp * POL;               // VPT * kFxT values of the slice, TB order
     const int tid = threadIdx.x;
     const int b = tile0 + blockIdx.x;
-    const int64_t p0 = (int64_t)b * tp;
-    int64_t np = npix - p0;
-    if (np > tp) np = tp;
+    const int64_t p0 = tile_p0[b];
+    const int64_t np = tile_p0[b + 1] - p0;
     const int nvals = (int)(np * POL);
     for (int i = tid; i < nvals; i += kFxT) tile[i] = 0.0;
     const int64_t k_begin = tile_off[b], k_end = tile_off[b + 1];
@@ -496,7 +495,7 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
     k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
-        t->tp, t->npix, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
+        t->tp, t->d_tile_p0, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
         t->d_fx_tb, d_tod_tb, d_out);

@@ -209,6 +209,13 @@ class _TileHandle(object):
         info = self._info()
         return int(info[8]), int(info[9])
 
+    def pixel_range(self, tile_lo, tile_hi):
+        """Pixels [p0, p1) covered by the tiles [tile_lo, tile_hi) (tiles are not of equal width when
+        the plan balanced them for an uneven hit map)."""
+        r = (ctypes.c_int64 * 2)()
+        _hip.call("cm2_tiles_pixel_range", self.h, int(tile_lo), int(tile_hi), r)
+        return int(r[0]), int(r[1])
+
     def set_pt_order(self, fixed):
         """True: P^T sums every pixel in time order (default); False: LDS atomics."""
         _hip.call("cm2_tiles_set_pt_order", self.h, 1 if fixed else 0)
@@ -322,13 +329,19 @@ class _TiledNormalLO(_DeviceOp):
         if reducer is None:
             _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(src), D.ptr(out), st)
             return D.like_input(out, v)
-        ngroups = max(1, min(ngroups, T.ntiles))
+        # groups of tiles with the same pixel boundaries on every rank (ranks whose hit maps differ
+        # may have cut their tiles differently: the boundaries depend on npix and the tile size only)
+        ngroups = max(1, min(int(ngroups), 8))
+        cuts = (ctypes.c_int64 * (ngroups + 1))()
+        _hip.call("cm2_tiles_group_tiles", T.h, ngroups, cuts)
         works = []
         for g in range(ngroups):
-            lo, hi = T.ntiles * g // ngroups, T.ntiles * (g + 1) // ngroups
+            lo, hi = int(cuts[g]), int(cuts[g + 1])
+            if hi == lo:
+                continue
             _hip.call("cm2_Pt_tiles_apply_range", T.h, D.ptr(src), D.ptr(out), lo, hi, st)
-            a = P.pol * lo * T.tile_pixels
-            b = min(P.pol * hi * T.tile_pixels, out.numel())
+            p0, p1 = T.pixel_range(lo, hi)
+            a, b = P.pol * p0, P.pol * p1
             works.append(reducer(out[a:b]))
         for w in works:
             if w is not None:

@@ -103,6 +103,16 @@ int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* fixed != 0: P^T adds each pixel's terms in time order (reference order, reproducible);
  * fixed == 0: LDS / global atomics */
 int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
+/* h_p0p1[0..1] = pixel range [p0, p1) covered by the tiles [tile_lo, tile_hi).  Tiles are uniform
+ * (tile_pixels wide) unless the hit map is uneven: when a uniform tile would hold over 25 % more
+ * samples than the mean, the pixel ranges are cut to equal sample counts instead (never wider than
+ * tile_pixels), because the fixed-order P^T gives a tile to one workgroup.  Results are the same
+ * bit for bit either way.  CM2_TILE_BALANCE=0 / 1 forces the choice. */
+int cm2_tiles_pixel_range(const cm2_tiles *t, int64_t tile_lo, int64_t tile_hi, int64_t *h_p0p1);
+/* h_tiles[0..ngroups]: group g = tiles [h_tiles[g], h_tiles[g+1]) -- consecutive pieces of the map
+ * for cm2_Pt_tiles_apply_range whose pixel boundaries depend on npix and tile_pixels only, so that
+ * every rank of a TOD-sharded run reduces the same pixels (balanced tilings keep these cuts). */
+int cm2_tiles_group_tiles(const cm2_tiles *t, int ngroups, int64_t *h_tiles);
 /* d_tod_tb[k] = (P x) for the k-th sample in TB order */
 int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
 /* d_out = P^T v for a TB-ordered v (d_out is overwritten) */

@@ -10,6 +10,10 @@ npix = 12 * nside * nside; pol = 3
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 pix = torch.randint(0, npix, (nt,), generator=g, device=dev, dtype=torch.int32)
+skew = float(os.environ.get("PROBE_SKEW", "0"))          # this share of the samples on 10 % of the map
+if skew > 0:
+    hot = torch.rand(nt, generator=g, device=dev) < skew
+    pix[hot] = (pix[hot].to(torch.int64) % (npix // 10)).to(torch.int32)
 phi = 0.3 + 0.0785 * torch.arange(nt, device=dev, dtype=torch.float64)
 ang = SimpleNamespace(cos=torch.cos(2 * phi), sin=torch.sin(2 * phi))
 ang._d_cos, ang._d_sin = ang.cos, ang.sin

@@ -123,7 +123,9 @@ def test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles):
     s[:8] = [0.0, 0.0, 1.0, -1.0, np.sin(1e-9), np.sin(1e-9), np.sin(np.pi - 1e-7), 1.0]
     P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
     T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
-    assert T.nvalid == int((pairs >= 0).sum()) and T.ntiles == (npix + tp - 1) // tp
+    assert T.nvalid == int((pairs >= 0).sum())
+    # (uniform tiles; a run with CM2_TILE_BALANCE=1 re-cuts them to equal sample counts)
+    assert T.ntiles == (npix + tp - 1) // tp or os.environ.get("CM2_TILE_BALANCE") == "1"
     assert T.half_angle == (angles == "half" and pol > 1)
     if pol > 1:
         # weights that are not a (cos, sin) pair: the plan must keep both arrays

@@ -451,3 +451,43 @@ def test_cm2_pcg_driver_equals_python_cg(cm, oracle):
     _hip.call("cm2_pcg", n, ctypes.cast(cbA, ctypes.c_void_p), None, None, None, D.ptr(bd), D.ptr(x3), 1,
               1e-14, 0.0, 2, None, None, ctypes.byref(iters), ctypes.byref(inf), D.stream())
     assert inf.value == 2 and iters.value == 2
+
+
+def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkeypatch):
+    """Half of the samples on a tenth of the map: the tile plan re-cuts its pixel ranges to equal
+    sample counts (the fixed-order P^T gives a tile to one workgroup), P^T N^-1 P does not change
+    by a bit against the uniform tiling, and the groups of tiles a sharded run reduces cover the
+    same pixels in both plans."""
+    import ctypes
+    from types import SimpleNamespace
+    from cosmomap2_amd import _hip
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(99)
+    pol, nside, nt, nblk, lam = 3, 64, 1 << 21, 4, 40
+    npix = 12 * nside * nside
+    pairs = rng.integers(0, npix, nt)
+    hot = rng.random(nt) < 0.5
+    pairs[hot] = pairs[hot] % (npix // 10)
+    pairs[rng.random(nt) < 0.02] = -1
+    phi = 0.3 + 0.0785 * np.arange(nt)
+    ang = SimpleNamespace(cos=np.cos(2 * phi), sin=np.sin(2 * phi))
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / 9.0) for b in range(nblk)]
+    x = rng.standard_normal(pol * npix)
+    out, tiles, groups = {}, {}, {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("CM2_TILE_BALANCE", raising=False)
+        else:
+            monkeypatch.setenv("CM2_TILE_BALANCE", mode)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=ang)
+        T = L._sparse_tiles(P, tile_pixels=128, slice_samples=4096)
+        N = cm.I.BlockLO(nt // nblk, bands, offdiag=True, method=3)
+        out[mode] = np.asarray(L._TiledNormalLO(P, N) * x)
+        tiles[mode] = T.ntiles
+        cuts = (ctypes.c_int64 * 5)()
+        _hip.call("cm2_tiles_group_tiles", T.h, 4, cuts)
+        groups[mode] = [T.pixel_range(int(cuts[g]), int(cuts[g + 1])) for g in range(4)]
+    assert tiles["0"] == npix // 128 and tiles[None] != tiles["0"]          # re-cut on its own
+    assert np.array_equal(out["0"], out[None])
+    assert groups["0"] == groups[None] and groups[None][0][0] == 0 and groups[None][-1][1] == npix
