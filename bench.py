@@ -587,6 +587,30 @@ def main():
                                                  / HBM_PEAK_GBS, 4)}
         del A_r, P_r, ces_r, pix_r, x_r
 
+    # ---- uneven hit map: half of the samples on a tenth of the map (tiles re-cut to equal load) --
+    uneven = None
+    if rank == 0 and world == 1 and lam and not args.no_raster:
+        gen_u = torch.Generator(device=dev).manual_seed(20161203)
+        pix_u = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
+        hot = torch.rand(nt, generator=gen_u, device=dev) < 0.5
+        pix_u[hot] = pix_u[hot] % (npix // 10)
+        del hot
+        phi_u = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+        ces_u = ProcessTimeSamples(pix_u, npix, pol=pol, phi=phi_u)
+        del phi_u
+        n_u = ces_u.get_new_pixel[0]
+        P_u = SparseLO(n_u, nt, pix_u, pol=pol, angle_processed=ces_u)
+        A_u = P_u.T * N * P_u
+        x_u = torch.rand(pol * n_u, generator=torch.Generator(device=dev).manual_seed(9), device=dev,
+                         dtype=torch.float64)
+        _, med_u = ev_time(lambda: A_u * x_u, reps)
+        T_u = L._sparse_tiles(P_u)
+        uneven = {"pointing": "50 % of the samples on the first tenth of the map, the rest uniform",
+                  "tiles": int(T_u.ntiles), "widest_tile_pixels": int(T_u.tile_pixels),
+                  "ms_per_step": round(med_u, 4), "value": round(nt / (med_u * 1e-3), 1),
+                  "unit": "TOD samples/s"}
+        del A_u, P_u, ces_u, pix_u, x_u, T_u
+
     fft_len = N.noise_info()["fft_len"] if lam else 0
 
     # ---- the other scaling mode's point (N > 1) --------------------------------------------
@@ -687,7 +711,7 @@ def main():
             "distributed": dist_info,
             "other_scaling_point": other,
             "pcg": pcg,
-            "raster_pointing": raster,
+            "raster_pointing": raster, "uneven_hit_map": uneven,
             "filters": filters,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
