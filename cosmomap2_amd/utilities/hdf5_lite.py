@@ -76,8 +76,12 @@ class _Reader(object):
         hsize = self.u32(addr + 8)
         blocks = [(addr + 16, hsize)]
         out = []
+        seen = set()
         while blocks and len(out) < nmsg:
             p, left = blocks.pop(0)
+            if p in seen or p < 0 or p + left > len(self.d):
+                raise Hdf5FormatError("object header continuation outside the file or cyclic")
+            seen.add(p)
             end = p + left
             while p + 8 <= end and len(out) < nmsg:
                 mtype, msize = self.u16(p), self.u16(p + 2)
@@ -102,8 +106,12 @@ class _Reader(object):
         """[(name, object header address)] of an old-style group."""
         out = []
         stack = [btree_addr]
+        seen = set()
         while stack:
             a = stack.pop() + self.base
+            if a in seen:
+                raise Hdf5FormatError("cyclic group B-tree")
+            seen.add(a)
             if self.d[a:a + 4] == b"TREE":
                 ntype, used = self.d[a + 4], self.u16(a + 6)
                 if ntype != 0:
@@ -147,7 +155,11 @@ class _Reader(object):
 
     def read_chunks(self, btree, rank, chunk, dt, out):
         stack = [btree]
+        seen = set()
         while stack:
+            if stack[-1] in seen:
+                raise Hdf5FormatError("cyclic chunk B-tree")
+            seen.add(stack[-1])
             a = stack.pop() + self.base
             if self.d[a:a + 4] != b"TREE" or self.d[a + 4] != 1:
                 raise Hdf5FormatError("bad chunk B-tree node")
@@ -185,7 +197,13 @@ class _Reader(object):
                 layout = p
         if shape is None or dt is None or layout is None:
             raise Hdf5FormatError("object is neither a group nor a readable dataset")
-        count = int(np.prod(shape)) if shape else 1
+        count = 1
+        for extent in shape:                        # python ints: no overflow on a corrupt extent
+            count *= int(extent)
+        # a chunked dataset may be larger than the file (unallocated chunks read as zeros), but
+        # not absurdly so: refuse what can only be a corrupt dataspace before allocating it
+        if count * dt.itemsize > 64 * len(self.d) + (1 << 24):
+            raise Hdf5FormatError("dataset of %d bytes in a file of %d" % (count * dt.itemsize, len(self.d)))
         ver = self.d[layout]
         p = layout
         if ver == 3:
@@ -241,18 +259,22 @@ class _Reader(object):
             arr = arr.copy()
         return arr
 
-    def obj(self, addr):
+    def obj(self, addr, _depth=0, _open=None):
+        _open = set() if _open is None else _open
+        if addr in _open or _depth > 64:
+            raise Hdf5FormatError("cyclic or too deeply nested groups")
+        _open = _open | {addr}
         msgs = self.messages(addr)
         for mtype, p, size in msgs:
             if mtype == 0x11:                       # symbol table -> group
                 bt, heap = self.u64(p), self.u64(p + 8)
-                return {name: self.obj(a) for name, a in self.group_entries(bt, heap)}
+                return {name: self.obj(a, _depth + 1, _open) for name, a in self.group_entries(bt, heap)}
         return self.dataset(msgs)
 
 
 def read_file(path):
     """The whole file as nested dicts: groups -> dicts, datasets -> NumPy arrays (scalar
-    datasets -> 0-d arrays)."""
+    datasets -> 0-d arrays).  A truncated or corrupt file raises :class:`Hdf5FormatError`."""
     # the file is mapped, not read: every dataset is copied once, from the page cache into its own
     # array (a 600 MB Ritz-vector checkpoint is not held twice); the mapping goes with `data`
     with open(path, "rb") as f:
@@ -262,7 +284,13 @@ def read_file(path):
             data = f.read()
     if len(data) < 64:
         raise Hdf5FormatError("not an HDF5 file (too short)")
-    return _Reader(data).obj(struct.unpack_from("<Q", data, 24 + (4 if data[8] == 1 else 0) + 40)[0])
+    try:
+        return _Reader(data).obj(struct.unpack_from("<Q", data, 24 + (4 if data[8] == 1 else 0) + 40)[0])
+    except Hdf5FormatError:
+        raise
+    except (IndexError, struct.error, ValueError, TypeError, OverflowError, KeyError,
+            UnicodeDecodeError, RecursionError, MemoryError, AssertionError) as e:
+        raise Hdf5FormatError("corrupt or truncated HDF5 file (%s: %s)" % (type(e).__name__, e))
 
 
 # =============================================================================== writer ===

@@ -77,6 +77,15 @@ def read_map(filename, field=0, dtype=np.float64, nest=False, h=False):
         data = f.read()
     if data[:6] != b"SIMPLE":
         raise FitsFormatError("not a FITS file")
+    try:
+        return _read_map(data, field, dtype, nest, h)
+    except (FitsFormatError, NotImplementedError):
+        raise
+    except (KeyError, ValueError, IndexError, TypeError, OverflowError, MemoryError) as e:
+        raise FitsFormatError("corrupt or truncated FITS file (%s: %s)" % (type(e).__name__, e))
+
+
+def _read_map(data, field, dtype, nest, h):
     prim, pos = _parse_header(data, 0)
     naxis = int(prim.get("NAXIS", 0))
     nbytes = abs(int(prim.get("BITPIX", 8))) // 8

@@ -351,3 +351,48 @@ def test_fits_map_round_trip_fuzz(tmp_path):
                         np.testing.assert_array_equal(a, b.astype(np.float64))
                     with pytest.raises(NotImplementedError):
                         hf.read_map(p, nest=not nest)
+
+
+def test_corrupt_files_raise_the_format_errors(tmp_path):
+    """Truncated files and files with random bytes changed either still parse or raise
+    Hdf5FormatError / FitsFormatError -- no other exception, no hang, no huge allocation."""
+    from cosmomap2_amd.utilities import hdf5_lite as h5, healpix_fits as hf
+    rng = np.random.default_rng(0)
+    p = str(tmp_path / "c.hdf5")
+    h5.write_file(p, {"g": {"a": np.arange(100.), "h": {"z": np.arange(5)},
+                            "b": h5.Chunked(np.arange(64, dtype=">i4").reshape(8, 8), (4, 4))},
+                      "x": np.float64(2.0)})
+    good = open(p, "rb").read()
+    outcomes = set()
+    for i in range(600):
+        d = bytearray(good)
+        if i % 2 == 0:
+            d = d[:int(rng.integers(0, len(d)))]
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        open(p, "wb").write(bytes(d))
+        try:
+            h5.read_file(p)
+            outcomes.add("ok")
+        except h5.Hdf5FormatError:
+            outcomes.add("format error")
+    assert outcomes == {"ok", "format error"}
+    q = str(tmp_path / "c.fits")
+    hf.write_map(q, [np.arange(12 * 4 * 4, dtype=float)] * 3)
+    good = open(q, "rb").read()
+    outcomes = set()
+    for i in range(400):
+        d = bytearray(good)
+        if i % 2 == 0:
+            d = d[:int(rng.integers(0, len(d)))]
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(0, min(len(d), 6000)))] = int(rng.integers(0, 256))
+        open(q, "wb").write(bytes(d))
+        try:
+            hf.read_map(q, field=None)
+            outcomes.add("ok")
+        except (hf.FitsFormatError, NotImplementedError):     # (a flipped ORDERING keyword)
+            outcomes.add("format error")
+    assert outcomes == {"ok", "format error"}
