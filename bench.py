@@ -84,6 +84,56 @@ def git_head():
         return None
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(gpus, argv, port):
+    """The command `python bench.py --gpus N` runs for N > 1 when it was NOT started by
+    torch.distributed.run itself: one rank per GPU of this node, rendezvous on 127.0.0.1 --
+    the same line the driver uses (bench.py's own arguments are passed through unchanged)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(int(gpus)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(gpus, argv):
+    """Start the N ranks as a CHILD process (never exec: nothing in this process has touched the
+    GPU, and it must stay that way), relay rank 0's JSON line, and fail unless the job really ran
+    on N ranks.  Returns the exit code."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launcher_command(gpus, argv, _free_port())
+    print("bench.py: starting %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print("bench.py: torch.distributed.run exited with %d" % proc.returncode, file=sys.stderr)
+        return proc.returncode or 1
+    if line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    rec = json.loads(line)
+    ws = (rec.get("distributed") or {}).get("world_size")
+    if rec.get("n_gpus") != gpus or ws != gpus:
+        print("bench.py: asked for %d ranks, the job reports n_gpus=%r world_size=%r"
+              % (gpus, rec.get("n_gpus"), ws), file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +161,11 @@ def main():
     args = ap.parse_args()
     if args.fft_len:
         os.environ["CM2_FFT_LEN"] = str(args.fft_len)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, before torch is imported
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -132,8 +187,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(2)
 
     import cosmomap2_amd
     from cosmomap2_amd import device as D
@@ -284,8 +343,9 @@ def main():
                      "local_matvec_ms": round(1e3 * el_local / args.steps, 4),
                      "exposed_allreduce_ms": round(ms_per_step - 1e3 * el_local / args.steps, 4),
                      "allreduce_bytes": 8 * n,
-                     "allreduce_chunks": (int(os.environ["CM2_ALLREDUCE_CHUNKS"]) if os.environ.get("CM2_ALLREDUCE_CHUNKS")
-                                          else (4 if nt >= 40_000_000 else 2 if nt >= 15_000_000 else 1))}
+                     # the collective choice the operator made (max over ranks of the shard sizes)
+                     "allreduce_chunks": A.allreduce_chunks(nt),
+                     "map_allreduces_per_matvec": A.collectives_issued // (args.steps + args.warmup)}
 
     # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
     def ev_time(fn, reps):

@@ -82,11 +82,30 @@ def allreduce_sum_(t, group=None):
     return t
 
 
-def make_sync(group=None):
-    """Callable for ``cg(..., sync=)``: every rank continues with the max over ranks of
-    its ||r||^2, so that all ranks stop at the same iteration."""
+def _collective_max(value, group=None):
+    """Max over ranks of a host integer (RCCL needs the buffer in HBM, gloo on the host)."""
     dist = torch.distributed
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    dev = D.dev() if dist.get_backend(group) == "nccl" else "cpu"
+    buf = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    return int(buf.item())
+
+
+def make_sync(group=None, force=False):
+    """Callable for ``cg(..., sync=)``: every rank continues with the max over ranks of
+    its ||r||^2, so that all ranks stop at the same iteration.  ``None`` for a one-rank group
+    unless ``force`` (the RCCL test drives the collective through a one-rank group).
+
+    The callable has two forms.  ``sync(value)`` maps the host value (blocking all-reduce).
+    ``sync.reduce_(t)`` max-reduces a one-element device tensor in place on the current stream
+    WITHOUT waiting for it (RCCL only; ``None`` on gloo): the PCG driver folds it into its deferred
+    read of ||r||^2, so the stop test costs no extra host synchronisation."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size(group) == 1 and not force:
         return None
     backend = dist.get_backend(group)
 
@@ -95,6 +114,11 @@ def make_sync(group=None):
         buf = torch.tensor([value], dtype=torch.float64, device=dev)
         dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
         return float(buf.item())
+
+    def reduce_(t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return t
+    sync.reduce_ = reduce_ if backend == "nccl" else None
     return sync
 
 
@@ -107,34 +131,52 @@ class ShardedLO(lp.LinearOperator):
     def __init__(self, local_op, group=None):
         self.local_op = local_op
         self.group = group
+        self._chunks = None              # collective choice, made at the first matvec
+        self.collectives_issued = 0      # map all-reduces issued so far (tests compare ranks)
         n = local_op.shape[0]
         super(ShardedLO, self).__init__(n, n, self._mult, symmetric=True,
                                         device_ok=lp.supports_device(local_op))
 
+    def allreduce_chunks(self, nloc=None):
+        """Number of tile groups whose all-reduces are overlapped with the back-projection.  The
+        choice is COLLECTIVE: every rank must issue the same number (and sizes) of collectives per
+        matvec, so it is derived from the MAX over ranks of the per-rank sample count (one 8-byte
+        all-reduce at the first matvec, cached), never from this rank's own shard -- uneven shards
+        on either side of a threshold would otherwise disagree.  A chunk's all-reduce hides behind
+        the back-projection of the next chunk: worth it while that takes longer than a small
+        collective's latency (P^T of 1e8 samples: 0.4 ms) -> 4 groups from 4e7 samples per rank
+        up, 2 from 1.5e7; a strongly scaled shard (1e7 samples: 0.05 ms) sends the map in one
+        piece.  CM2_ALLREDUCE_CHUNKS overrides (it must be set identically on every rank)."""
+        import os
+        if os.environ.get("CM2_ALLREDUCE_CHUNKS"):
+            return int(os.environ["CM2_ALLREDUCE_CHUNKS"])
+        if self._chunks is None:
+            if nloc is None:
+                return None
+            nmax = _collective_max(int(nloc), self.group)
+            self._chunks = 4 if nmax >= 40_000_000 else (2 if nmax >= 15_000_000 else 1)
+        return self._chunks
+
     def _overlapped(self, x):
         """Tile-order chain with a fused noise operator: reduce tile groups while the next
-        ones are still being back-projected (CM2_ALLREDUCE_CHUNKS groups, default 4; 0 or 1
-        = one all-reduce after the matvec)."""
+        ones are still being back-projected (:meth:`allreduce_chunks` groups; 0 or 1 = one
+        all-reduce after the matvec).  With CM2_ALLREDUCE_CHUNKS set the chunked path is also
+        taken by a one-rank group (the collectives are then trivial; used by the RCCL test)."""
         import os
         dist = torch.distributed
-        if not (dist.is_available() and dist.is_initialized()) \
-                or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if dist.get_world_size(self.group) == 1 and not os.environ.get("CM2_ALLREDUCE_CHUNKS"):
             return None
         plan = getattr(self.local_op, "_compiled", None)
         ops = plan() if plan is not None else [self.local_op]
         if len(ops) != 1 or not hasattr(ops[0], "reduced_matvec"):
             return None
-        if os.environ.get("CM2_ALLREDUCE_CHUNKS"):
-            chunks = int(os.environ["CM2_ALLREDUCE_CHUNKS"])
-        else:
-            # a chunk's all-reduce hides behind the back-projection of the next chunk: worth it
-            # while that takes longer than a small collective's latency (P^T of 1e8 samples:
-            # 0.4 ms); a strongly scaled shard (1e7 samples: 0.05 ms) sends the map in one piece
-            nloc = int(getattr(getattr(ops[0], "P", None), "nrows", 0))
-            chunks = 4 if nloc >= 40_000_000 else (2 if nloc >= 15_000_000 else 1)
+        chunks = self.allreduce_chunks(int(getattr(getattr(ops[0], "P", None), "nrows", 0)))
         if chunks <= 1:
             return None
         group = self.group
+        self.collectives_issued += chunks
         return ops[0].reduced_matvec(
             x, lambda view: dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True),
             chunks)
@@ -148,6 +190,7 @@ class ShardedLO(lp.LinearOperator):
             y = np.ascontiguousarray(y)
         elif not y.is_contiguous():
             y = y.contiguous()
+        self.collectives_issued += 1
         return allreduce_sum_(y, self.group)
 
 

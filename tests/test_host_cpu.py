@@ -228,3 +228,43 @@ def test_header_is_plain_c_and_links(tmp_path):
                            "-I" + os.path.join(ROOT, "include"), str(src), "-L" + libdir,
                            "-lcosmomap2_hip", "-Wl,-rpath," + libdir, "-o", exe])
     assert subprocess.call([exe]) == 0
+
+
+def test_bench_launcher_command_line(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE starts N ranks itself: the command it runs is
+    the driver's torch.distributed.run line with bench.py's own arguments passed through, and the
+    relay fails unless the job reports N ranks."""
+    import json
+    import subprocess
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "5", "--config", "c3"], 29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29777"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--config", "c3"]
+
+    class _Done(object):
+        def __init__(self, line, rc=0):
+            self.stdout, self.returncode = (line + "\n").encode(), rc
+
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return seen["result"]
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    good = json.dumps({"metric": "m", "n_gpus": 2, "distributed": {"world_size": 2}})
+    seen["result"] = _Done(good)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a job that ran on fewer ranks than asked for, a failed job, a job without a line: non-zero
+    seen["result"] = _Done(json.dumps({"metric": "m", "n_gpus": 1, "distributed": None}))
+    assert bench.launch_ranks(2, ["--gpus", "2"]) != 0
+    seen["result"] = _Done(good, rc=3)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 3
+    seen["result"] = _Done("no json here")
+    assert bench.launch_ranks(2, ["--gpus", "2"]) != 0

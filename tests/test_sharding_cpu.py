@@ -118,6 +118,43 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(lo, hi)
         sync = make_sync()
         assert sync(float(rank + 1)) == float(world)        # max over ranks
+        assert sync.reduce_ is None                         # gloo: no device-side form
+
+        # ---- the number of overlapped all-reduces per matvec is a COLLECTIVE choice: uneven
+        #      shards on either side of a threshold (rank 0: 14e6 samples -> 1 chunk by itself,
+        #      rank 1: 15e6 -> 2) must still issue the same collectives on every rank
+        class _P(object):
+            nrows = 14_000_000 + 1_000_000 * rank
+
+        class _Chunked(lp.LinearOperator):
+            """stand-in for the tile-order chain: reduces its output in `chunks` equal pieces"""
+            P = _P()
+
+            def __init__(self):
+                super(_Chunked, self).__init__(8, 8, lambda v: v * 1.0, symmetric=True)
+
+            def _compiled(self):
+                return [self]
+
+            def reduced_matvec(self, v, reducer, chunks):
+                out = torch.from_numpy(np.array(v, dtype=np.float64))
+                step = -(-out.numel() // chunks)
+                works = [reducer(out[a:a + step]) for a in range(0, out.numel(), step)]
+                for wk in works:
+                    wk.wait()
+                return out.numpy()
+
+        os.environ.pop("CM2_ALLREDUCE_CHUNKS", None)
+        Ac = ShardedLO(_Chunked())
+        assert Ac.allreduce_chunks() is None                # not decided before the first matvec
+        yc = Ac * np.arange(8.0)
+        assert np.array_equal(yc, world * np.arange(8.0))
+        assert Ac.allreduce_chunks() == 2                   # from the MAX over ranks, on every rank
+        cnt = torch.tensor([Ac.collectives_issued], dtype=torch.int64)
+        lo_c, hi_c = cnt.clone(), cnt.clone()
+        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+        assert int(lo_c) == int(hi_c) == 2, (int(lo_c), int(hi_c))
 
         # ---- row-sharded vectors (reduce-scatter variant): every rank owns n / N rows
         from cosmomap2_amd.sharding import RowShards, RowShardedNormalLO
