@@ -227,11 +227,26 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         CM2_HIP(hipMemcpyAsync(r.p, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
         if (int rc = cm2_axpy(n, -1.0, q.p, r.p, stream_)) return rc;
     }
+    // ||r||^2 is read through pinned memory behind an event, and the host waits for it only
+    // after it has queued everything of the next iteration that touches neither x nor r
+    // (z = M r, rho, p, q = A p, p.q): the GPU never idles while the host issues launches.
+    // On convergence the speculative work is dropped (it wrote z, p, q and two scalars).
+    struct Deferred {
+        double *host = nullptr;
+        hipEvent_t ev = nullptr;
+        ~Deferred() { if (host) (void)hipHostFree(host); if (ev) (void)hipEventDestroy(ev); }
+    } df;
+    CM2_HIP(hipHostMalloc((void **)&df.host, sizeof(double), hipHostMallocDefault));
+    CM2_HIP(hipEventCreateWithFlags(&df.ev, hipEventDisableTiming));
+    auto post = [&](const double *d) -> int {
+        CM2_HIP(hipMemcpyAsync(df.host, d, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipEventRecord(df.ev, stream));
+        return 0;
+    };
     if (int rc = cm2_dot(n, r.p, r.p, rr, work, stream)) return rc;
-    if (int rc = fetch(rr)) return rc;
+    if (int rc = post(rr)) return rc;
     int cur = 0;
     for (int64_t it = 0; it < maxiter; ++it) {
-        if (sqrt(h) < atol) return 0;
         const double *zz = r.p;
         if (M) {
             if (M(M_ctx, r.p, z.p, stream_)) { set_error("cm2_pcg: the preconditioner callback failed"); return 1; }
@@ -245,11 +260,23 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         }
         if (A(A_ctx, p.p, q.p, stream_)) { set_error("cm2_pcg: the operator callback failed"); return 1; }
         if (int rc = cm2_dot(n, p.p, q.p, pq, work, stream)) return rc;
+        // ---- the state before this iteration: report it, then the stop test
+        CM2_HIP(hipEventSynchronize(df.ev));
+        h = *df.host;
+        if (it > 0) {
+            *h_iters = it;
+            if (callback) callback(cb_ctx, it, d_x, sqrt(h));
+        }
+        if (sqrt(h) < atol) return 0;
         if (int rc = cm2_pcg_update_xr(n, rho[cur], pq, p.p, q.p, d_x, r.p, rr, work, stream_)) return rc;
         cur = 1 - cur;
-        if (int rc = fetch(rr)) return rc;
-        *h_iters = it + 1;
-        if (callback) callback(cb_ctx, it + 1, d_x, sqrt(h));
+        if (int rc = post(rr)) return rc;
+    }
+    if (maxiter > 0) {
+        CM2_HIP(hipEventSynchronize(df.ev));
+        h = *df.host;
+        *h_iters = maxiter;
+        if (callback) callback(cb_ctx, maxiter, d_x, sqrt(h));
     }
     *h_info = (int)maxiter;                                // not converged within maxiter
     return 0;

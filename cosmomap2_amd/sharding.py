@@ -26,6 +26,8 @@ Two layouts of the map-domain vectors (x, r, p, z, Z):
   all-reduce; M_BD, the vector updates and the passes over Z / AZ (3 n r 8 bytes per M2, 1.8 GB
   at nside 256, r = 32) shrink by the number of ranks.
 """
+import os
+
 import numpy as np
 
 from . import device as D
@@ -35,6 +37,16 @@ torch = D.torch
 
 __all__ = ["shard_blocks", "allreduce_sum_", "ShardedLO", "make_sync", "world", "RowShards",
            "RowShardedNormalLO", "row_sharded_bd", "row_sharded_two_level"]
+
+
+def _trivial(group=None):
+    """True when a collective over `group` would be the identity and may be skipped: no process
+    group, or one rank -- unless CM2_FORCE_COLLECTIVES is set (the one-rank RCCL test then sends
+    every collective of this module through the transport)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not os.environ.get("CM2_FORCE_COLLECTIVES")
 
 
 def world(group=None):
@@ -72,7 +84,7 @@ def shard_blocks(block_sizes, world_size, rank):
 def allreduce_sum_(t, group=None):
     """In-place sum over ranks of a tensor (HBM: RCCL; host: gloo).  No-op for one rank."""
     dist = torch.distributed
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _trivial(group):
         return t
     if isinstance(t, np.ndarray):
         buf = torch.from_numpy(t)
@@ -85,7 +97,7 @@ def allreduce_sum_(t, group=None):
 def _collective_max(value, group=None):
     """Max over ranks of a host integer (RCCL needs the buffer in HBM, gloo on the host)."""
     dist = torch.distributed
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _trivial(group):
         return int(value)
     dev = D.dev() if dist.get_backend(group) == "nccl" else "cpu"
     buf = torch.tensor([int(value)], dtype=torch.int64, device=dev)
@@ -105,7 +117,7 @@ def make_sync(group=None, force=False):
     dist = torch.distributed
     if not (dist.is_available() and dist.is_initialized()):
         return None
-    if dist.get_world_size(group) == 1 and not force:
+    if _trivial(group) and not force:
         return None
     backend = dist.get_backend(group)
 
@@ -147,7 +159,6 @@ class ShardedLO(lp.LinearOperator):
         collective's latency (P^T of 1e8 samples: 0.4 ms) -> 4 groups from 4e7 samples per rank
         up, 2 from 1.5e7; a strongly scaled shard (1e7 samples: 0.05 ms) sends the map in one
         piece.  CM2_ALLREDUCE_CHUNKS overrides (it must be set identically on every rank)."""
-        import os
         if os.environ.get("CM2_ALLREDUCE_CHUNKS"):
             return int(os.environ["CM2_ALLREDUCE_CHUNKS"])
         if self._chunks is None:
@@ -162,11 +173,10 @@ class ShardedLO(lp.LinearOperator):
         ones are still being back-projected (:meth:`allreduce_chunks` groups; 0 or 1 = one
         all-reduce after the matvec).  With CM2_ALLREDUCE_CHUNKS set the chunked path is also
         taken by a one-rank group (the collectives are then trivial; used by the RCCL test)."""
-        import os
         dist = torch.distributed
         if not (dist.is_available() and dist.is_initialized()):
             return None
-        if dist.get_world_size(self.group) == 1 and not os.environ.get("CM2_ALLREDUCE_CHUNKS"):
+        if _trivial(self.group) and not os.environ.get("CM2_ALLREDUCE_CHUNKS"):
             return None
         plan = getattr(self.local_op, "_compiled", None)
         ops = plan() if plan is not None else [self.local_op]
@@ -232,7 +242,7 @@ class RowShards(object):
 
     def gather(self, loc):
         """Whole vector from every rank's rows (all-gather)."""
-        if self.world == 1:
+        if _trivial(self.group):
             return loc[:self.n] if len(loc) != self.n else loc
         full = self._like(loc, self.rows * self.world)
         torch.distributed.all_gather_into_tensor(self._as_tensor(full), self._as_tensor(
@@ -241,7 +251,7 @@ class RowShards(object):
 
     def reduce_scatter(self, full):
         """This rank's rows of the sum over ranks of whole vectors (reduce-scatter)."""
-        if self.world == 1:
+        if _trivial(self.group):
             return self.local(full)
         padded = self._like(full, self.rows * self.world)
         padded[:self.n] = full

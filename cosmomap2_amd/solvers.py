@@ -18,7 +18,8 @@ convention and reproduces scipy's recurrence step for step (scipy 1.15
 (src/test_BD_precond_onto_real_data.py:41-47).  The scalars alpha and beta never
 visit the host: the fused update kernels read rho, rho_prev and p.q from device
 memory; the only per-iteration synchronisation is the 8-byte read of ||r||^2 for
-the convergence test.
+the convergence test, and that read is deferred behind the launches of the next iteration
+(see the comment in :func:`cg`), so the GPU does not wait for the host between iterations.
 """
 import math
 
@@ -58,8 +59,9 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
     or float64 tensors in HBM (result is a tensor, ``callback`` receives a tensor).
 
     ``sync``: optional callable mapping the host value of ||r||^2 to the value every
-    rank must use (sharding.py passes an all-reduce so that all ranks take the same
-    branch).  ``dot_reduce``: optional callable summing a device scalar over ranks in place --
+    rank must use (sharding.make_sync: a max over ranks so that all ranks take the same
+    branch); when it has a ``reduce_`` attribute (RCCL) the reduction is queued on the device
+    in front of the deferred read instead, and the host form is not called.  ``dot_reduce``: optional callable summing a device scalar over ranks in place --
     for row-sharded vectors (sharding.RowShards.allreduce_), where every rank holds only its
     rows and each scalar product is a local sum plus an 8-byte all-reduce; alpha and beta still
     never visit the host.
@@ -102,16 +104,39 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
             r = D.add_scaled(bd, -1.0, _apply(A, x))          # r = b - A x0
         else:
             r = bd.clone()
+    # ||r||^2 reaches the host through a deferred read: once it is final on the stream (summed
+    # over ranks for row-sharded vectors, max-reduced on the device when `sync` can), an
+    # asynchronous copy to pinned memory and an event are queued behind it.  The host does not
+    # wait there: it first queues everything of the NEXT iteration that touches neither x nor r
+    # (z = M r, rho, the update of p, q = A p, p.q) and only then waits for the event -- by which
+    # time the GPU has that iteration's kernels in its queue and never idles while Python issues
+    # launches.  When the value says "converged", x is returned as it is and the speculative
+    # work is simply dropped (it wrote z, p, q and two scalars only), so callback invocations,
+    # return values and iteration counts are those of scipy's recurrence.
+    rr_pinned = torch.empty(1, dtype=torch.float64).pin_memory()
+    rr_event = torch.cuda.Event()
+    reduce_dev = getattr(sync, "reduce_", None) if sync is not None else None
+
+    def post_rr():
+        if reduce_dev is not None:
+            reduce_dev(rr)
+        rr_pinned.copy_(rr, non_blocking=True)
+        rr_event.record()
+
+    def wait_rr():
+        rr_event.synchronize()
+        value = float(rr_pinned[0])
+        if sync is not None and reduce_dev is None:
+            value = sync(value)
+        return value
+
     dot_into(rr, r, r)
-    rr_host = float(rr.item())
-    if sync is not None:
-        rr_host = sync(rr_host)
+    post_rr()
 
     p = None
     cur = 0
     for iteration in range(int(maxiter)):
-        if math.sqrt(rr_host) < atol:
-            return (D.to_host(x) if host_io else x), 0
+        # queued ahead of the stop test: nothing here writes x or r
         z = _apply(M, r) if M is not None else r
         dot_into(rho[cur], r, z)
         if iteration > 0:
@@ -121,14 +146,14 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
             p = z.clone()
         q = _apply(A, p)
         dot_into(pq, p, q)
+        if math.sqrt(wait_rr()) < atol:             # ||r|| of the state before this iteration
+            return (D.to_host(x) if host_io else x), 0
         _hip.check(lib.cm2_pcg_update_xr(n, D.ptr(rho[cur]), D.ptr(pq), D.ptr(p), D.ptr(q),
                                          D.ptr(x), D.ptr(r), D.ptr(rr), D.ptr(work), st()))
         cur = 1 - cur
         if dot_reduce is not None:
             dot_reduce(rr)
-        rr_host = float(rr.item())
-        if sync is not None:
-            rr_host = sync(rr_host)
+        post_rr()
         if callback is not None:
             callback(D.to_host(x) if host_io else x)
     return (D.to_host(x) if host_io else x), int(maxiter)

@@ -1311,8 +1311,9 @@ def test_full_size_properties_c4(cm):
 
 def test_full_size_properties_c5_share(cm):
     """One GPU's share of BASELINE config C5: nside 512 IQU, 1.25e8 samples = 8 detector blocks
-    of 15 625 000, lambda 2048."""
-    _full_size_toeplitz_properties(cm, 512, 125_000_000, 8, 20161206)
+    of 15 625 000, lambda 2048, Toeplitz N^-1 + two-level preconditioner (deflation space of
+    dimension 32), as BASELINE config 5 names it."""
+    _full_size_toeplitz_properties(cm, 512, 125_000_000, 8, 20161206, two_level_rank=32)
 
 
 def test_config_c1_reference_runnable_case(cm, oracle):

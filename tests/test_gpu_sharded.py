@@ -25,3 +25,17 @@ def test_two_ranks_share_one_gpu():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "SHARDED-OK" in res.stdout, res.stdout[-2000:]
     assert "ROWSHARDED-OK" in res.stdout, res.stdout[-2000:]
+
+
+def test_one_rank_rccl_group():
+    """The "nccl" (RCCL) backend itself, with one rank on the one GPU of the test box: every
+    collective of sharding.py is forced through the transport (tests/_nccl_worker.py) and the
+    results must be those of the single-process run, bit for bit."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": "29541"})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py")],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "RCCL-1RANK-OK" in res.stdout, res.stdout[-2000:]
