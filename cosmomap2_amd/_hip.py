@@ -48,6 +48,7 @@ PROTOTYPES = {
     "cm2_noise_apply_tiles": [_vp, _vp, _vp, _vp, _vp],
     "cm2_noise_expand_diag": [_vp, _vp, _vp],
     "cm2_noise_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_noise_tile_kernel_info": [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)],
     "cm2_weights_accumulate": [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cm2_pixel_mask": [_int, _i64, _vp, _vp, _vp, _vp, _dbl, _vp, _vp],
     "cm2_pixel_compact": [_i64, _vp, _vp, ctypes.POINTER(_i64), _vp],

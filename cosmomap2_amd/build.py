@@ -47,7 +47,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            flags = list(FLAGS)
+            flags = list(FLAGS) + os.environ.get("CM2_EXTRA_HIPCC_FLAGS", "").split()
             if os.path.basename(s) in FMA_OK:
                 flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
             jobs.append([HIPCC] + flags + ["-c", s, "-o", o])

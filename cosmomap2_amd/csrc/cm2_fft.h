@@ -20,5 +20,21 @@ int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, 
                            double *d_out, hipStream_t stream);
 int64_t fused_os_length(const FusedOS *f);
 void fused_os_destroy(FusedOS *f);
+// what the tile-order application uses: kernel[0] = 0 segment-pair kernel (cm2_fft.hip), 16 / 32 =
+// one-real-window kernel with that many points per thread (cm2_fft_real.hip); kernel[1] = list
+// format (1 plain, 2 run-coded, 0 not built yet); returns the HBM bytes per sample it is built to move
+double fused_os_tile_info(const FusedOS *f, int *kernel);
+
+// ---- one real window per workgroup (cm2_fft_real.hip) ----
+struct RealOS;
+int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
+                   const std::vector<int64_t> &off, hipStream_t stream);
+int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream);
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, bool want_rc,
+                          const double *d_v, double *d_out, hipStream_t stream);
+double real_os_tile_bytes_per_sample(const RealOS *f);
+int real_os_list_mode(const RealOS *f);
+int64_t real_os_window(const RealOS *f);
+void real_os_destroy(RealOS *f);
 
 }  // namespace cm2

@@ -544,7 +544,43 @@ struct FusedOS {
     uint64_t list_plan = 0;              // id of the tile plan the lists were built for
     uint32_t *d_lst_k = nullptr;         // [npairs][20480] addresses: window part 1 | part 2 | results
     uint16_t *d_lst_q = nullptr;         // positions in the window / result window
+    // the one-real-window kernel (cm2_fft_real.hip), built on first use when CM2_OS_KERNEL selects it
+    RealOS *real = nullptr;
+    int real_pt = 0;                     // 0: segment-pair kernel of this file
+    bool real_rc = true;                 // run-coded lists
+    double *d_bands = nullptr;           // borrowed from the noise operator (lives as long as it does)
+    int64_t lambda = 0;
+    std::vector<int64_t> off;
 };
+
+// CM2_OS_KERNEL = pair | real16 | real32 selects the overlap-save kernel of the tile-order and
+// time-order applications; CM2_OS_LISTS = rc | plain the list format of the real-window kernel.
+static void os_choice(int *pt, bool *rc)
+{
+    *pt = 16;
+    *rc = true;
+    if (const char *e = getenv("CM2_OS_KERNEL")) {
+        if (!strcmp(e, "pair")) *pt = 0;
+        else if (!strcmp(e, "real32")) *pt = 32;
+        else if (!strcmp(e, "real16")) *pt = 16;
+    }
+    if (const char *e = getenv("CM2_OS_LISTS"))
+        if (!strcmp(e, "plain")) *rc = false;
+}
+
+static int ensure_real(FusedOS *f, hipStream_t stream)
+{
+    int pt;
+    bool rc;
+    os_choice(&pt, &rc);
+    f->real_rc = rc;
+    if (pt == f->real_pt && (pt == 0 || f->real)) return 0;
+    if (f->real) real_os_destroy(f->real);
+    f->real = nullptr;
+    f->real_pt = pt;
+    if (pt == 0) return 0;
+    return real_os_create(&f->real, pt, f->d_bands, f->lambda, f->off, stream);
+}
 
 static void free_lists(FusedOS *f)
 {
@@ -559,6 +595,7 @@ void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
     free_lists(f);
+    if (f->real) real_os_destroy(f->real);
     void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -583,9 +620,22 @@ static int launch_reg(const FusedOS *f, const double *d_v, double *d_out, hipStr
     return 0;
 }
 
-int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
+int fused_os_apply(const FusedOS *f_, const double *d_v, double *d_out, hipStream_t stream)
 {
+    FusedOS *f = const_cast<FusedOS *>(f_);
+    if (int rc = ensure_real(f, stream)) return rc;
+    if (f->real) return real_os_apply(f->real, d_v, d_out, stream);
     return launch_reg<false>(f, d_v, d_out, stream);
+}
+
+double fused_os_tile_info(const FusedOS *f, int *kernel)
+{
+    if (kernel) {
+        kernel[0] = f ? f->real_pt : 0;
+        kernel[1] = f ? (f->real ? real_os_list_mode(f->real) : (f->d_lst_k ? 1 : 0)) : 0;
+    }
+    if (f && f->real) return real_os_tile_bytes_per_sample(f->real);
+    return 35.0;           // 1.5 x 8 gathered + 8 written + 2.5 list entries of 6 bytes
 }
 
 // the three address-sorted lists of every pair for the tile plan whose index is d_idx
@@ -638,6 +688,8 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
 int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, const double *d_v,
                            double *d_out, hipStream_t stream)
 {
+    if (int rc = ensure_real(f, stream)) return rc;
+    if (f->real) return real_os_apply_indexed(f->real, d_idx, plan_id, f->real_rc, d_v, d_out, stream);
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
     // again to a later plan of the same size)
     if (f->list_plan != plan_id || (f->npairs > 0 && !f->d_lst_k))
@@ -655,6 +707,9 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     FusedOS *f = new FusedOS();
     struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};   // early returns
     f->halo = (int)(lambda - 1);
+    f->d_bands = const_cast<double *>(d_bands);
+    f->lambda = lambda;
+    f->off = off;
     const int64_t nb = (int64_t)off.size() - 1;
     // segment pairs: fixed geometry (hop 4096, halo 2048 whatever lambda is)
     std::vector<PairDesc> pairs;

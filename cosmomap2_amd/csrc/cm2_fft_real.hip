@@ -1,0 +1,1008 @@
+// cm2_fft_real.hip -- banded-Toeplitz N^-1 by overlap-save, ONE REAL WINDOW per workgroup.
+//
+// Reference semantics: ToeplitzLO.mult, interfaces/linearoperators.py:582-595 (symmetric band,
+// ZERO boundary at both ends of every block), dispatched per block as interfaces/blkop.py:195-206.
+//
+// Where cm2_fft.hip packs two segments of a block as one complex signal A + iB of 8192 points
+// (224 VGPRs, 66 KB of LDS: two workgroups of one wave per SIMD each per CU, which behave as two
+// sequential machines -- DESIGN.md section 3), this kernel transforms one real window of
+// 2N samples as a complex signal of N points
+//
+//     z[a] = x[2a] + i x[2a+1],   Z = FFT_N(z),
+//     Z'[k] = alpha_k Z[k] + i beta_k conj(Z[N-k]),   z' = IFFT_N(Z') = y[2a] + i y[2a+1]
+//
+// with two real tables per noise block, alpha = (S - D sin(pi k/N)) / N, beta = D cos(pi k/N) / N,
+// S, D = (H[k] +- H[k+N]) / 2 and H the band's real, even spectrum on 2N points: no untangling pass;
+// the partner bin N-k lives in ONE other thread (k' = N-k is (263 - t, 31 - m) resp. (271 - t,
+// 15 - m) in the digit-reversed register layout), so the pairing costs one more plane exchange.
+//
+//   PT = 16: N = 4096, window 8192 samples, 4096 outputs; 16 complex points per thread,
+//            <= 128 VGPRs and <= 40 KB of LDS -> FOUR workgroups (16 waves) per CU;
+//   PT = 32: N = 8192, window 16384 samples, 12288 outputs (overlap 1.33 instead of 1.5); the
+//            register budget of the pair kernel, two workgroups per CU.
+//
+// On the tile-bucketed order the window is reached through address-sorted lists (two half-window
+// lists, one or two result lists), in one of two formats:
+//   plain : a 4-byte address and a 2-byte position per entry;
+//   RC    : run-coded -- a window's samples in one pixel tile are consecutive addresses, so a list is
+//           a few hundred runs: per entry 2 bytes (position, bit 15 = "a run starts here"), per run
+//           one 4-byte word delta = address - slot, staged in LDS; entry s of run r has address
+//           delta[r] + s, r from a ballot and a population count.  2.0 + 4 / run length bytes per
+//           entry instead of 6.
+// This translation unit is compiled with FMA contraction ON (results are compared with the direct
+// sum at 1e-12, not bit for bit).
+#include "cm2_fft.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace cm2;
+
+namespace {
+
+constexpr double kCos32[32] = {1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828, 0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304};
+constexpr double kSin32[32] = {0.0, 0.19509032201612828, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476, 0.8314696123025452, 0.9238795325112867, 0.9807852804032304, 1.0, 0.9807852804032304, 0.9238795325112867, 0.8314696123025452, 0.7071067811865476, 0.5555702330196022, 0.3826834323650898, 0.19509032201612828, 0.0, -0.19509032201612828, -0.3826834323650898, -0.5555702330196022, -0.7071067811865476, -0.8314696123025452, -0.9238795325112867, -0.9807852804032304, -1.0, -0.9807852804032304, -0.9238795325112867, -0.8314696123025452, -0.7071067811865476, -0.5555702330196022, -0.3826834323650898, -0.19509032201612828};
+
+__host__ __device__ constexpr int ilog2(int r) { return r <= 1 ? 0 : 1 + ilog2(r >> 1); }
+
+template <int R>
+__host__ __device__ constexpr int brev(int m)
+{
+    int out = 0;
+    for (int b = 0; b < ilog2(R); ++b) out |= ((m >> b) & 1) << (ilog2(R) - 1 - b);
+    return out;
+}
+
+constexpr int kT = 256;           // threads per workgroup
+constexpr int kHalo = 2048;       // window halo on both sides (>= lambda - 1)
+
+template <int PT>
+struct Geo {
+    static constexpr int N = kT * PT;                 // complex points
+    static constexpr int W = 2 * N;                   // window samples
+    static constexpr int HOP = W - 2 * kHalo;         // outputs per window
+    static constexpr int RR = PT == 16 ? 1 : 2;       // result rounds through the LDS buffer
+    static constexpr int RSLOTS = (PT - 8) / RR;      // register slots per round (m = 4 + j RSLOTS ...)
+    static constexpr int RLEN = 512 * RSLOTS;         // outputs per round
+    static constexpr int NLIST = 2 + RR;              // lists per window: two window halves, results
+    static constexpr int PER = 2 * N + HOP;           // list entries per window
+    static constexpr int LDSD = N + N / 32;           // doubles of the exchange buffer
+    static constexpr int BLK = PT / 16;               // radix-16 blocks per thread
+    __host__ __device__ static constexpr int list_off(int l) { return l <= 2 ? l * N : 2 * N + (l - 2) * RLEN; }
+    __host__ __device__ static constexpr int list_len(int l) { return l < 2 ? N : RLEN; }
+};
+
+// Diagnostic build only (-DCM2_OS_STAMPS, never in the shipped library): thread 0 of every workgroup
+// records s_memtime at the phase boundaries into a buffer of 8 words per window.
+#ifdef CM2_OS_STAMPS
+__device__ unsigned long long *g_os_stamps = nullptr;
+#define OS_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if (g_os_stamps && threadIdx.x == 0) g_os_stamps[(int64_t)win * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define OS_STAMP(i) do { } while (0)
+#endif
+
+struct WinDesc {              // one workgroup's work: HOP (or fewer) outputs of one noise block
+    int64_t start, len, lo, hi;
+    int32_t blk, pad;
+};
+
+struct ListHdr {              // one run-coded list
+    uint32_t nvalid;          // entries with a sample (they come first: invalid keys sort last)
+    uint32_t nruns;
+    int32_t wbase[4];         // run index in front of each wave's first slot (-1: none)
+    uint32_t pad[2];
+};
+
+// ---- register layouts, as in cm2_fft.hip with 32 -> PT -------------------------------------------
+//   P1: a = t + 256 m                      radix-PT pass over stride 256   (n = N)
+//   P2: a = (16 (m>>4) + (t>>4)) 256 + (t&15) + 16 (m&15)      radix-16 over stride 16 (n = 256)
+//   P3: a = PT t + m                       radix-16 on contiguous points
+// padded LDS index padi(a) = a + (a >> 5) split into a per-thread base and a compile-time offset
+template <int PT, int L>
+__device__ __forceinline__ int reg_base(int t)
+{
+    if (L == 1) return t + (t >> 5);
+    if (L == 2) return (t >> 4) * 264 + (t & 15);
+    return PT == 32 ? 33 * t : 16 * t + (t >> 1);
+}
+template <int L>
+__host__ __device__ constexpr int reg_off(int m)
+{
+    return L == 1 ? 264 * m : (L == 2 ? 4224 * (m >> 4) + 16 * (m & 15) + ((m & 15) >> 1) : m);
+}
+// where slot m of the array sits after in-place butterflies (dft_sub leaves output m of a radix-R
+// block at index brev<R>(m)): PERM = 0 natural, 32 one radix-32 block, 16 radix-16 blocks
+template <int PERM>
+__host__ __device__ constexpr int reg_slot(int m)
+{
+    return PERM == 32 ? brev<32>(m) : (PERM == 16 ? 16 * (m >> 4) + brev<16>(m & 15) : m);
+}
+
+template <int PT, int FROM, int TO, int PERM>
+__device__ __forceinline__ void reg_exchange(double (&a)[PT], double *__restrict__ buf, int t)
+{
+    double *__restrict__ wp = buf + reg_base<PT, FROM>(t);
+    const double *__restrict__ rp = buf + reg_base<PT, TO>(t);
+#pragma unroll
+    for (int m = 0; m < PT; ++m) wp[reg_off<FROM>(m)] = a[reg_slot<PERM>(m)];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < PT; ++m) a[m] = rp[reg_off<TO>(m)];
+    __syncthreads();
+}
+
+// in-place decimation-in-frequency butterflies on the sub-block [OFF, OFF + R)
+template <int PT, int R, int OFF>
+__device__ __forceinline__ void dft_sub(double (&re)[PT], double (&im)[PT])
+{
+#pragma unroll
+    for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const int a = OFF + blk + i, b = a + h;
+                const int tw = i * (32 / (2 * h));
+                const double ar = re[a], ai = im[a], br = re[b], bi = im[b];
+                re[a] = ar + br;
+                im[a] = ai + bi;
+                const double dr = ar - br, di = ai - bi;
+                if (tw == 0) {
+                    re[b] = dr;
+                    im[b] = di;
+                } else if (tw == 8) {
+                    re[b] = di;
+                    im[b] = -dr;
+                } else {
+                    const double c = kCos32[tw], s = kSin32[tw];
+                    re[b] = dr * c + di * s;
+                    im[b] = di * c - dr * s;
+                }
+            }
+        }
+    }
+}
+
+// decimation-in-time counterpart: input m at index brev<R>(m), output natural
+template <int PT, int R, int OFF>
+__device__ __forceinline__ void dit_sub(double (&re)[PT], double (&im)[PT])
+{
+#pragma unroll
+    for (int h = 1; h <= R / 2; h <<= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const int a = OFF + blk + i, b = a + h;
+                const int tw = i * (32 / (2 * h));
+                double tr, ti;
+                if (tw == 0) {
+                    tr = re[b];
+                    ti = im[b];
+                } else if (tw == 8) {
+                    tr = im[b];
+                    ti = -re[b];
+                } else {
+                    const double c = kCos32[tw], s = kSin32[tw];
+                    tr = re[b] * c + im[b] * s;
+                    ti = im[b] * c - re[b] * s;
+                }
+                const double ar = re[a], ai = im[a];
+                re[a] = ar + tr;
+                im[a] = ai + ti;
+                re[b] = ar - tr;
+                im[b] = ai - ti;
+            }
+        }
+    }
+}
+
+// forward pass on a block: butterfly, then output m (at index brev(m)) times w1^m
+template <int PT, int R, int OFF>
+__device__ __forceinline__ void reg_fwd(double (&xr)[PT], double (&xi)[PT], double2 w1)
+{
+    dft_sub<PT, R, OFF>(xr, xi);
+    double cr = 1.0, ci = 0.0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+        const double nr = cr * w1.x - ci * w1.y;
+        ci = cr * w1.y + ci * w1.x;
+        cr = nr;
+        const int i = OFF + brev<R>(m);
+        const double tr = xr[i] * cr - xi[i] * ci;
+        xi[i] = xr[i] * ci + xi[i] * cr;
+        xr[i] = tr;
+    }
+}
+
+// inverse pass on a block: input m (natural index) times conj(w1^m), then the inverse butterfly
+// (swap . forward . swap); output m ends at index brev(m)
+template <int PT, int R, int OFF>
+__device__ __forceinline__ void reg_inv(double (&xr)[PT], double (&xi)[PT], double2 w1)
+{
+    double cr = 1.0, ci = 0.0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+        const double nr = cr * w1.x - ci * w1.y;
+        ci = cr * w1.y + ci * w1.x;
+        cr = nr;
+        const int i = OFF + m;
+        const double tr = xr[i] * cr + xi[i] * ci;
+        xi[i] = xi[i] * cr - xr[i] * ci;
+        xr[i] = tr;
+    }
+    dft_sub<PT, R, OFF>(xi, xr);
+}
+
+// ---- list walks ---------------------------------------------------------------------------------
+// MODE 0: time order (addresses computed), 1: plain lists, 2: run-coded lists.
+// Slot of entry u of this thread in a list of E entries per thread: every wave owns a contiguous
+// range of the list, a wave instruction covers 64 consecutive slots.
+template <int E>
+__device__ __forceinline__ int slot_of(int t, int u) { return 64 * (E * (t >> 6) + u) + (t & 63); }
+
+struct ListArgs {
+    const uint32_t *k;        // plain: addresses of this list
+    const uint16_t *q;        // plain / RC: positions of this list
+    const ListHdr *hdr;       // RC
+    const uint32_t *tab;      // RC: run table of this list in global memory
+};
+
+// RC: request the run table of a list (at most TPT words per thread)
+template <int TPT>
+__device__ __forceinline__ void tab_request(const ListArgs &la, int t, uint32_t nruns, uint32_t (&tv)[TPT])
+{
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) {
+        const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
+        tv[i] = la.tab[r < nruns ? r : 0u];
+    }
+}
+template <int TPT>
+__device__ __forceinline__ void tab_store(uint32_t *__restrict__ tab_lds, int t, int rmax,
+                                          const uint32_t (&tv)[TPT])
+{
+#pragma unroll
+    for (int i = 0; i < TPT; ++i)
+        if (t + i * kT < rmax) tab_lds[t + i * kT] = tv[i];
+}
+
+// RC: addresses of E entries from their 16-bit words (bit 15 = run start) and the run table in LDS
+template <int E>
+__device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_t *__restrict__ tab_lds,
+                                          int wbase, uint32_t nvalid, int t, uint32_t (&kk)[E])
+{
+    int rb = wbase;
+    // slot of entry u = s0 + 64 u; s0 passes through an empty asm statement so that the E slot
+    // numbers are recomputed here (one add each) instead of being kept live from list to list
+    uint32_t s0 = (uint32_t)slot_of<E>(t, 0);
+    asm volatile("" : "+v"(s0));
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const bool flag = (qq[u] & 0x8000u) != 0u;
+        const uint64_t mask = __ballot(flag);
+        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        int r = rb + below + (flag ? 1 : 0);
+        rb += __popcll(mask);
+        r = r < 0 ? 0 : r;
+        const uint32_t s = s0 + 64u * (uint32_t)u;
+        const uint32_t a = tab_lds[r] + s;           // read for every entry: no branch, no wait per entry
+        kk[u] = s < nvalid ? a : kInvalidSample;
+    }
+}
+
+// ---- the partner exchange and the spectrum product ------------------------------------------------
+// Z'[k] = alpha Z[k] + i beta conj(Z[N-k]):  re' = alpha re + beta pim,  im' = alpha im + beta pre.
+// Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3; its
+// partner is published at P3 index A_e(t) - m of the padded plane (see the header comment).
+template <int PT>
+__device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT], double *__restrict__ buf,
+                                               int t, const double2 *__restrict__ ab)
+{
+    double *__restrict__ wp = buf + reg_base<PT, 3>(t);
+    int A0, A1;
+    if (PT == 32) {
+        const int gen = 33 * (263 - t) + 31;
+        A0 = t >= 8 ? gen : (t == 0 ? 16 : 33 * (8 - t) + 15);
+        A1 = t >= 8 ? gen : 33 * (7 - t) + 47;
+    } else {
+        const int tp = t >= 16 ? 271 - t : 16 - t;
+        A0 = t == 0 ? 16 : 16 * tp + (tp >> 1) + 15;
+        A1 = A0;
+    }
+    const double *__restrict__ r0 = buf + A0;
+    const double *__restrict__ r1 = buf + A1;
+    const bool self0 = (t == 0);            // bin k = 0 (and N/2 through the formula) pairs with itself
+#pragma unroll
+    for (int m = 0; m < PT; ++m) wp[m] = zr[reg_slot<16>(m)];
+    __syncthreads();
+    double pr[PT];
+#pragma unroll
+    for (int m = 0; m < PT; ++m) {
+        const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
+        pr[m] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < PT; ++m) wp[m] = zi[reg_slot<16>(m)];
+    __syncthreads();
+    // (alpha, beta) and the partner's imaginary parts are streamed four bins at a time: the three
+    // arrays zr, zi, pr are the whole register budget of the 16-point variant
+#pragma unroll
+    for (int m0 = 0; m0 < PT; m0 += 4) {
+        double2 c[4];
+        double pim[4];
+        // (the pointer passes through an empty asm statement per chunk: the table loads have no
+        // other dependency and would all be hoisted in front of the exchange, 4 VGPRs per bin)
+        const double2 *abp = ab + m0;
+        asm volatile("" : "+v"(abp));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i;
+            const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
+            c[i] = abp[i];
+            pim[i] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i;
+            const int s = reg_slot<16>(m);
+            const double nr = c[i].x * zr[s] + c[i].y * pim[i];
+            const double ni = c[i].x * zi[s] + c[i].y * pr[m];
+            zr[s] = nr;
+            zi[s] = ni;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+}
+
+// MODE 0: time order; 1: plain lists; 2: run-coded lists.  TPT: run-table words per thread (RC).
+template <int PT, int MODE, int TPT>
+__global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
+    const WinDesc *__restrict__ wins, int nwin, const double2 *__restrict__ Wtw,
+    const double2 *Wtw_inv, const double2 *__restrict__ AB, const uint32_t *__restrict__ lst_k,
+    const uint16_t *__restrict__ lst_q, const ListHdr *__restrict__ hdrs,
+    const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v,
+    double *__restrict__ out)
+{
+    using G = Geo<PT>;
+    constexpr int N = G::N, H = PT / 2;
+    extern __shared__ double buf[];
+    uint32_t *__restrict__ tab_lds = reinterpret_cast<uint32_t *>(buf + G::LDSD);   // RC: 2 x rmax words
+    const int t = threadIdx.x;
+    const int per_xcd = (nwin + 7) / 8;
+    const int win = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (win >= nwin) return;
+    const WinDesc wd = wins[win];
+    const int64_t w0 = wd.start - kHalo;            // time of window position 0
+    const int wave = t >> 6;
+    OS_STAMP(0);
+
+    auto list_args = [&](int l) {
+        ListArgs la;
+        const int64_t e0 = (int64_t)win * G::PER + G::list_off(l);
+        la.k = lst_k ? lst_k + e0 : nullptr;
+        la.q = lst_q ? lst_q + e0 : nullptr;
+        la.hdr = hdrs ? hdrs + ((int64_t)win * G::NLIST + l) : nullptr;
+        la.tab = tabs ? tabs + ((int64_t)win * G::NLIST + l) * rmax : nullptr;
+        return la;
+    };
+
+    double zr[PT], zi[PT];
+    // ---- load the window, one half (N positions) at a time through the LDS buffer --------------
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double vv[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const int64_t ts = w0 + (int64_t)h * N + t + u * kT;
+                vv[u] = (ts >= wd.lo && ts < wd.hi) ? v[ts] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PT; ++u) buf[t + u * kT] = vv[u];
+            __syncthreads();
+            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double2 p = sp[256 * m];
+                zr[h * H + m] = p.x;
+                zi[h * H + m] = p.y;
+            }
+            __syncthreads();
+        }
+    } else {
+        const ListArgs l0 = list_args(0), l1 = list_args(1);
+        uint32_t qa[PT], qb[PT], ka[PT], kb[PT];
+        uint32_t ta[TPT], tb[TPT];
+        uint32_t nva = 0, nvb = 0;
+        int wba = -1, wbb = -1;
+        if constexpr (MODE == 2) {
+            nva = l0.hdr->nvalid;
+            nvb = l1.hdr->nvalid;
+            wba = l0.hdr->wbase[wave];
+            wbb = l1.hdr->wbase[wave];
+            tab_request<TPT>(l0, t, l0.hdr->nruns, ta);
+            tab_request<TPT>(l1, t, l1.hdr->nruns, tb);
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            qa[u] = l0.q[slot_of<PT>(t, u)];
+            if constexpr (MODE == 1) ka[u] = l0.k[slot_of<PT>(t, u)];
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            qb[u] = l1.q[slot_of<PT>(t, u)];
+            if constexpr (MODE == 1) kb[u] = l1.k[slot_of<PT>(t, u)];
+        }
+        if constexpr (MODE == 2) {
+            tab_store<TPT>(tab_lds, t, rmax, ta);
+            tab_store<TPT>(tab_lds + rmax, t, rmax, tb);
+            __syncthreads();
+            rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double vv[PT];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) vv[u] = v[ka[u] != kInvalidSample ? ka[u] : 0u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = ka[u] != kInvalidSample ? vv[u] : 0.0;
+        if constexpr (MODE == 2) rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) vv[u] = v[kb[u] != kInvalidSample ? kb[u] : 0u];
+        __syncthreads();
+        {
+            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double2 p = sp[256 * m];
+                zr[m] = p.x;
+                zi[m] = p.y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = kb[u] != kInvalidSample ? vv[u] : 0.0;
+        __syncthreads();
+        {
+            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double2 p = sp[256 * m];
+                zr[H + m] = p.x;
+                zi[H + m] = p.y;
+            }
+        }
+        __syncthreads();
+    }
+
+    OS_STAMP(1);
+    const double2 w_a = Wtw[t];                      // n = N:   exp(-2 pi i t / N)
+    const double2 w_b = Wtw[PT * (t & 15)];          // n = 256: exp(-2 pi i (t & 15) / 256)
+
+    // ---- forward: radix PT, radix 16, radix 16 ----
+    reg_fwd<PT, PT, 0>(zr, zi, w_a);
+    reg_exchange<PT, 1, 2, PT>(zr, buf, t);
+    reg_exchange<PT, 1, 2, PT>(zi, buf, t);
+    reg_fwd<PT, 16, 0>(zr, zi, w_b);
+    if constexpr (PT == 32) reg_fwd<PT, 16, 16>(zr, zi, w_b);
+    reg_exchange<PT, 2, 3, 16>(zr, buf, t);
+    reg_exchange<PT, 2, 3, 16>(zi, buf, t);
+    dft_sub<PT, 16, 0>(zr, zi);
+    if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi);
+    OS_STAMP(2);
+    // ---- pairing with bin N-k and the spectrum product ----
+    partner_filter<PT>(zr, zi, buf, t, AB + (int64_t)wd.blk * N + PT * t);
+    OS_STAMP(3);
+    // ---- inverse: radix 16 (decimation in time on the bit-reversed data), radix 16, radix PT ----
+    dit_sub<PT, 16, 0>(zi, zr);
+    if constexpr (PT == 32) dit_sub<PT, 16, 16>(zi, zr);
+    // the inverse passes read their twiddles again (through a second pointer to the same table,
+    // so that nothing of the forward passes stays live across the pairing step)
+    const double2 w_bi = Wtw_inv[PT * (t & 15)], w_ai = Wtw_inv[t];
+    reg_exchange<PT, 3, 2, 0>(zr, buf, t);
+    reg_exchange<PT, 3, 2, 0>(zi, buf, t);
+    reg_inv<PT, 16, 0>(zr, zi, w_bi);
+    if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
+    // The result list of round 0 is requested here, behind the middle inverse pass: its run table
+    // goes to LDS in front of the last exchange (whose barriers publish it), its 16-bit words are
+    // in registers by the end of the last pass.  The pointers pass through an empty asm statement:
+    // the loads have no other dependency and would otherwise be hoisted to the top of the kernel
+    // and spilled.
+    constexpr int ERq = G::RLEN / kT;
+    uint32_t qs[ERq], ks[ERq];
+    uint32_t ts_[TPT];
+    uint32_t nvs = 0;
+    int wbs = -1;
+    auto request_results = [&](int j) {
+        if constexpr (MODE != 0) {
+            ListArgs ls = list_args(2 + j);
+            asm volatile("" : "+v"(ls.q), "+v"(ls.k), "+v"(ls.hdr), "+v"(ls.tab));
+            if constexpr (MODE == 2) {
+                nvs = ls.hdr->nvalid;
+                wbs = ls.hdr->wbase[wave];
+                tab_request<TPT>(ls, t, ls.hdr->nruns, ts_);
+            }
+#pragma unroll
+            for (int u = 0; u < ERq; ++u) {
+                qs[u] = ls.q[slot_of<ERq>(t, u)];
+                if constexpr (MODE == 1) ks[u] = ls.k[slot_of<ERq>(t, u)];
+            }
+        }
+    };
+    request_results(0);
+    reg_exchange<PT, 2, 1, 16>(zr, buf, t);
+    if constexpr (MODE == 2) tab_store<TPT>(tab_lds, t, rmax, ts_);
+    reg_exchange<PT, 2, 1, 16>(zi, buf, t);
+    reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
+    // ---- store: y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4), RSLOTS slots a round --
+    OS_STAMP(4);
+    constexpr int ER = G::RLEN / kT;                 // result entries per thread and round
+#pragma unroll
+    for (int j = 0; j < G::RR; ++j) {
+        if (j > 0) {
+            __syncthreads();                         // the previous round's reads are done
+            request_results(j);
+            if constexpr (MODE == 2) {
+                tab_store<TPT>(tab_lds, t, rmax, ts_);
+                __syncthreads();
+            }
+        }
+        if constexpr (MODE == 2) rc_decode<ER>(qs, tab_lds, wbs, nvs, t, ks);
+        double2 *__restrict__ sp = reinterpret_cast<double2 *>(buf) + t;
+#pragma unroll
+        for (int mm = 0; mm < G::RSLOTS; ++mm) {
+            const int m = 4 + j * G::RSLOTS + mm;
+            sp[256 * mm] = make_double2(zr[brev<PT>(m)], zi[brev<PT>(m)]);
+        }
+        __syncthreads();
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < ER; ++u) {
+                const int e = t + u * kT;
+                const int64_t o = (int64_t)j * G::RLEN + e;
+                if (o < wd.len) out[wd.start + o] = buf[e];
+            }
+        } else {
+            double rv[ER];
+#pragma unroll
+            for (int u = 0; u < ER; ++u) rv[u] = buf[qs[u] & 0x7FFFu];
+#pragma unroll
+            for (int u = 0; u < ER; ++u)
+                if (ks[u] != kInvalidSample) out[ks[u]] = rv[u];
+        }
+    }
+    OS_STAMP(5);
+}
+
+// ---- plan-time kernels ----------------------------------------------------------------------------
+// entries of the lists of windows [w0, w0 + nw), PER per window, in the order they are stored:
+//   list 0 / 1: window positions [0, N) / [N, 2N)        -> value = position within the half
+//   list 2 (3): results [0, RLEN) ([RLEN, 2 RLEN))       -> value = position within the round
+// key = address in the tile order (0xFFFFFFFF: no sample); a segmented sort then orders every list
+// by address.
+template <int PT>
+__global__ __launch_bounds__(256) void k_real_keys(const WinDesc *__restrict__ wins, int64_t w0,
+                                                    int64_t nw, const uint32_t *__restrict__ idx,
+                                                    uint32_t *__restrict__ keys,
+                                                    uint16_t *__restrict__ vals)
+{
+    using G = Geo<PT>;
+    const int64_t total = nw * G::PER;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const int64_t p = g / G::PER;
+        const int e = (int)(g - p * G::PER);
+        const WinDesc wd = wins[w0 + p];
+        uint32_t k = kInvalidSample;
+        int val;
+        if (e < 2 * G::N) {
+            val = e & (G::N - 1);
+            const int64_t ts = wd.start - kHalo + e;
+            if (ts >= wd.lo && ts < wd.hi) k = idx[ts];
+        } else {
+            const int o = e - 2 * G::N;
+            val = o % G::RLEN;
+            if (o < wd.len) k = idx[wd.start + o];
+        }
+        keys[g] = k;
+        vals[g] = (uint16_t)val;
+    }
+}
+
+template <int PT>
+struct RealListOffset {
+    int end;
+    __host__ __device__ int operator()(int s) const
+    {
+        using G = Geo<PT>;
+        const int l = s % G::NLIST + end;
+        return (s / G::NLIST) * G::PER + (l == G::NLIST ? G::PER : G::list_off(l));
+    }
+};
+
+// run structure of one sorted list per workgroup: a run starts where the address is not the
+// previous address + 1.  PASS 0 counts the runs (for the table stride), PASS 1 writes the 16-bit
+// words (bit 15 = run start), the header and the run table delta[r] = address - slot.
+template <int PT, int PASS>
+__global__ __launch_bounds__(256) void k_real_rc(int64_t nlists, const uint32_t *__restrict__ lk,
+                                                  uint16_t *__restrict__ lq, ListHdr *__restrict__ hdrs,
+                                                  uint32_t *__restrict__ tabs, int rmax,
+                                                  uint32_t *__restrict__ max_runs)
+{
+    using G = Geo<PT>;
+    __shared__ int wsum[4];
+    __shared__ int csum[4];
+    const int64_t lid = blockIdx.x;
+    if (lid >= nlists) return;
+    const int l = (int)(lid % G::NLIST);
+    const int64_t win = lid / G::NLIST;
+    const int64_t e0 = win * G::PER + G::list_off(l);
+    const int len = G::list_len(l);
+    const int per = len / 256;                          // consecutive entries per thread
+    const int t = threadIdx.x;
+    const int s0 = t * per;
+    // flags and valid counts of this thread's entries
+    int nflag = 0, nval = 0;
+    uint32_t prev = s0 > 0 ? lk[e0 + s0 - 1] : kInvalidSample;
+    for (int i = 0; i < per; ++i) {
+        const uint32_t k = lk[e0 + s0 + i];
+        const bool valid = k != kInvalidSample;
+        const bool flag = valid && (s0 + i == 0 || k != prev + 1u);
+        nflag += flag ? 1 : 0;
+        nval += valid ? 1 : 0;
+        prev = k;
+    }
+    // block-wide exclusive scan of nflag (fixed order), total of nval
+    int incl = nflag, vincl = nval;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int a = __shfl_up(incl, off, 64), b = __shfl_up(vincl, off, 64);
+        if ((t & 63) >= off) { incl += a; vincl += b; }
+    }
+    if ((t & 63) == 63) { wsum[t >> 6] = incl; csum[t >> 6] = vincl; }
+    __syncthreads();
+    int base = 0, total = 0, vtotal = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < (t >> 6)) base += wsum[w];
+        total += wsum[w];
+        vtotal += csum[w];
+    }
+    const int excl = base + incl - nflag;
+    if (PASS == 0) {
+        if (t == 0) atomicMax(max_runs, (uint32_t)total);
+        return;
+    }
+    // second walk: write words and table entries
+    int r = excl - 1;
+    prev = s0 > 0 ? lk[e0 + s0 - 1] : kInvalidSample;
+    for (int i = 0; i < per; ++i) {
+        const int s = s0 + i;
+        const uint32_t k = lk[e0 + s];
+        const bool valid = k != kInvalidSample;
+        const bool flag = valid && (s == 0 || k != prev + 1u);
+        if (flag) {
+            ++r;
+            tabs[lid * rmax + r] = k - (uint32_t)s;
+        }
+        const uint16_t q = lq[e0 + s];
+        lq[e0 + s] = (uint16_t)((q & 0x7FFFu) | (flag ? 0x8000u : 0u));
+        prev = k;
+        // run index in front of each wave's first slot (waves own len / 4 consecutive slots)
+        if (s % (len / 4) == 0) hdrs[lid].wbase[s / (len / 4)] = flag ? r - 1 : r;
+    }
+    if (t == 0) {
+        hdrs[lid].nvalid = (uint32_t)vtotal;
+        hdrs[lid].nruns = (uint32_t)total;
+    }
+}
+
+// W[t] = exp(-2 pi i t / N)
+__global__ void k_real_twiddles(int N, double2 *__restrict__ W)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N) W[t] = make_double2(cospi(2.0 * t / N), -sinpi(2.0 * t / N));
+}
+
+// H[b][k] = a0 + 2 sum_{j>=1} a_j cos(2 pi j k / (2N)),  k = 0..N  (real, even: symmetric band)
+__global__ __launch_bounds__(256) void k_real_spectrum(int nb, int64_t lambda, int N,
+                                                        const double *__restrict__ bands,
+                                                        double *__restrict__ Hs)
+{
+    const int64_t total = (int64_t)nb * (N + 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / (N + 1);
+        const int64_t k = e - b * (N + 1);
+        const double *band = bands + b * lambda;
+        double acc = 0.0;
+        for (int64_t j = lambda - 1; j >= 1; --j) {
+            const int64_t m = (j * k) % (2 * (int64_t)N);
+            acc += band[j] * cospi((double)m / (double)N);
+        }
+        Hs[e] = band[0] + 2.0 * acc;
+    }
+}
+
+// AB[b][a] = (alpha_k, beta_k), a = d1 256 + d2 16 + d3 the P3 position holding k = d1 + PT d2 + 16 PT d3
+template <int PT>
+__global__ __launch_bounds__(256) void k_real_alpha_beta(int nb, const double *__restrict__ Hs,
+                                                          double2 *__restrict__ AB)
+{
+    constexpr int N = Geo<PT>::N;
+    const int64_t total = (int64_t)nb * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N;
+        const int a = (int)(e - b * N);
+        const int d1 = a / 256, d2 = (a / 16) % 16, d3 = a % 16;
+        const int k = d1 + PT * d2 + 16 * PT * d3;
+        const double *h = Hs + b * (N + 1);
+        const double hk = h[k], hp = h[N - k];          // H[k + N] = H[N - k]
+        const double S = 0.5 * (hk + hp), Dd = 0.5 * (hk - hp);
+        const double th = (double)k / (double)N;
+        AB[e] = make_double2((S - Dd * sinpi(th)) / (double)N, (Dd * cospi(th)) / (double)N);
+    }
+}
+
+}  // namespace
+
+namespace cm2 {
+
+struct RealOS {
+    int pt = 16;
+    int64_t nwin = 0;
+    int64_t nb = 0;
+    WinDesc *d_wins = nullptr;
+    double2 *d_AB = nullptr;
+    double2 *d_W = nullptr;
+    // lists of the tile-order path, built for one tile plan at a time
+    uint64_t list_plan = 0;
+    int list_mode = 0;                   // 1 plain, 2 run-coded
+    uint32_t *d_lst_k = nullptr;
+    uint16_t *d_lst_q = nullptr;
+    ListHdr *d_hdrs = nullptr;
+    uint32_t *d_tabs = nullptr;
+    int rmax = 0;
+    bool want_rc = true;                 // what the lists were asked to be when they were built
+    double list_bytes_per_window = 0.0;
+};
+
+static void real_free_lists(RealOS *f)
+{
+    void *ptrs[] = {f->d_lst_k, f->d_lst_q, f->d_hdrs, f->d_tabs};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    f->d_lst_k = nullptr;
+    f->d_lst_q = nullptr;
+    f->d_hdrs = nullptr;
+    f->d_tabs = nullptr;
+    f->list_plan = 0;
+    f->list_mode = 0;
+    f->rmax = 0;
+}
+
+void real_os_destroy(RealOS *f)
+{
+    if (!f) return;
+    real_free_lists(f);
+    void *ptrs[] = {f->d_wins, f->d_AB, f->d_W};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete f;
+}
+
+int64_t real_os_window(const RealOS *f) { return f ? 512 * (int64_t)f->pt : 0; }
+
+template <int PT>
+static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const std::vector<int64_t> &off,
+                       hipStream_t stream)
+{
+    using G = Geo<PT>;
+    const int64_t nb = (int64_t)off.size() - 1;
+    f->nb = nb;
+    std::vector<WinDesc> wins;
+    for (int64_t b = 0; b < nb; ++b)
+        for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += G::HOP) {
+            WinDesc wd;
+            wd.start = s0;
+            wd.len = off[b + 1] - s0 < G::HOP ? off[b + 1] - s0 : G::HOP;
+            wd.lo = off[b];
+            wd.hi = off[b + 1];
+            wd.blk = (int32_t)b;
+            wd.pad = 0;
+            wins.push_back(wd);
+        }
+    f->nwin = (int64_t)wins.size();
+    CM2_HIP(hipMalloc(&f->d_wins, sizeof(WinDesc) * (wins.size() ? wins.size() : 1)));
+    if (!wins.empty())
+        CM2_HIP(hipMemcpy(f->d_wins, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice));
+    CM2_HIP(hipMalloc(&f->d_AB, sizeof(double2) * (nb > 0 ? nb : 1) * G::N));
+    if (nb > 0) {
+        DevTemp<double> Hs;
+        CM2_HIP(Hs.alloc(nb * (G::N + 1)));
+        k_real_spectrum<<<grid_for(nb * (G::N + 1)), kBlock, 0, stream>>>((int)nb, lambda, G::N, d_bands, Hs);
+        CM2_LAUNCH_OK();
+        k_real_alpha_beta<PT><<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_AB);
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipStreamSynchronize(stream));
+    }
+    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * G::N));
+    k_real_twiddles<<<(G::N + 255) / 256, 256, 0, stream>>>(G::N, f->d_W);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
+                   const std::vector<int64_t> &off, hipStream_t stream)
+{
+    CM2_CHECK(out != nullptr, "real_os_create: out is NULL");
+    *out = nullptr;
+    CM2_CHECK(pt == 16 || pt == 32, "real_os_create: points per thread must be 16 or 32, got %d", pt);
+    CM2_CHECK(lambda >= 1 && lambda - 1 <= kHalo, "fused overlap-save supports lambda <= 2049, got %lld",
+              (long long)lambda);
+    RealOS *f = new RealOS();
+    f->pt = pt;
+    struct Guard { RealOS *f; ~Guard() { if (f) real_os_destroy(f); } } guard{f};
+    if (int rc = (pt == 16 ? real_create<16>(f, d_bands, lambda, off, stream)
+                           : real_create<32>(f, d_bands, lambda, off, stream)))
+        return rc;
+    guard.f = nullptr;
+    *out = f;
+    return 0;
+}
+
+template <int PT, int MODE, int TPT>
+static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream)
+{
+    using G = Geo<PT>;
+    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE == 2 ? sizeof(uint32_t) * 2 * (size_t)f->rmax : 0);
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<PT, MODE, TPT>, lds, granted));
+    if (f->nwin == 0) return 0;
+    const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
+    k_os_real<PT, MODE, TPT><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
+                                                        f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+template <int PT>
+static int real_launch(const RealOS *f, int mode, const double *d_v, double *d_out, hipStream_t stream)
+{
+    if (mode == 0) return real_launch_t<PT, 0, 1>(f, d_v, d_out, stream);
+    if (mode == 1) return real_launch_t<PT, 1, 1>(f, d_v, d_out, stream);
+    const int tpt = (f->rmax + kT - 1) / kT;
+    if (tpt <= 2) return real_launch_t<PT, 2, 2>(f, d_v, d_out, stream);
+    if (tpt <= 4) return real_launch_t<PT, 2, 4>(f, d_v, d_out, stream);
+    if (tpt <= 8) return real_launch_t<PT, 2, 8>(f, d_v, d_out, stream);
+    set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
+    return 2;
+}
+
+int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream)
+{
+    return f->pt == 16 ? real_launch<16>(f, 0, d_v, d_out, stream) : real_launch<32>(f, 0, d_v, d_out, stream);
+}
+
+template <int PT>
+static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, bool want_rc, hipStream_t stream)
+{
+    using G = Geo<PT>;
+    real_free_lists(f);
+    if (f->nwin == 0) {
+        f->list_plan = plan_id;
+        f->list_mode = 1;
+        return 0;
+    }
+    const int64_t total = f->nwin * G::PER;
+    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
+    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
+    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    int64_t chunk_w = ((int64_t)1 << 30) / G::PER;             // hipCUB counts items in int
+    if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS"))      // test hook: force several chunks
+        if (atoll(e) > 0 && atoll(e) < chunk_w) chunk_w = atoll(e);
+    const int64_t cw_max = f->nwin < chunk_w ? f->nwin : chunk_w;
+    {
+        DevTemp<uint32_t> keys_in;
+        DevTemp<uint16_t> vals_in;
+        DevTemp<char> d_temp;
+        CM2_HIP(keys_in.alloc(cw_max * G::PER));
+        CM2_HIP(vals_in.alloc(cw_max * G::PER));
+        hipcub::CountingInputIterator<int> seg_id(0);
+        using OffsetIt = hipcub::TransformInputIterator<int, RealListOffset<PT>, hipcub::CountingInputIterator<int>>;
+        OffsetIt seg_begin(seg_id, RealListOffset<PT>{0}), seg_end(seg_id, RealListOffset<PT>{1});
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
+            nullptr, tb, keys_in.p, f->d_lst_k, vals_in.p, f->d_lst_q, (int)(cw_max * G::PER),
+            (int)(G::NLIST * cw_max), seg_begin, seg_end, 0, 32, stream));
+        CM2_HIP(d_temp.alloc(tb + 16));
+        for (int64_t p0 = 0; p0 < f->nwin; p0 += chunk_w) {
+            const int64_t nw = f->nwin - p0 < chunk_w ? f->nwin - p0 : chunk_w;
+            k_real_keys<PT><<<grid_for(nw * G::PER), kBlock, 0, stream>>>(f->d_wins, p0, nw, d_idx, keys_in, vals_in);
+            CM2_LAUNCH_OK();
+            size_t tbc = tb;
+            CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
+                d_temp.p, tbc, keys_in.p, f->d_lst_k + p0 * G::PER, vals_in.p, f->d_lst_q + p0 * G::PER,
+                (int)(nw * G::PER), (int)(G::NLIST * nw), seg_begin, seg_end, 0, 32, stream));
+        }
+        CM2_HIP(hipStreamSynchronize(stream));
+    }
+    f->list_mode = 1;
+    f->list_bytes_per_window = 6.0 * G::PER;
+    if (want_rc) {
+        const int64_t nlists = f->nwin * G::NLIST;
+        CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
+        DevTemp<uint32_t> d_max;
+        CM2_HIP(d_max.alloc(1));
+        CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
+        k_real_rc<PT, 0><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, nullptr, nullptr, 0, d_max);
+        CM2_LAUNCH_OK();
+        uint32_t h_max = 0;
+        CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        int rmax = (int)((h_max + 63) / 64 * 64);
+        if (rmax < 64) rmax = 64;
+        // the two window-half tables live in LDS beside the exchange buffer: keep the kernel at its
+        // occupancy (PT = 16: 40 KB per workgroup) when they fit, run-coded lists only up to 8 words
+        // per thread
+        if (rmax <= 8 * kT) {
+            CM2_HIP(hipMalloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
+            CM2_HIP(hipMalloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+            CM2_HIP(hipMemsetAsync(f->d_hdrs, 0, sizeof(ListHdr) * nlists, stream));
+            k_real_rc<PT, 1><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, f->d_hdrs,
+                                                                   f->d_tabs, rmax, nullptr);
+            CM2_LAUNCH_OK();
+            CM2_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(f->d_lst_k);                      // the addresses are now in the run tables
+            f->d_lst_k = nullptr;
+            f->rmax = rmax;
+            f->list_mode = 2;
+            f->list_bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
+        }
+    }
+    guard.f = nullptr;
+    f->list_plan = plan_id;
+    return 0;
+}
+
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, bool want_rc,
+                          const double *d_v, double *d_out, hipStream_t stream)
+{
+    if (f->list_plan != plan_id || f->list_mode == 0 || f->want_rc != want_rc) {
+        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, plan_id, want_rc, stream)
+                                  : real_build_lists<32>(f, d_idx, plan_id, want_rc, stream)))
+            return rc;
+        f->want_rc = want_rc;          // (a plan whose run tables do not fit stays on plain lists)
+    }
+    return f->pt == 16 ? real_launch<16>(f, f->list_mode, d_v, d_out, stream)
+                       : real_launch<32>(f, f->list_mode, d_v, d_out, stream);
+}
+
+// HBM bytes per output sample the tile-order kernel is built to move (lists + gathers + results)
+double real_os_tile_bytes_per_sample(const RealOS *f)
+{
+    if (!f) return 0.0;
+    const double hop = 512.0 * f->pt - 2.0 * kHalo, win = 512.0 * f->pt;
+    const double lists = f->list_bytes_per_window > 0 ? f->list_bytes_per_window : 6.0 * (win + hop);
+    return (lists + 8.0 * win + 8.0 * hop) / hop;
+}
+
+int real_os_list_mode(const RealOS *f) { return f ? f->list_mode : 0; }
+
+#ifdef CM2_OS_STAMPS
+extern "C" int cm2_os_debug_stamps(unsigned long long *d_buf)
+{
+    CM2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_os_stamps), &d_buf, sizeof(d_buf)));
+    return 0;
+}
+#endif
+
+}  // namespace cm2

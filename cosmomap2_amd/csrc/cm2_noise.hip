@@ -402,6 +402,17 @@ extern "C" int cm2_noise_info(const cm2_noise *n, int64_t *h_info)
     return 0;
 }
 
+extern "C" int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample)
+{
+    CM2_CHECK(n && h_info && h_bytes_per_sample, "cm2_noise_tile_kernel_info: NULL argument");
+    int kernel[2] = {0, 0};
+    *h_bytes_per_sample = cm2::fused_os_tile_info(n->fused, kernel);
+    h_info[0] = kernel[0];
+    h_info[1] = kernel[1];
+    h_info[2] = kernel[0] ? 512 * (int64_t)kernel[0] : 12288;
+    return 0;
+}
+
 extern "C" int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream_)
 {
     CM2_CHECK(n && d_w, "cm2_noise_expand_diag: NULL argument");

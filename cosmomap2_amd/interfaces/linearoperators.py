@@ -568,6 +568,16 @@ class BlockLO(blk.BlockDiagonalLinearOperator):
         return dict(nt=info[0], nblocks=info[1], lam=info[2], method=info[3], fft_len=info[4],
                     tiles_ok=bool(info[5]))
 
+    def tile_kernel_info(self):
+        """Overlap-save kernel of the tile-order application: points per thread (0 = segment-pair
+        kernel), list format, window length, designed HBM bytes per sample."""
+        info = (ctypes.c_int64 * 3)()
+        bps = ctypes.c_double(0.0)
+        _hip.call("cm2_noise_tile_kernel_info", self._noise.h, info, ctypes.byref(bps))
+        return dict(os_kernel=("pair" if info[0] == 0 else "real%d" % info[0]),
+                    os_lists={0: "not built", 1: "plain", 2: "run-coded"}[int(info[1])],
+                    os_window=int(info[2]), tile_bytes_per_sample=round(float(bps.value), 2))
+
     def _apply_all(self, v):
         return _noise_apply(self._noise, self._nt, v)
 

@@ -133,10 +133,9 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
     dot_into(rr, r, r)
     post_rr()
 
-    p = None
-    cur = 0
-    for iteration in range(int(maxiter)):
-        # queued ahead of the stop test: nothing here writes x or r
+    def ahead():
+        """z = M r, rho, p, q = A p, p.q of iteration `iteration` (nothing here writes x or r)."""
+        nonlocal p
         z = _apply(M, r) if M is not None else r
         dot_into(rho[cur], r, z)
         if iteration > 0:
@@ -146,8 +145,27 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
             p = z.clone()
         q = _apply(A, p)
         dot_into(pq, p, q)
-        if math.sqrt(wait_rr()) < atol:             # ||r|| of the state before this iteration
+        return q
+
+    # Running ahead costs one iteration's worth of GPU time when the stop test then says
+    # "converged" (the queued kernels cannot be recalled), so it is skipped when the two last
+    # residuals known to the host predict convergence at this test (geometric extrapolation, with a
+    # factor 10 in the norm to spare): that iteration waits first, as a plain loop would.  The
+    # prediction only chooses between two orders of the same operations; results never depend on it.
+    p = None
+    cur = 0
+    known = []                                       # ||r||^2 values the host has seen
+    for iteration in range(int(maxiter)):
+        predicted = known[-1] * (known[-1] / known[-2]) if len(known) >= 2 and known[-2] > 0 \
+            else (known[-1] if known else float("inf"))
+        run_ahead = not (predicted <= 100.0 * atol * atol)
+        q = ahead() if run_ahead else None
+        rr_host = wait_rr()                          # ||r||^2 of the state before this iteration
+        known.append(rr_host)
+        if math.sqrt(rr_host) < atol:
             return (D.to_host(x) if host_io else x), 0
+        if q is None:
+            q = ahead()
         _hip.check(lib.cm2_pcg_update_xr(n, D.ptr(rho[cur]), D.ptr(pq), D.ptr(p), D.ptr(q),
                                          D.ptr(x), D.ptr(r), D.ptr(rr), D.ptr(work), st()))
         cur = 1 - cur

@@ -164,6 +164,14 @@ int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
  * an AUTO operator that applies the direct sum on the time order still runs the fused
  * overlap-save kernel on a tile order) */
 int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
+/* Which overlap-save kernel cm2_noise_apply_tiles runs for this operator (none of this exists in
+ * the reference, whose ToeplitzLO.mult is a NumPy loop, interfaces/linearoperators.py:582-595):
+ * h_info[0] = points per thread of the one-real-window kernel (16 or 32; 0 = the segment-pair
+ * kernel), h_info[1] = list format (1 plain, 2 run-coded, 0 = lists not built yet), h_info[2] =
+ * window length in samples; *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to
+ * move (lists + gathered windows + results).  Environment switches read at every application:
+ * CM2_OS_KERNEL = real16 (default) | real32 | pair, CM2_OS_LISTS = rc (default) | plain. */
+int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample);
 
 /* ------------------------------------------------------------------------- *
  * a6-a7  ProcessTimeSamples  (utilities/process_ces.py:58-555)
