@@ -385,10 +385,15 @@ def main():
                 28.0 * nt + map_bytes / 2, (2.0 + ang + 8.0) * nv + map_bytes / 2)
             if args.toeplitz == "fused":
                 v_tb = D.empty(T.nvalid)
-                os_designed = float(N.noise_info().get("tile_bytes_per_sample", 35.0)) * nv
-                stages["N^-1 on tile order (k_overlap_save_reg, register+LDS FFT)"] = (ev_time(lambda: call(
-                    "cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st()),
-                    reps), 16.0 * nt, os_designed)
+                os_ms = ev_time(lambda: call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb),
+                                             D.ptr(v_tb), st()), reps)
+                kinfo = N.tile_kernel_info()               # which kernel ran, its list format
+                tile_info["overlap_save"] = kinfo
+                os_name = ("k_overlap_save_reg, segment pairs" if kinfo["os_kernel"] == "pair" else
+                           "k_os_real<%s>, one real window of %d samples per workgroup, %s lists"
+                           % (kinfo["os_kernel"][4:], kinfo["os_window"], kinfo["os_lists"]))
+                stages["N^-1 on tile order (%s)" % os_name] = (
+                    os_ms, 16.0 * nt, float(kinfo["tile_bytes_per_sample"]) * nv)
                 del v_tb
             else:
                 stages["tiles->time (k_tiles_to_time)"] = (ev_time(lambda: call(
@@ -444,8 +449,15 @@ def main():
     stage_report = {}
     for k, v in stages.items():
         ms = v[0][0]
-        rec = {"ms": round(ms, 4), "bytes_survey": v[1],
-               "GB/s_survey": round(v[1] / (ms * 1e-3) / 1e9, 1)}
+        rec = {"ms": round(ms, 4), "bytes_survey": v[1]}
+        if v[2] is None or v[2] >= v[1]:
+            # a rate on SURVEY's algorithmic bytes is only a bandwidth when the kernel moves at
+            # least that much: k_P_tiles / k_Pt_tiles are built to move fewer bytes than SURVEY
+            # counts (half-angle storage), and bytes_survey / time there is a throughput figure
+            # that can exceed the HBM peak -- it is reported as samples/s only
+            rec["GB/s_survey"] = round(v[1] / (ms * 1e-3) / 1e9, 1)
+        else:
+            rec["samples_per_s"] = round(nt / (ms * 1e-3), 1)
         if v[2] is not None:
             rec["bytes_designed"] = v[2]
             rec["GB/s_designed"] = round(v[2] / (ms * 1e-3) / 1e9, 1)

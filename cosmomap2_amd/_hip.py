@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcosmomap2_hip.so")
+# CM2_LIB_PATH: load another build of the same library (kernel experiments: several builds of one
+# source with different -D switches, timed in one process each)
+LIB_PATH = os.environ.get("CM2_LIB_PATH") or os.path.join(_HERE, "libcosmomap2_hip.so")
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

@@ -557,7 +557,7 @@ struct FusedOS {
 // time-order applications; CM2_OS_LISTS = rc | plain the list format of the real-window kernel.
 static void os_choice(int *pt, bool *rc)
 {
-    *pt = 16;
+    *pt = 32;               // fastest on MI355X (profiles/r03_os_variants.md)
     *rc = true;
     if (const char *e = getenv("CM2_OS_KERNEL")) {
         if (!strcmp(e, "pair")) *pt = 0;

@@ -52,6 +52,39 @@ __host__ __device__ constexpr int brev(int m)
     return out;
 }
 
+// Experiment switches (compile time; the defaults are what measured fastest, profiles/r03_os_*):
+//   CM2_OS_AB_BATCH32 : (alpha, beta) bins per batch of the 32-point variant; the first batch is
+//                       requested in front of the last forward pass when CM2_OS_AB_EARLY
+//   CM2_OS_LOAD2      : both window halves' gathers in flight together (two dependent round trips
+//                       instead of three, 2 x PT more live values)
+//   CM2_OS_RES_BOTH   : both result rounds' lists requested in front of the last exchange
+#ifndef CM2_OS_AB_BATCH32
+#define CM2_OS_AB_BATCH32 4
+#endif
+#ifndef CM2_OS_AB_EARLY
+#define CM2_OS_AB_EARLY 0
+#endif
+#ifndef CM2_OS_LOAD2
+#define CM2_OS_LOAD2 0
+#endif
+#ifndef CM2_OS_RES_BOTH
+#define CM2_OS_RES_BOTH 0
+#endif
+//   CM2_OS_NT_STORE / CM2_OS_NT_LIST / CM2_OS_NT_GATHER : non-temporal result stores / list loads /
+//                       sample gathers
+#ifndef CM2_OS_NT_STORE
+#define CM2_OS_NT_STORE 0
+#endif
+#ifndef CM2_OS_NT_LIST
+#define CM2_OS_NT_LIST 1
+#endif
+#ifndef CM2_OS_NT_GATHER
+#define CM2_OS_NT_GATHER 0
+#endif
+template <class T> __device__ __forceinline__ T ld_list(const T *p) { return CM2_OS_NT_LIST ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double ld_gather(const double *p) { return CM2_OS_NT_GATHER ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_result(double *p, double x) { if (CM2_OS_NT_STORE) __builtin_nontemporal_store(x, p); else *p = x; }
+
 constexpr int kT = 256;           // threads per workgroup
 constexpr int kHalo = 2048;       // window halo on both sides (>= lambda - 1)
 
@@ -71,15 +104,25 @@ struct Geo {
     __host__ __device__ static constexpr int list_len(int l) { return l < 2 ? N : RLEN; }
 };
 
-// Diagnostic build only (-DCM2_OS_STAMPS, never in the shipped library): thread 0 of every workgroup
-// records s_memtime at the phase boundaries into a buffer of 8 words per window.
+// Diagnostic build only (-DCM2_OS_STAMPS, never in the shipped library): every workgroup records
+// s_memtime at its phase boundaries into a buffer of 8 words per window (profiles/scripts/
+// os_stamps.py).  Every lane stores: a branch at a phase boundary splits the kernel's one basic
+// block and costs the register allocator 70-150 spilled VGPRs, which would time a different kernel.
 #ifdef CM2_OS_STAMPS
-__device__ unsigned long long *g_os_stamps = nullptr;
-#define OS_STAMP(i)                                                                         \
-    do {                                                                                    \
-        if (g_os_stamps && threadIdx.x == 0) g_os_stamps[(int64_t)win * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
+static unsigned long long *g_os_stamps_host = nullptr;      // set by cm2_os_debug_stamps
+static unsigned long long *os_stamp_buf()                   // never NULL: a dummy when none is wanted
+{
+    static unsigned long long *dummy = nullptr;
+    if (g_os_stamps_host) return g_os_stamps_host;
+    if (!dummy && hipMalloc(&dummy, sizeof(unsigned long long) * 8 * (1 << 20)) != hipSuccess) abort();
+    return dummy;
+}
+#define OS_STAMP_PARAM , unsigned long long *__restrict__ stamps
+#define OS_STAMP_ARG , os_stamp_buf()
+#define OS_STAMP(i) (stamps[(int64_t)win * 8 + (i)] = __builtin_amdgcn_s_memtime())
 #else
+#define OS_STAMP_PARAM
+#define OS_STAMP_ARG
 #define OS_STAMP(i) do { } while (0)
 #endif
 
@@ -298,9 +341,25 @@ __device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_
 // Z'[k] = alpha Z[k] + i beta conj(Z[N-k]):  re' = alpha re + beta pim,  im' = alpha im + beta pre.
 // Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3; its
 // partner is published at P3 index A_e(t) - m of the padded plane (see the header comment).
-template <int PT>
+// (alpha, beta) reach the registers in batches of BA bins, one batch after the other (the table
+// loads are L2 hits that take a microsecond on a chip busy with gathers); with CM2_OS_AB_EARLY the
+// first batch is requested by the caller in front of the last forward pass.
+template <int PT> struct PairBatch { static constexpr int BA = PT == 32 ? CM2_OS_AB_BATCH32 : 4; };
+
+template <int PT, int BA>
+__device__ __forceinline__ void ab_request(const double2 *ab, int m0, double2 (&c)[BA])
+{
+    // the pointer passes through an empty asm statement: the loads have no other dependency and
+    // would otherwise all be hoisted to one place (4 VGPRs per bin)
+    const double2 *abp = ab + m0 * kT;
+    asm volatile("" : "+v"(abp));
+#pragma unroll
+    for (int i = 0; i < BA; ++i) c[i] = abp[i * kT];
+}
+
+template <int PT, int BA>
 __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT], double *__restrict__ buf,
-                                               int t, const double2 *__restrict__ ab)
+                                               int t, const double2 *__restrict__ ab, double2 (&c)[BA])
 {
     double *__restrict__ wp = buf + reg_base<PT, 3>(t);
     int A0, A1;
@@ -329,31 +388,27 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
 #pragma unroll
     for (int m = 0; m < PT; ++m) wp[m] = zi[reg_slot<16>(m)];
     __syncthreads();
-    // (alpha, beta) and the partner's imaginary parts are streamed four bins at a time: the three
-    // arrays zr, zi, pr are the whole register budget of the 16-point variant
 #pragma unroll
-    for (int m0 = 0; m0 < PT; m0 += 4) {
-        double2 c[4];
-        double pim[4];
-        // (the pointer passes through an empty asm statement per chunk: the table loads have no
-        // other dependency and would all be hoisted in front of the exchange, 4 VGPRs per bin)
-        const double2 *abp = ab + m0;
-        asm volatile("" : "+v"(abp));
+    for (int m0 = 0; m0 < PT; m0 += BA) {
+        if (m0 > 0 || !CM2_OS_AB_EARLY) ab_request<PT, BA>(ab, m0, c);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i;
-            const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
-            c[i] = abp[i];
-            pim[i] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
-        }
+        for (int i0 = 0; i0 < BA; i0 += 4) {
+            double pim[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + i;
-            const int s = reg_slot<16>(m);
-            const double nr = c[i].x * zr[s] + c[i].y * pim[i];
-            const double ni = c[i].x * zi[s] + c[i].y * pr[m];
-            zr[s] = nr;
-            zi[s] = ni;
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i0 + i;
+                const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
+                pim[i] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i0 + i;
+                const int s = reg_slot<16>(m);
+                const double nr = c[i0 + i].x * zr[s] + c[i0 + i].y * pim[i];
+                const double ni = c[i0 + i].x * zi[s] + c[i0 + i].y * pr[m];
+                zr[s] = nr;
+                zi[s] = ni;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -367,7 +422,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const double2 *Wtw_inv, const double2 *__restrict__ AB, const uint32_t *__restrict__ lst_k,
     const uint16_t *__restrict__ lst_q, const ListHdr *__restrict__ hdrs,
     const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v,
-    double *__restrict__ out)
+    double *__restrict__ out OS_STAMP_PARAM)
 {
     using G = Geo<PT>;
     constexpr int N = G::N, H = PT / 2;
@@ -416,6 +471,95 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             __syncthreads();
         }
     } else {
+#if CM2_OS_LOAD2
+        // Both halves' lists are requested together and both halves' gathers are in flight
+        // together: two dependent round trips (lists, samples), not three.  After its gather is
+        // issued an address is dead; whether an entry has a sample is kept in bit 15 of its word
+        // (plain lists: set by the list builder; run-coded: slot >= number of valid entries).
+        const ListArgs l0 = list_args(0), l1 = list_args(1);
+        uint32_t qa[PT], qb[PT];
+        double va[PT], vb[PT];
+        uint32_t ta[TPT], tb[TPT];
+        uint32_t nva = 0, nvb = 0;
+        int wba = -1, wbb = -1;
+        if constexpr (MODE == 2) {
+            nva = l0.hdr->nvalid;
+            nvb = l1.hdr->nvalid;
+            wba = l0.hdr->wbase[wave];
+            wbb = l1.hdr->wbase[wave];
+            tab_request<TPT>(l0, t, l0.hdr->nruns, ta);
+            tab_request<TPT>(l1, t, l1.hdr->nruns, tb);
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) qa[u] = ld_list(l0.q + slot_of<PT>(t, u));
+#pragma unroll
+        for (int u = 0; u < PT; ++u) qb[u] = ld_list(l1.q + slot_of<PT>(t, u));
+        if constexpr (MODE == 2) {
+            tab_store<TPT>(tab_lds, t, rmax, ta);
+            tab_store<TPT>(tab_lds + rmax, t, rmax, tb);
+            __syncthreads();
+        }
+        {
+            uint32_t ka[PT];
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int u = 0; u < PT; ++u) ka[u] = ld_list(l0.k + slot_of<PT>(t, u));
+            } else {
+                rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
+#pragma unroll
+                for (int u = 0; u < PT; ++u)
+                    qa[u] = (qa[u] & 0x7FFFu) | (ka[u] == kInvalidSample ? 0x8000u : 0u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) va[u] = ld_gather(v + ((qa[u] & 0x8000u) ? 0u : ka[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint32_t kb[PT];
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int u = 0; u < PT; ++u) kb[u] = ld_list(l1.k + slot_of<PT>(t, u));
+            } else {
+                rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
+#pragma unroll
+                for (int u = 0; u < PT; ++u)
+                    qb[u] = (qb[u] & 0x7FFFu) | (kb[u] == kInvalidSample ? 0x8000u : 0u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) vb[u] = ld_gather(v + ((qb[u] & 0x8000u) ? 0u : kb[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = (qa[u] & 0x8000u) ? 0.0 : va[u];
+        __syncthreads();
+        {
+            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double2 p = sp[256 * m];
+                zr[m] = p.x;
+                zi[m] = p.y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = (qb[u] & 0x8000u) ? 0.0 : vb[u];
+        __syncthreads();
+        {
+            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double2 p = sp[256 * m];
+                zr[H + m] = p.x;
+                zi[H + m] = p.y;
+            }
+        }
+        __syncthreads();
+    }
+
+#else
         const ListArgs l0 = list_args(0), l1 = list_args(1);
         uint32_t qa[PT], qb[PT], ka[PT], kb[PT];
         uint32_t ta[TPT], tb[TPT];
@@ -431,13 +575,13 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         }
 #pragma unroll
         for (int u = 0; u < PT; ++u) {
-            qa[u] = l0.q[slot_of<PT>(t, u)];
-            if constexpr (MODE == 1) ka[u] = l0.k[slot_of<PT>(t, u)];
+            qa[u] = ld_list(l0.q + slot_of<PT>(t, u));
+            if constexpr (MODE == 1) ka[u] = ld_list(l0.k + slot_of<PT>(t, u));
         }
 #pragma unroll
         for (int u = 0; u < PT; ++u) {
-            qb[u] = l1.q[slot_of<PT>(t, u)];
-            if constexpr (MODE == 1) kb[u] = l1.k[slot_of<PT>(t, u)];
+            qb[u] = ld_list(l1.q + slot_of<PT>(t, u));
+            if constexpr (MODE == 1) kb[u] = ld_list(l1.k + slot_of<PT>(t, u));
         }
         if constexpr (MODE == 2) {
             tab_store<TPT>(tab_lds, t, rmax, ta);
@@ -448,14 +592,14 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         __builtin_amdgcn_sched_barrier(0);
         double vv[PT];
 #pragma unroll
-        for (int u = 0; u < PT; ++u) vv[u] = v[ka[u] != kInvalidSample ? ka[u] : 0u];
+        for (int u = 0; u < PT; ++u) vv[u] = ld_gather(v + (ka[u] != kInvalidSample ? ka[u] : 0u));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = ka[u] != kInvalidSample ? vv[u] : 0.0;
         if constexpr (MODE == 2) rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PT; ++u) vv[u] = v[kb[u] != kInvalidSample ? kb[u] : 0u];
+        for (int u = 0; u < PT; ++u) vv[u] = ld_gather(v + (kb[u] != kInvalidSample ? kb[u] : 0u));
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
@@ -482,6 +626,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         __syncthreads();
     }
 
+#endif
     OS_STAMP(1);
     const double2 w_a = Wtw[t];                      // n = N:   exp(-2 pi i t / N)
     const double2 w_b = Wtw[PT * (t & 15)];          // n = 256: exp(-2 pi i (t & 15) / 256)
@@ -494,11 +639,15 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     if constexpr (PT == 32) reg_fwd<PT, 16, 16>(zr, zi, w_b);
     reg_exchange<PT, 2, 3, 16>(zr, buf, t);
     reg_exchange<PT, 2, 3, 16>(zi, buf, t);
+    constexpr int BA = PairBatch<PT>::BA;
+    const double2 *ab = AB + (int64_t)wd.blk * N + t;
+    double2 cab[BA];
+    if (CM2_OS_AB_EARLY) ab_request<PT, BA>(ab, 0, cab);
     dft_sub<PT, 16, 0>(zr, zi);
     if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi);
     OS_STAMP(2);
     // ---- pairing with bin N-k and the spectrum product ----
-    partner_filter<PT>(zr, zi, buf, t, AB + (int64_t)wd.blk * N + PT * t);
+    partner_filter<PT, BA>(zr, zi, buf, t, ab, cab);
     OS_STAMP(3);
     // ---- inverse: radix 16 (decimation in time on the bit-reversed data), radix 16, radix PT ----
     dit_sub<PT, 16, 0>(zi, zr);
@@ -515,46 +664,62 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     // in registers by the end of the last pass.  The pointers pass through an empty asm statement:
     // the loads have no other dependency and would otherwise be hoisted to the top of the kernel
     // and spilled.
-    constexpr int ERq = G::RLEN / kT;
-    uint32_t qs[ERq], ks[ERq];
-    uint32_t ts_[TPT];
-    uint32_t nvs = 0;
-    int wbs = -1;
-    auto request_results = [&](int j) {
+    constexpr int ER = G::RLEN / kT;                 // result entries per thread and round
+    constexpr bool kBoth = CM2_OS_RES_BOTH && G::RR == 2 && MODE != 0;   // round 1 requested with round 0
+    uint32_t qs[ER], ks[ER], qs1[kBoth ? ER : 1], ks1[kBoth ? ER : 1];
+    uint32_t ts_[TPT], ts1[TPT];
+    uint32_t nvs = 0, nvs1 = 0;
+    int wbs = -1, wbs1 = -1;
+    auto request_results = [&](int j, auto &qq, auto &kq, uint32_t (&tq)[TPT], uint32_t &nv, int &wb) {
         if constexpr (MODE != 0) {
             ListArgs ls = list_args(2 + j);
             asm volatile("" : "+v"(ls.q), "+v"(ls.k), "+v"(ls.hdr), "+v"(ls.tab));
             if constexpr (MODE == 2) {
-                nvs = ls.hdr->nvalid;
-                wbs = ls.hdr->wbase[wave];
-                tab_request<TPT>(ls, t, ls.hdr->nruns, ts_);
+                nv = ls.hdr->nvalid;
+                wb = ls.hdr->wbase[wave];
+                tab_request<TPT>(ls, t, ls.hdr->nruns, tq);
             }
 #pragma unroll
-            for (int u = 0; u < ERq; ++u) {
-                qs[u] = ls.q[slot_of<ERq>(t, u)];
-                if constexpr (MODE == 1) ks[u] = ls.k[slot_of<ERq>(t, u)];
+            for (int u = 0; u < ER; ++u) {
+                qq[u] = ld_list(ls.q + slot_of<ER>(t, u));
+                if constexpr (MODE == 1) kq[u] = ld_list(ls.k + slot_of<ER>(t, u));
             }
         }
     };
-    request_results(0);
+    request_results(0, qs, ks, ts_, nvs, wbs);
+    if constexpr (kBoth) request_results(1, qs1, ks1, ts1, nvs1, wbs1);
     reg_exchange<PT, 2, 1, 16>(zr, buf, t);
-    if constexpr (MODE == 2) tab_store<TPT>(tab_lds, t, rmax, ts_);
+    if constexpr (MODE == 2) {
+        tab_store<TPT>(tab_lds, t, rmax, ts_);
+        if constexpr (kBoth) tab_store<TPT>(tab_lds + rmax, t, rmax, ts1);
+    }
     reg_exchange<PT, 2, 1, 16>(zi, buf, t);
     reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
     // ---- store: y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4), RSLOTS slots a round --
     OS_STAMP(4);
-    constexpr int ER = G::RLEN / kT;                 // result entries per thread and round
 #pragma unroll
     for (int j = 0; j < G::RR; ++j) {
+        const uint32_t *tabj = tab_lds;
         if (j > 0) {
             __syncthreads();                         // the previous round's reads are done
-            request_results(j);
-            if constexpr (MODE == 2) {
-                tab_store<TPT>(tab_lds, t, rmax, ts_);
-                __syncthreads();
+            if constexpr (kBoth) {
+#pragma unroll
+                for (int u = 0; u < ER; ++u) {
+                    qs[u] = qs1[u];
+                    if constexpr (MODE == 1) ks[u] = ks1[u];
+                }
+                nvs = nvs1;
+                wbs = wbs1;
+                tabj = tab_lds + rmax;
+            } else {
+                request_results(j, qs, ks, ts_, nvs, wbs);
+                if constexpr (MODE == 2) {
+                    tab_store<TPT>(tab_lds, t, rmax, ts_);
+                    __syncthreads();
+                }
             }
         }
-        if constexpr (MODE == 2) rc_decode<ER>(qs, tab_lds, wbs, nvs, t, ks);
+        if constexpr (MODE == 2) rc_decode<ER>(qs, tabj, wbs, nvs, t, ks);
         double2 *__restrict__ sp = reinterpret_cast<double2 *>(buf) + t;
 #pragma unroll
         for (int mm = 0; mm < G::RSLOTS; ++mm) {
@@ -575,7 +740,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             for (int u = 0; u < ER; ++u) rv[u] = buf[qs[u] & 0x7FFFu];
 #pragma unroll
             for (int u = 0; u < ER; ++u)
-                if (ks[u] != kInvalidSample) out[ks[u]] = rv[u];
+                if (ks[u] != kInvalidSample) st_result(out + ks[u], rv[u]);
         }
     }
     OS_STAMP(5);
@@ -612,7 +777,7 @@ __global__ __launch_bounds__(256) void k_real_keys(const WinDesc *__restrict__ w
             if (o < wd.len) k = idx[wd.start + o];
         }
         keys[g] = k;
-        vals[g] = (uint16_t)val;
+        vals[g] = (uint16_t)(val | (k == kInvalidSample ? 0x8000 : 0));   // bit 15: no sample
     }
 }
 
@@ -747,7 +912,11 @@ __global__ __launch_bounds__(256) void k_real_alpha_beta(int nb, const double *_
         const double hk = h[k], hp = h[N - k];          // H[k + N] = H[N - k]
         const double S = 0.5 * (hk + hp), Dd = 0.5 * (hk - hp);
         const double th = (double)k / (double)N;
-        AB[e] = make_double2((S - Dd * sinpi(th)) / (double)N, (Dd * cospi(th)) / (double)N);
+        // stored [m][t] (a = PT t + m): the 256 threads read bin m of all of them in one contiguous
+        // 4 KB piece -- [t][m] order made every lane of a load touch another cache line
+        const int t = a / PT, m = a % PT;
+        AB[b * N + (int64_t)m * kT + t] = make_double2((S - Dd * sinpi(th)) / (double)N,
+                                                        (Dd * cospi(th)) / (double)N);
     }
 }
 
@@ -869,7 +1038,7 @@ static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, hipS
     if (f->nwin == 0) return 0;
     const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_os_real<PT, MODE, TPT><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
-                                                        f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out);
+                                                        f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out OS_STAMP_ARG);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -1000,7 +1169,7 @@ int real_os_list_mode(const RealOS *f) { return f ? f->list_mode : 0; }
 #ifdef CM2_OS_STAMPS
 extern "C" int cm2_os_debug_stamps(unsigned long long *d_buf)
 {
-    CM2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_os_stamps), &d_buf, sizeof(d_buf)));
+    g_os_stamps_host = d_buf;
     return 0;
 }
 #endif

@@ -170,7 +170,7 @@ int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
  * kernel), h_info[1] = list format (1 plain, 2 run-coded, 0 = lists not built yet), h_info[2] =
  * window length in samples; *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to
  * move (lists + gathered windows + results).  Environment switches read at every application:
- * CM2_OS_KERNEL = real16 (default) | real32 | pair, CM2_OS_LISTS = rc (default) | plain. */
+ * CM2_OS_KERNEL = real32 (default) | real16 | pair, CM2_OS_LISTS = rc (default) | plain. */
 int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample);
 
 /* ------------------------------------------------------------------------- *

@@ -21,7 +21,7 @@ import os
 import shutil
 import sys
 
-HOT = ["k_P_tiles", "k_overlap_save", "k_Pt_tiles_fixed", "k_Pt_tiles<", "k_PtNP_sell", "k_P_time",
+HOT = ["k_P_tiles", "k_overlap_save", "k_os_real", "k_Pt_tiles_fixed", "k_Pt_tiles<", "k_PtNP_sell", "k_P_time",
        "k_Pt_sell", "k_Zt_partial_wide", "k_Z_axpy_wide", "k_Z_apply", "k_m2_finish_wide", "k_gemm_tn_mfma_pairs", "k_panel_gemm_mfma",
        "k_bdprecond", "k_dot_partial", "k_pcg_update_xr", "k_pcg_update_p"]
 
@@ -54,7 +54,7 @@ def main(src, tag):
     n = 3 * npix
     r = (bench.get("pcg") or {}).get("two_level", {}).get("rank", 32)
     zb = 8.0 * n * r
-    alg = {"k_P_tiles": 28.0 * nt + 24 * npix, "k_overlap_save": 16.0 * nt,
+    alg = {"k_P_tiles": 28.0 * nt + 24 * npix, "k_overlap_save": 16.0 * nt, "k_os_real": 16.0 * nt,
            "k_Pt_tiles_fixed": 28.0 * nt + 24 * npix, "k_Pt_tiles<": 28.0 * nt + 24 * npix,
            "k_PtNP_sell": 28.0 * nt + 48 * npix,
            "k_P_time": 28.0 * nt + 24 * npix, "k_Pt_sell": 28.0 * nt + 24 * npix,
