@@ -280,11 +280,11 @@ def main():
             t0 = time.time()
             L._sparse_tiles(P)
             sync()
-            tm["tile_plan"] = time.time() - t0
+            tm["tile_plan_and_fixed_order_PT_lists"] = time.time() - t0
             t0 = time.time()
-            A_local * x            # first application: FFT address lists, fixed-order P^T lists
+            A_local * x            # first application: the overlap-save kernel's address lists
             sync()
-            tm["first_matvec_fft_lists_and_PT_lists"] = time.time() - t0
+            tm["first_matvec_overlap_save_lists"] = time.time() - t0
         # The first ~20 matvecs after an idle period run ~3 % slower than the steady state (the
         # same 20-step loop measured again later in the process is faster by that much): part of
         # the setup is therefore 0.15 s of untimed matvecs, so that the W warm-up steps and the K

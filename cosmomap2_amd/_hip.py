@@ -26,6 +26,7 @@ PROTOTYPES = {
     "cm2_pointing_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _vp],
     "cm2_pointing_destroy": [_vp],
     "cm2_pointing_info": [_vp, ctypes.POINTER(_i64)],
+    "cm2_pointing_build_sell": [_vp, _vp],
     "cm2_P_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_apply": [_vp, _vp, _vp, _vp],
     "cm2_pointing_set_weights": [_vp, _vp, _vp],
@@ -36,6 +37,7 @@ PROTOTYPES = {
     "cm2_tiles_pixel_range": [_vp, _i64, _i64, ctypes.POINTER(_i64)],
     "cm2_tiles_group_tiles": [_vp, _int, ctypes.POINTER(_i64)],
     "cm2_tiles_set_pt_order": [_vp, _int],
+    "cm2_tiles_prepare_pt": [_vp, _vp],
     "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_i32_time_to_tiles": [_vp, _vp, _vp, _vp],

@@ -470,12 +470,21 @@ extern "C" int cm2_pointing_destroy(cm2_pointing *p)
     return 0;
 }
 
+extern "C" int cm2_pointing_build_sell(cm2_pointing *p, void *stream_)
+{
+    CM2_CHECK(p, "cm2_pointing_build_sell: NULL plan");
+    return ensure_sell(p, as_stream(stream_));
+}
+
 extern "C" int cm2_pointing_info(const cm2_pointing *p, int64_t *h_info)
 {
     CM2_CHECK(p && h_info, "cm2_pointing_info: NULL argument");
-    if (int rc = ensure_sell(p, nullptr)) return rc;      // reports the pixel-major plan's sizes
     h_info[0] = p->nt; h_info[1] = p->npix; h_info[2] = p->pol;
-    h_info[3] = p->nvalid; h_info[4] = p->sell_len; h_info[5] = p->nslices;
+    if (p->sell_built) {
+        h_info[3] = p->nvalid; h_info[4] = p->sell_len; h_info[5] = p->nslices;
+    } else {
+        h_info[3] = h_info[4] = h_info[5] = -1;           // pixel-major copy not built (builds nothing)
+    }
     return 0;
 }
 

@@ -40,6 +40,7 @@ struct cm2_tiles {
     // packed into groups of 4 list entries that hold whole runs (= samples of one pixel)
     int pt_fixed = 1;
     int fx_S = 0;
+    int fx_failed = 0;       // a build of the fixed-order lists failed: not retried on every apply
     std::vector<int64_t> tile_off;      // [ntiles+1] first TB position of every tile (host)
     int64_t *d_tile_off = nullptr;
     int64_t *d_fx_slice0 = nullptr;     // [ntiles+1] first slice of every tile

@@ -618,6 +618,13 @@ extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
     return 0;
 }
 
+extern "C" int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream_)
+{
+    CM2_CHECK(t, "cm2_tiles_prepare_pt: NULL plan");
+    bool fixed = false;
+    return cm2::fx_plan(t, as_stream(stream_), &fixed);
+}
+
 extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 {
     CM2_CHECK(t, "cm2_tiles_set_pt_order: NULL argument");

@@ -36,6 +36,8 @@
 //     thread and slice, and no dependent round trip).
 #include "cm2_tiles.h"
 
+#include <mutex>
+
 #include <hipcub/hipcub.hpp>
 
 using namespace cm2;
@@ -536,11 +538,24 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
     cm2_tiles *t = const_cast<cm2_tiles *>(tc);
     *use = false;
     if (!t->pt_fixed) return 0;
+    // The lists are normally built by cm2_tiles_prepare_pt right after the plan (the Python layer
+    // and the C demos call it): an application then allocates nothing and is safe to capture or
+    // to issue from several host threads.  A plan that was not prepared builds them here, under
+    // a lock (two threads applying P^T on one plan would otherwise both build).
+    static std::mutex build_lock;
+    std::lock_guard<std::mutex> hold(build_lock);
+    if (t->fx_failed) {
+        set_error("the fixed-order P^T lists of this tile plan could not be built (earlier error); "
+                  "cm2_tiles_set_pt_order(t, 0) selects the atomic form");
+        return 1;
+    }
+    struct FailMark { cm2_tiles *t; bool ok; ~FailMark() { if (!ok) { t->fx_failed = 1; t->fx_S = 0; } } } mark{t, false};
     if (t->fx_S == 0) {
         int smax = 4 * kFxT;                             // 4 staged values per thread at most
         while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
         if (fx_lds_bytes(t, smax) > 159 * 1024) {        // the tile alone fills LDS: atomics
             t->pt_fixed = 0;
+            mark.ok = true;
             return 0;
         }
         int forced = 0;
@@ -563,6 +578,7 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
             }
         }
     }
+    mark.ok = true;
     *use = true;
     return 0;
 }

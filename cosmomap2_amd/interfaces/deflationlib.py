@@ -28,6 +28,15 @@ def _norm(v):
     return math.sqrt(D.dot(v, v))
 
 
+def _own(out, inp):
+    """A matvec result that may be modified in place: operators return freshly allocated vectors
+    (the reference's convention, linearoperators.py:365, :390), so a copy is made only when the
+    result IS the input (identity-like operators hand their argument back)."""
+    if D.is_tensor(out) and D.is_tensor(inp) and out.data_ptr() == inp.data_ptr():
+        return out.clone()
+    return out
+
+
 def _transpose(mat):
     """Row-major (rows x cols) tensor in HBM -> its (cols x rows) transpose, by the tiled kernel."""
     rows, cols = int(mat.shape[0]), int(mat.shape[1])
@@ -84,7 +93,7 @@ def arnoldi(A, b, x0=None, tol=1e-5, maxiter=1000, inner_m=30):
     hs = []
     out = (lambda seq: [D.to_host(v) for v in seq]) if host_io else (lambda seq: seq)
     for j in range(1, 1 + inner_m):
-        v_new = _apply(A, vs[j - 1]).clone()
+        v_new = _own(_apply(A, vs[j - 1]), vs[j - 1])
         hcur = []
         for v in vs:                                   # :94-97
             alpha = D.dot(v, v_new)
@@ -235,7 +244,7 @@ def _arnoldi_M(A, x0d, M, nmax):
     k_done = 0
     hmax = 0.0                                         # largest |H| entry seen so far
     for k in range(nmax):
-        Av = _apply(A, Vb.vecs[k]).clone()
+        Av = _own(_apply(A, Vb.vecs[k]), Vb.vecs[k])
         h = Vb.dots(Av)                                # duals V: <v_j, Av> = <p_j, Av>_M
         Pb.subtract(Av, h)
         h2 = Vb.dots(Av)                               # second sweep on the corrected vector

@@ -132,6 +132,8 @@ class SparseLO(_DeviceOp):
         return self._angles.sin
 
     def plan_info(self):
+        """Sizes of the pixel-major plan (built here if no P^T has needed it yet)."""
+        _hip.call("cm2_pointing_build_sell", self._plan, D.stream())
         info = (ctypes.c_int64 * 6)()
         _hip.call("cm2_pointing_info", self._plan, info)
         return dict(nt=info[0], npix=info[1], pol=info[2], nvalid=info[3],
@@ -266,6 +268,8 @@ def _sparse_tiles(P, tile_pixels=None, slice_samples=None):
         _hip.call("cm2_tiles_create", ctypes.byref(h), D.ptr(P._d_pix), D.ptr(P._d_cos),
                   D.ptr(P._d_sin), P.nrows, P.ncols, int(P.pol), int(tile_pixels),
                   int(slice_samples), D.stream())
+        # the fixed-order P^T lists are built with the plan: applications then only launch kernels
+        _hip.call("cm2_tiles_prepare_pt", h, D.stream())
         P._tiles = _TileHandle(h)
     return P._tiles
 

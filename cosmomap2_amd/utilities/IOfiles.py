@@ -11,8 +11,10 @@ observed-pixel list (:258-275) and the map lists (:351-375).
 
 Container: HDF5 through :mod:`cosmomap2_amd.utilities.hdf5_lite`, a small pure-Python
 reader / writer of the HDF5 subset the reference's files use (h5py is not part of this
-image); the group and dataset names are the reference's, so files are interchangeable with
-the reference's h5py code.
+image); the group and dataset names are the reference's.  The reader is checked on the
+reference's own h5py-written files; the writer emits the same object-header messages, but its
+files have only been read back by this reader (neither h5py nor libhdf5 exists in this image),
+so "h5py opens them" is intended, not verified.
 """
 import os
 

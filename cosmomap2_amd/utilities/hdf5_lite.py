@@ -210,8 +210,10 @@ class _Reader(object):
             cls = self.d[p + 1]
             if cls == 0:
                 n = self.u16(p + 2)
+                if n < count * dt.itemsize:
+                    raise Hdf5FormatError("compact dataset holds %d bytes, its dataspace needs %d"
+                                          % (n, count * dt.itemsize))
                 raw = np.frombuffer(self.d, dtype=dt, count=count, offset=p + 4)
-                assert n >= count * dt.itemsize
             elif cls == 1:
                 addr = self.u64(p + 2)
                 if addr == _UNDEF:
@@ -372,7 +374,15 @@ class _Writer(object):
         grid = [-(-s // c) for s, c in zip(arr.shape, chunks)]
         nchunks = int(np.prod(grid))
         if nchunks > 64:
-            raise Hdf5FormatError("at most 64 chunks per dataset are written (one B-tree leaf)")
+            # one B-tree leaf indexes at most 64 chunks: coarser chunks along the first dimension
+            # until they fit (any chunk shape is a valid HDF5 file; readers see the same array)
+            chunks = list(chunks)
+            while int(np.prod([-(-s // c) for s, c in zip(arr.shape, chunks)])) > 64:
+                d = max(range(rank), key=lambda i: -(-arr.shape[i] // chunks[i]))
+                chunks[d] = min(arr.shape[d], 2 * chunks[d])
+            chunks = tuple(chunks)
+            grid = [-(-s // c) for s, c in zip(arr.shape, chunks)]
+            nchunks = int(np.prod(grid))
         esz = arr.dtype.itemsize
         csize = int(np.prod(chunks)) * esz
         keys = []

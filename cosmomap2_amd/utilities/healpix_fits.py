@@ -14,7 +14,7 @@ float32 columns of 1024 pixels per row named TEMPERATURE, Q_POLARISATION, U_POLA
 """
 import numpy as np
 
-__all__ = ["read_map", "write_map", "FitsFormatError"]
+__all__ = ["read_map", "write_map", "FitsFormatError", "nest2ring", "ring2nest", "reorder"]
 
 _BLOCK = 2880
 _TYPES = {"E": ">f4", "D": ">f8", "J": ">i4", "K": ">i8", "I": ">i2", "B": "u1", "L": "u1"}
@@ -22,6 +22,86 @@ _TYPES = {"E": ">f4", "D": ">f8", "J": ">i4", "K": ">i8", "I": ">i2", "B": "u1",
 
 class FitsFormatError(RuntimeError):
     pass
+
+
+# ------------------------------------------------------------ RING <-> NESTED ordering ------
+# Integer arithmetic of the HEALPix pixelisation (Gorski et al. 2005, ApJ 622, 759; what
+# hp.reorder / hp.read_map(nest=...) do for the reference): a NESTED index is
+# face * nside^2 + (bits of ix and iy interleaved); a RING index counts along iso-latitude rings.
+_JRLL = np.array([2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4], dtype=np.int64)   # ring of a face's north corner / nside
+_JPLL = np.array([1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7], dtype=np.int64)   # its longitude index, in units of pi/4
+
+
+def _check_nside(nside):
+    nside = int(nside)
+    if nside < 1 or nside & (nside - 1) or nside > (1 << 29):
+        raise ValueError("nside must be a power of two (NESTED ordering needs it), got %r" % nside)
+    return nside
+
+
+def _compact_bits(v):
+    """Every second bit of v (bits 0, 2, 4, ...) packed together."""
+    v = v & 0x5555555555555555
+    v = (v | (v >> 1)) & 0x3333333333333333
+    v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0F
+    v = (v | (v >> 4)) & 0x00FF00FF00FF00FF
+    v = (v | (v >> 8)) & 0x0000FFFF0000FFFF
+    v = (v | (v >> 16)) & 0x00000000FFFFFFFF
+    return v
+
+
+def nest2ring(nside, ipix):
+    """RING index of NESTED pixel(s) ``ipix`` (``hp.nest2ring``)."""
+    nside = _check_nside(nside)
+    ip = np.asarray(ipix, dtype=np.int64)
+    npix = 12 * nside * nside
+    if ip.size and (ip.min() < 0 or ip.max() >= npix):
+        raise ValueError("pixel index outside [0, %d)" % npix)
+    nl4, ncap = 4 * nside, 2 * nside * (nside - 1)
+    face = ip // (nside * nside)
+    ipf = ip % (nside * nside)
+    ix, iy = _compact_bits(ipf), _compact_bits(ipf >> 1)
+    jr = _JRLL[face] * nside - ix - iy - 1                   # ring, 1 .. 4 nside - 1
+    north, south = jr < nside, jr > 3 * nside
+    nr = np.where(north, jr, np.where(south, nl4 - jr, nside))
+    n_before = np.where(north, 2 * nr * (nr - 1),
+                        np.where(south, npix - 2 * (nr + 1) * nr, ncap + (jr - nside) * nl4))
+    kshift = np.where(north | south, 0, (jr - nside) & 1)
+    jp = (_JPLL[face] * nr + ix - iy + 1 + kshift) // 2
+    jp = np.where(jp > nl4, jp - nl4, np.where(jp < 1, jp + nl4, jp))
+    out = n_before + jp - 1
+    return out if out.ndim else int(out)
+
+
+def ring2nest(nside, ipix):
+    """NESTED index of RING pixel(s) ``ipix`` (``hp.ring2nest``), through the inverse of the
+    whole permutation (a table of 12 nside^2 entries)."""
+    nside = _check_nside(nside)
+    npix = 12 * nside * nside
+    inv = np.empty(npix, dtype=np.int64)
+    inv[nest2ring(nside, np.arange(npix, dtype=np.int64))] = np.arange(npix, dtype=np.int64)
+    ip = np.asarray(ipix, dtype=np.int64)
+    if ip.size and (ip.min() < 0 or ip.max() >= npix):
+        raise ValueError("pixel index outside [0, %d)" % npix)
+    out = inv[ip]
+    return out if out.ndim else int(out)
+
+
+def reorder(m, n2r=False, r2n=False):
+    """``hp.reorder``: a full-sky map in the other ordering (exactly one of n2r / r2n)."""
+    if bool(n2r) == bool(r2n):
+        raise ValueError("give exactly one of n2r=True (NESTED -> RING) or r2n=True")
+    m = np.asarray(m)
+    nside = int(round((m.shape[-1] / 12.0) ** 0.5))
+    if 12 * nside * nside != m.shape[-1]:
+        raise ValueError("map length %d is not 12 * nside**2" % m.shape[-1])
+    perm = nest2ring(nside, np.arange(m.shape[-1], dtype=np.int64))   # perm[nest] = ring
+    out = np.empty_like(m)
+    if n2r:
+        out[..., perm] = m
+    else:
+        out[...] = m[..., perm]
+    return out
 
 
 def _parse_header(data, pos):
@@ -69,8 +149,9 @@ def read_map(filename, field=0, dtype=np.float64, nest=False, h=False):
     """
     ``hp.read_map(filename, field=...)``: the map(s) of the first binary-table extension.
     ``field`` is a column index or a sequence of indices (``field=[0, 1, 2]`` for I, Q, U;
-    ``None`` for all).  ``nest=False`` asks for RING ordering, ``nest=True`` for NESTED,
-    ``nest=None`` takes the file's ordering; converting between the two is not provided.
+    ``None`` for all).  ``nest=False`` (healpy's default) returns RING ordering, ``nest=True``
+    NESTED, whatever the file's ORDERING keyword says (the map is reordered when they differ);
+    ``nest=None`` takes the file's ordering as it is.
     With ``h=True`` the header keywords are returned as the last element.
     """
     with open(filename, "rb") as f:
@@ -79,7 +160,7 @@ def read_map(filename, field=0, dtype=np.float64, nest=False, h=False):
         raise FitsFormatError("not a FITS file")
     try:
         return _read_map(data, field, dtype, nest, h)
-    except (FitsFormatError, NotImplementedError):
+    except FitsFormatError:
         raise
     except (KeyError, ValueError, IndexError, TypeError, OverflowError, MemoryError) as e:
         raise FitsFormatError("corrupt or truncated FITS file (%s: %s)" % (type(e).__name__, e))
@@ -110,9 +191,7 @@ def _read_map(data, field, dtype, nest, h):
     if off != width:
         raise FitsFormatError("column formats add up to %d bytes per row, NAXIS1 says %d" % (off, width))
     ordering = str(hdr.get("ORDERING", "RING")).strip().upper()
-    if nest is not None and (ordering == "NESTED") != bool(nest):
-        raise NotImplementedError("the file is in %s ordering; reordering is not provided "
-                                  "(pass nest=None to take the file's ordering)" % ordering)
+    convert = nest is not None and (ordering == "NESTED") != bool(nest)
     table = np.frombuffer(data, dtype=np.uint8, count=width * nrows, offset=pos).reshape(nrows, width)
     fields = range(nf) if field is None else ([field] if np.isscalar(field) else list(field))
     maps = []
@@ -123,6 +202,8 @@ def _read_map(data, field, dtype, nest, h):
     nside = hdr.get("NSIDE")
     if nside is not None and any(m.size != 12 * int(nside) ** 2 for m in maps):
         raise FitsFormatError("column length does not match NSIDE = %r" % nside)
+    if convert:
+        maps = [reorder(m, n2r=not nest, r2n=bool(nest)) for m in maps]
     out = maps[0] if (field is not None and np.isscalar(field)) else tuple(maps)
     if h:
         return (out, hdr) if (field is not None and np.isscalar(field)) else tuple(maps) + (hdr,)
@@ -153,7 +234,9 @@ def _header_bytes(cards):
 def write_map(filename, m, nest=False, dtype=np.float32, coord=None, column_names=None):
     """
     ``hp.write_map(filename, m)``: one map or a sequence of maps (I or I, Q, U) of the same
-    HEALPix size into a binary table of ``1024``-pixel rows, one column per map.
+    HEALPix size into a binary table of ``1024``-pixel rows, one column per map.  ``nest`` states
+    the ordering of ``m`` (written to the ORDERING keyword; the pixels are stored as given, as
+    healpy does).
     """
     maps = [np.asarray(m)] if np.ndim(m) == 1 else [np.asarray(x) for x in m]
     npix = maps[0].size

@@ -46,14 +46,21 @@ typedef struct cm2_pointing cm2_pointing;
  * already resident in HBM.  The plan KEEPS the three pointers (caller keeps the
  * buffers alive) and adds a pixel-major copy: samples grouped by pixel in time
  * order, 64 pixels per slice, slices sorted by hit count (sliced-ELL), which is
- * what makes P^T a race-free, fixed-order reduction.  d_cos/d_sin may be NULL
- * for pol == 1.  Replaces SparseLO.__init__ (linearoperators.py:527-550);
- * pol not in {1,2,3} fails like the RuntimeError at :549.  Synchronises. */
+ * what makes P^T a race-free, fixed-order reduction (built lazily, see LIFETIME below).
+ * d_cos/d_sin may be NULL for pol == 1.  Replaces SparseLO.__init__
+ * (linearoperators.py:527-550); pol not in {1,2,3} fails like the RuntimeError at :549.
+ * Synchronises. */
 int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix, const double *d_cos,
                         const double *d_sin, int64_t nt, int64_t npix, int pol,
                         void *stream);
 int cm2_pointing_destroy(cm2_pointing *p);
-/* h_info[0..5] = nt, npix, pol, valid samples, padded pixel-major length, slices */
+/* LIFETIME: the pixel-major copy is built by its first user (cm2_Pt_apply, cm2_pointing_set_weights,
+ * cm2_PtNP_diag_apply) or by cm2_pointing_build_sell, FROM d_pix / d_cos / d_sin: the caller must keep
+ * those three buffers alive AND UNCHANGED at least until then (cm2_P_apply reads them for the whole
+ * life of the plan).  An operator that only runs on the tile order (cm2_tiles) never builds it. */
+int cm2_pointing_build_sell(cm2_pointing *p, void *stream);
+/* h_info[0..5] = nt, npix, pol, then valid samples, padded pixel-major length, slices of the
+ * pixel-major copy, or -1, -1, -1 while that copy has not been built (this call builds nothing) */
 int cm2_pointing_info(const cm2_pointing *p, int64_t *h_info);
 
 /* P x: gather, time order.  d_out[t] = I_p + Q_p cos2phi_t + U_p sin2phi_t, 0 for
@@ -103,6 +110,11 @@ int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* fixed != 0: P^T adds each pixel's terms in time order (reference order, reproducible);
  * fixed == 0: LDS / global atomics */
 int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
+/* Builds the per-slice (pixel, time) lists of the fixed-order P^T now (allocations, sorts, one
+ * synchronisation) instead of inside the first cm2_Pt_tiles_apply: afterwards an application only
+ * launches kernels, so it may be captured into a graph or issued from several host threads.  A plan
+ * that was not prepared builds the lists on its first P^T under a lock.  No-op for the atomic form. */
+int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream);
 /* h_p0p1[0..1] = pixel range [p0, p1) covered by the tiles [tile_lo, tile_hi).  Tiles are uniform
  * (tile_pixels wide) unless the hit map is uneven: when a uniform tile would hold over 25 % more
  * samples than the mean, the pixel ranges are cut to equal sample counts instead (never wider than

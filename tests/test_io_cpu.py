@@ -105,8 +105,9 @@ def test_hdf5_lite_round_trip_groups_scalars_and_many_links(tmp_path):
     gc = h5.read_file(pc)
     np.testing.assert_array_equal(gc["Ritz_eigenvectors"]["Eigenvectors"], big)
     np.testing.assert_array_equal(gc["v"], np.arange(23))
-    with pytest.raises(h5.Hdf5FormatError):
-        h5.write_file(str(tmp_path / "bad2.h5"), {"x": h5.Chunked(np.zeros(1000), (1,))})
+    # more chunks than one B-tree leaf indexes (64): written with coarser chunks, same array back
+    h5.write_file(str(tmp_path / "many.h5"), {"x": h5.Chunked(np.arange(1000.0), (1,))})
+    np.testing.assert_array_equal(h5.read_file(str(tmp_path / "many.h5"))["x"], np.arange(1000.0))
     with pytest.raises(h5.Hdf5FormatError):
         h5._Reader(b"not an hdf5 file at all")
     with pytest.raises(h5.Hdf5FormatError):
@@ -223,8 +224,11 @@ def test_healpix_fits_write_read_round_trip(tmp_path):
     hf.write_map(p1, I, dtype=np.float64, nest=True)
     np.testing.assert_array_equal(hf.read_map(p1, nest=True), I)
     np.testing.assert_array_equal(hf.read_map(p1, nest=None), I)
-    with pytest.raises(NotImplementedError):
-        hf.read_map(p1, nest=False)                                      # no NESTED -> RING reordering
+    # a NESTED file read with healpy's default nest=False comes back in RING ordering
+    np.testing.assert_array_equal(hf.read_map(p1, nest=False), hf.reorder(I, n2r=True))
+    np.testing.assert_array_equal(hf.read_map(p1), hf.reorder(I, n2r=True))
+    np.testing.assert_array_equal(hf.read_map(p, nest=True),
+                                  hf.reorder(I.astype(np.float32).astype(np.float64), r2n=True))
     small = rng.standard_normal(12 * 2 * 2)                              # npix not a multiple of 1024
     hf.write_map(p1, small, dtype=np.float64)
     np.testing.assert_array_equal(hf.read_map(p1), small)
@@ -233,6 +237,86 @@ def test_healpix_fits_write_read_round_trip(tmp_path):
     with pytest.raises(hf.FitsFormatError):
         open(p1, "wb").write(b"junk" * 1000)
         hf.read_map(p1)
+
+
+def _ring_centres(nside):
+    """(z, phi) of every pixel centre in RING order, ring by ring from the pixelisation's
+    definition (Gorski et al. 2005, eqs. 2-9)."""
+    z, phi = [], []
+    for i in range(1, 4 * nside):
+        if i < nside:                                   # north polar cap: 4 i pixels
+            n, zz = 4 * i, 1.0 - i * i / (3.0 * nside * nside)
+            ph = (np.arange(1, n + 1) - 0.5) * np.pi / (2.0 * i)
+        elif i <= 3 * nside:                            # equatorial belt: 4 nside pixels
+            n, zz = 4 * nside, 4.0 / 3.0 - 2.0 * i / (3.0 * nside)
+            # pixels of a ring are numbered by increasing phi in [0, 2 pi): every other ring is
+            # shifted by half a pixel, the others have a pixel centre at phi = 0
+            fodd = 1.0 if (i + nside) % 2 else 0.5
+            ph = (np.arange(1, n + 1) - fodd) * np.pi / (2.0 * nside)
+        else:                                           # south polar cap
+            k = 4 * nside - i
+            n, zz = 4 * k, -(1.0 - k * k / (3.0 * nside * nside))
+            ph = (np.arange(1, n + 1) - 0.5) * np.pi / (2.0 * k)
+        z += [zz] * n
+        phi += list(ph)
+    return np.array(z), np.array(phi)
+
+
+def _nest_centres(nside):
+    """(z, phi) of every pixel centre in NESTED order from the face geometry: base face f, cell
+    (ix, iy) of its nside x nside grid (the HEALPix C++ pix2loc, floating point on purpose: no ring
+    offsets, no shift bit)."""
+    jrll = [2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4]
+    jpll = [1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7]
+    z, phi = [], []
+    for p in range(12 * nside * nside):
+        f, ipf = divmod(p, nside * nside)
+        ix = sum(((ipf >> (2 * b)) & 1) << b for b in range(16))
+        iy = sum(((ipf >> (2 * b + 1)) & 1) << b for b in range(16))
+        jr = jrll[f] * nside - ix - iy - 1
+        if jr < nside:
+            nr, zz = jr, 1.0 - jr * jr / (3.0 * nside * nside)
+        elif jr > 3 * nside:
+            nr = 4 * nside - jr
+            zz = nr * nr / (3.0 * nside * nside) - 1.0
+        else:
+            nr, zz = nside, (2 * nside - jr) * 2.0 / (3.0 * nside)
+        tmp = (jpll[f] * nr + ix - iy) % (8 * nr)
+        z.append(zz)
+        phi.append(np.pi / 4.0 * tmp / nr)
+    return np.array(z), np.array(phi)
+
+
+@pytest.mark.parametrize("nside", [1, 2, 4, 8])
+def test_ring_nested_reordering_against_pixel_geometry(nside):
+    """nest2ring / ring2nest (integer arithmetic) against the permutation found by matching
+    pixel-centre coordinates of the two orderings, each built from its own definition."""
+    from cosmomap2_amd.utilities import healpix_fits as hf
+    npix = 12 * nside * nside
+    zr, pr = _ring_centres(nside)
+    zn, pn = _nest_centres(nside)
+    assert zr.size == npix and zn.size == npix
+    table = np.empty(npix, dtype=np.int64)                 # hand-built: table[nest] = ring
+    for p in range(npix):
+        hit = np.flatnonzero((np.abs(zr - zn[p]) < 1e-12) & (np.abs(pr - pn[p]) < 1e-12))
+        assert hit.size == 1, (p, hit)
+        table[p] = hit[0]
+    assert sorted(table) == list(range(npix))
+    np.testing.assert_array_equal(hf.nest2ring(nside, np.arange(npix)), table)
+    np.testing.assert_array_equal(hf.ring2nest(nside, table), np.arange(npix))
+    assert hf.nest2ring(nside, 0) == int(table[0]) and isinstance(hf.nest2ring(nside, 0), int)
+    m = np.random.default_rng(nside).standard_normal((2, npix))
+    ring = hf.reorder(m, n2r=True)
+    np.testing.assert_array_equal(ring[:, table], m)
+    np.testing.assert_array_equal(hf.reorder(ring, r2n=True), m)
+    if nside == 1:
+        np.testing.assert_array_equal(table, np.arange(12))     # the base pixels are ring-ordered
+    with pytest.raises(ValueError):
+        hf.nest2ring(3, 0)
+    with pytest.raises(ValueError):
+        hf.nest2ring(nside, npix)
+    with pytest.raises(ValueError):
+        hf.reorder(m)
 
 
 def test_healpix_fits_reader_on_the_reference_map():
@@ -349,8 +433,10 @@ def test_fits_map_round_trip_fuzz(tmp_path):
                     assert hdr["TFIELDS"] == nmaps and len(got) == nmaps + 1
                     for a, b in zip(got[:-1], maps):
                         np.testing.assert_array_equal(a, b.astype(np.float64))
-                    with pytest.raises(NotImplementedError):
-                        hf.read_map(p, nest=not nest)
+                    # asked for the other ordering, the reader converts (hp.read_map does)
+                    other = hf.read_map(p, nest=not nest)
+                    np.testing.assert_array_equal(
+                        other, hf.reorder(maps[0].astype(np.float64), n2r=nest, r2n=not nest))
 
 
 def test_corrupt_files_raise_the_format_errors(tmp_path):
@@ -396,3 +482,13 @@ def test_corrupt_files_raise_the_format_errors(tmp_path):
         except (hf.FitsFormatError, NotImplementedError):     # (a flipped ORDERING keyword)
             outcomes.add("format error")
     assert outcomes == {"ok", "format error"}
+
+
+def test_chunked_dataset_with_more_than_64_chunks(tmp_path):
+    """A Ritz checkpoint whose chunk grid exceeds one B-tree leaf (64 chunks) is written with
+    coarser chunks instead of failing, and reads back bit for bit."""
+    from cosmomap2_amd.utilities import hdf5_lite as h5
+    a = np.arange(40 * 30, dtype=np.float64).reshape(40, 30)
+    p = str(tmp_path / "many.hdf5")
+    h5.write_file(p, {"Z": h5.Chunked(a, (2, 3))})            # 20 x 10 = 200 chunks asked for
+    np.testing.assert_array_equal(np.asarray(h5.read_file(p)["Z"]), a)
