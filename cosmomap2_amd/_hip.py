@@ -72,6 +72,9 @@ PROTOTYPES = {
     "cm2_Zt_apply": [_i64, _int, _vp, _vp, _vp, _vp, _vp],
     "cm2_pcg": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _i64, _vp, _vp,
                 ctypes.POINTER(_i64), ctypes.POINTER(_int), _vp],
+    "cm2_arnoldi": [_i64, _vp, _vp, _vp, _vp, _dbl, _int, _vp, ctypes.POINTER(_dbl),
+                    ctypes.POINTER(_int), _vp],
+    "cm2_PtNP_tiles_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cm2_Z_apply": [_i64, _int, _vp, _vp, _vp, _vp],
     "cm2_Z_axpy": [_i64, _int, _vp, _vp, _dbl, _vp, _vp],
     "cm2_gemm_tn_work_doubles": [_int, _int],

@@ -527,3 +527,20 @@ extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const
     return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), cm2_tiles_plan_id(tiles),
                                        d_in_tb, d_out_tb, as_stream(stream_));
 }
+
+// One call for the whole tile-order chain y = P^T N^-1 P x (SURVEY 8b's fused cm2_PtNP_apply):
+// k_P_tiles, the overlap-save kernel on the tile order, the fixed-order (or atomic) P^T -- three
+// launches on `stream`, no allocation when the plan was prepared (cm2_tiles_prepare_pt) and the
+// operator has run once on this plan.  d_tb1 / d_tb2: scratch of >= (valid samples) doubles each.
+extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *d_tod_tb, void *stream);
+extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, double *d_out, void *stream);
+
+extern "C" int cm2_PtNP_tiles_apply(const cm2_tiles *tiles, cm2_noise *n, const double *d_x,
+                                    double *d_y, double *d_tb1, double *d_tb2, void *stream)
+{
+    CM2_CHECK(tiles && n && d_x && d_y && d_tb1 && d_tb2, "cm2_PtNP_tiles_apply: NULL argument");
+    CM2_CHECK(d_tb1 != d_tb2, "cm2_PtNP_tiles_apply: the two scratch buffers must differ");
+    if (int rc = cm2_P_tiles_apply(tiles, d_x, d_tb1, stream)) return rc;
+    if (int rc = cm2_noise_apply_tiles(n, tiles, d_tb1, d_tb2, stream)) return rc;
+    return cm2_Pt_tiles_apply(tiles, d_tb2, d_y, stream);
+}

@@ -298,6 +298,77 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
     return 0;
 }
 
+// Modified Gram-Schmidt Arnoldi with the reference's conventions (interfaces/deflationlib.py:
+// 17-113): r0 = b - A x0, early exit when ||r0|| < tol ||b|| or < tol (:80-82, *h_steps = 0),
+// per step w = A v_{j-1}; for every stored v: alpha = <v, w>, w -= alpha v (:94-97); h_{j+1,j} =
+// ||w||; stop when |w[j] h_{j+1,j}| <= tol -- the j-th COMPONENT of the normalised new vector, as
+// the reference tests it (:101) --, error when inner_m steps do not trigger it (:111-112).
+// d_V holds the basis vectors one after the other (vector i at d_V + i n, inner_m of them at
+// most); h_H is the (inner_m + 1) x inner_m Hessenberg matrix, row-major on the host, zero-filled
+// here; on return *h_steps = j and the first j vectors / the leading (j + 1) x j block are set.
+extern "C" int cm2_arnoldi(int64_t n, cm2_apply_fn A, void *A_ctx, const double *d_b,
+                           const double *d_x0, double tol, int inner_m, double *d_V, double *h_H,
+                           int *h_steps, void *stream_)
+{
+    CM2_CHECK(n >= 1 && A && d_b && d_V && h_H && h_steps && inner_m >= 1,
+              "cm2_arnoldi: NULL argument, n < 1 or inner_m < 1");
+    hipStream_t stream = as_stream(stream_);
+    *h_steps = 0;
+    for (int64_t i = 0; i < (int64_t)(inner_m + 1) * inner_m; ++i) h_H[i] = 0.0;
+    DevTemp<double> w, sc, work;
+    CM2_HIP(w.alloc(n));
+    CM2_HIP(sc.alloc(2));
+    CM2_HIP(work.alloc((size_t)cm2_reduce_work_doubles()));
+    double h = 0.0;
+    auto dot = [&](const double *a, const double *b2) -> int {
+        if (int rc = cm2_dot(n, a, b2, sc.p, work, stream)) return rc;
+        CM2_HIP(hipMemcpyAsync(&h, sc.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+    if (int rc = dot(d_b, d_b)) return rc;
+    CM2_CHECK(h == h && h - h == 0.0, "RHS must contain only finite numbers");   // deflationlib.py:60-61
+    double b_norm = sqrt(h);
+    if (b_norm == 0.0) b_norm = 1.0;
+    // r0 = b - A x0 into the first basis slot
+    double *v0 = d_V;
+    CM2_HIP(hipMemcpyAsync(v0, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    if (d_x0) {
+        if (A(A_ctx, d_x0, w.p, stream_)) { set_error("cm2_arnoldi: the operator callback failed"); return 1; }
+        if (int rc = cm2_axpy(n, -1.0, w.p, v0, stream_)) return rc;
+    }
+    if (int rc = dot(v0, v0)) return rc;
+    const double r_norm = sqrt(h);
+    if (r_norm < tol * b_norm || r_norm < tol) return 0;     // "Arnoldi exited at the first iteration"
+    if (int rc = cm2_scal(n, 1.0 / r_norm, v0, stream_)) return rc;
+    for (int j = 1; j <= inner_m; ++j) {
+        double *vnew = (j < inner_m) ? d_V + (int64_t)j * n : w.p;   // the last step's vector is not kept
+        if (A(A_ctx, d_V + (int64_t)(j - 1) * n, vnew, stream_)) {
+            set_error("cm2_arnoldi: the operator callback failed");
+            return 1;
+        }
+        for (int i = 0; i < j; ++i) {
+            const double *vi = d_V + (int64_t)i * n;
+            if (int rc = dot(vi, vnew)) return rc;
+            h_H[(int64_t)i * inner_m + (j - 1)] = h;
+            if (int rc = cm2_axpy(n, -h, vi, vnew, stream_)) return rc;
+        }
+        if (int rc = dot(vnew, vnew)) return rc;
+        const double hn = sqrt(h);
+        h_H[(int64_t)j * inner_m + (j - 1)] = hn;
+        if (int rc = cm2_scal(n, 1.0 / hn, vnew, stream_)) return rc;
+        double vj = 0.0;
+        if (j < n) {
+            CM2_HIP(hipMemcpyAsync(&vj, vnew + j, sizeof(double), hipMemcpyDeviceToHost, stream));
+            CM2_HIP(hipStreamSynchronize(stream));
+        }
+        *h_steps = j;
+        if (fabs(vj * hn) <= tol) return 0;
+    }
+    set_error("Convergence not achieved within the Arnoldi algorithm");     // deflationlib.py:112
+    return 4;
+}
+
 // ------------------------------------------------------------- Z^T x ----------
 // Z row-major [n][r].  Thread (row-lane, column): consecutive threads read
 // consecutive doubles of a row => full-line accesses; per-column partials are

@@ -169,6 +169,12 @@ int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, void *stream
  * kernel's own loads and stores.  d_out_tb != d_in_tb. */
 int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
                           double *d_out_tb, void *stream);
+/* y = P^T N^-1 P x in ONE call on the tile order (the chain `P.T*N*P` of the reference's scripts,
+ * src/test_M2_precond_onto_real_data.py:79-86, SURVEY 8b's cm2_PtNP_apply): cm2_P_tiles_apply,
+ * cm2_noise_apply_tiles, cm2_Pt_tiles_apply on `stream`.  d_tb1 != d_tb2: scratch of at least
+ * (valid samples of the plan, cm2_tiles_info[1]) doubles each. */
+int cm2_PtNP_tiles_apply(const cm2_tiles *tiles, cm2_noise *n, const double *d_x, double *d_y,
+                         double *d_tb1, double *d_tb2, void *stream);
 /* per-sample diagonal of a constant-diagonal noise operator (BlockLO.diag). */
 int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
 /* h_info[0..5] = nt, nblocks, lambda (0 for diag), method used, FFT length, 1 if
@@ -275,6 +281,17 @@ int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
             const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
             int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters, int *h_info,
             void *stream);
+
+/* a13  arnoldi (interfaces/deflationlib.py:17-113) as a C entry point, operator as a callback:
+ * modified Gram-Schmidt on r0 = b - A x0 (d_x0 may be NULL = 0) with the reference's early exit
+ * (||r0|| < tol ||b|| or < tol: *h_steps = 0, :80-82), its stop rule |v_new[j] h_{j+1,j}| <= tol
+ * (:101) and its failure after inner_m steps (returns non-zero, cm2_last_error() =
+ * "Convergence not achieved within the Arnoldi algorithm", :111-112; *h_steps = inner_m).
+ * d_V: inner_m vectors of n doubles, vector i at d_V + i*n; h_H: (inner_m + 1) x inner_m,
+ * row-major, host; on return the first *h_steps vectors and columns are set (build_hess :115-137
+ * reads its m x m matrix from the leading block). */
+int cm2_arnoldi(int64_t n, cm2_apply_fn A, void *A_ctx, const double *d_b, const double *d_x0,
+                double tol, int inner_m, double *d_V, double *h_H, int *h_steps, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * a10-a12  Deflation space and coarse operator

@@ -453,6 +453,105 @@ def test_cm2_pcg_driver_equals_python_cg(cm, oracle):
     assert inf.value == 2 and iters.value == 2
 
 
+def test_cm2_arnoldi_driver_equals_python_arnoldi(cm, oracle, golden):
+    """cm2_arnoldi (C entry point, operator as a callback) against interfaces.arnoldi on the same
+    operator: same number of steps, bit-identical Hessenberg columns and basis vectors; the
+    reference's early exit and its failure after inner_m steps; and the reference's own executed
+    arnoldi() vectors (golden arn_*) through the C driver."""
+    import ctypes
+    from cosmomap2_amd import _hip, device as D
+    t = cm.torch
+    APPLY = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+    def run(Aop, b, n, tol, inner_m, x0=None):
+        class Raw(object):
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8",
+                                                 "data": (int(ptr), False), "version": 2}
+
+        def f(ctx, d_in, d_out, stream):
+            x_in = t.as_tensor(Raw(d_in), device="cuda")
+            t.as_tensor(Raw(d_out), device="cuda").copy_(D.f64(Aop * x_in))
+            return 0
+        cb = APPLY(f)
+        V = D.zeros(n * inner_m)
+        H = (ctypes.c_double * ((inner_m + 1) * inner_m))()
+        steps = ctypes.c_int(-1)
+        bd = D.f64(b)                                 # kept alive for the whole call
+        x0d = D.f64(x0) if x0 is not None else None
+        rc = _hip.load().cm2_arnoldi(n, ctypes.cast(cb, ctypes.c_void_p), None, D.ptr(bd),
+                                     D.ptr(x0d), tol, inner_m, D.ptr(V), H, ctypes.byref(steps),
+                                     D.stream())
+        t.cuda.synchronize()
+        return rc, V.reshape(inner_m, n), np.array(H).reshape(inner_m + 1, inner_m), steps.value
+
+    # a small SPD matrix with a few distinct eigenvalues: the stop rule triggers after a few steps
+    rng = np.random.default_rng(12)
+    n = 60
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Amat = (Q * np.repeat([1.0, 2.0, 3.5, 5.0, 7.0, 9.0], 10)).dot(Q.T)
+    Aop = cm.I.lp.LinearOperator(n, n, lambda v: D.f64(Amat).matmul(D.f64(v)) if D.is_tensor(v)
+                               else Amat.dot(v), symmetric=True, device_ok=True)
+    b = rng.standard_normal(n)
+    vs, hs, j = cm.I.arnoldi(Aop, D.f64(b), tol=1e-10, inner_m=30)
+    rc, V, H, steps = run(Aop, b, n, 1e-10, 30)
+    assert rc == 0 and steps == j and 2 <= j < 30
+    for q in range(j):
+        np.testing.assert_array_equal(H[:q + 2, q], np.asarray(hs[q]))      # column q has q + 2 entries
+        assert t.equal(V[q], D.f64(vs[q]))
+    assert not H[j + 1:].any()
+    np.testing.assert_array_equal(cm.I.build_hess(hs, j), H[:j, :j])
+    # early exit (||r0|| < tol): zero steps; x0 given: r0 = b - A x0
+    rc, _, _, steps = run(Aop, 1e-14 * b, n, 1e-5, 10)
+    assert rc == 0 and steps == 0
+    xsol = np.linalg.solve(Amat, b)
+    rc, _, _, steps = run(Aop, b, n, 1e-5, 10, x0=xsol)
+    assert rc == 0 and steps == 0
+    # failure after inner_m steps: the reference's RuntimeError text
+    rc, _, _, steps = run(Aop, b, n, 1e-300, 3)
+    assert rc != 0 and steps == 3
+    assert b"Convergence not achieved within the Arnoldi algorithm" in _hip.load().cm2_last_error()
+    with pytest.raises(RuntimeError):
+        cm.I.arnoldi(Aop, D.f64(b), tol=1e-300, inner_m=3)
+    # the reference's own executed arnoldi() on its golden system
+    Ag, bg = golden["arn_A"], golden["arn_b"]
+    ng = bg.size
+    Ago = cm.I.lp.LinearOperator(ng, ng, lambda v: D.f64(Ag).matmul(D.f64(v)) if D.is_tensor(v) else Ag.dot(v),
+                               symmetric=True, device_ok=True)
+    jg = int(golden["arn_j"])
+    rc, V, H, steps = run(Ago, bg, ng, 1e-8, 30)          # the golden call: tol 1e-8, inner_m 30
+    assert rc == 0 and steps == jg
+    np.testing.assert_allclose(V[:jg].cpu().numpy(), golden["arn_V"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(H[:jg, :jg], golden["arn_H"], rtol=0, atol=1e-9)
+
+
+def test_cm2_PtNP_tiles_apply_is_the_three_calls(cm, oracle):
+    """cm2_PtNP_tiles_apply (one call for the tile-order chain) gives the bits of the three
+    separate calls."""
+    from types import SimpleNamespace
+    from cosmomap2_amd import _hip, device as D
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(77)
+    pol, npix, nt, nblk, lam = 3, 3000, 200000, 4, 50
+    pairs = rng.integers(0, npix, nt)
+    pairs[rng.random(nt) < 0.03] = -1
+    phi = 0.3 + 0.0785 * np.arange(nt)
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol,
+                      angle_processed=SimpleNamespace(cos=np.cos(2 * phi), sin=np.sin(2 * phi)))
+    T = L._sparse_tiles(P, tile_pixels=512, slice_samples=4096)
+    kk = np.arange(lam)
+    N = cm.I.BlockLO(nt // nblk, [(1.0 + 0.1 * b) * np.exp(-kk / 9.0) for b in range(nblk)],
+                     offdiag=True, method=3)
+    x = D.f64(rng.standard_normal(pol * npix))
+    want = D.f64(L._TiledNormalLO(P, N) * x)
+    y, w1, w2 = D.empty(pol * npix), D.empty(T.nvalid), D.empty(T.nvalid)
+    y.fill_(5.0)
+    _hip.call("cm2_PtNP_tiles_apply", T.h, N._noise.h, D.ptr(x), D.ptr(y), D.ptr(w1), D.ptr(w2), D.stream())
+    assert cm.torch.equal(y, want)
+    with pytest.raises(_hip.HipError):
+        _hip.call("cm2_PtNP_tiles_apply", T.h, N._noise.h, D.ptr(x), D.ptr(y), D.ptr(w1), D.ptr(w1), D.stream())
+
+
 def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkeypatch):
     """Half of the samples on a tenth of the map: the tile plan re-cuts its pixel ranges to equal
     sample counts (the fixed-order P^T gives a tile to one workgroup), P^T N^-1 P does not change
