@@ -378,8 +378,8 @@ def main():
             call = _hip.call
             tile_info = {"tile_pixels": T.tile_pixels, "tiles": T.ntiles,
                          "half_angle_storage": T.half_angle,
-                         "pt_order": "fixed (time order per pixel, no atomics)" if T.pt_fixed
-                         else "atomic"}
+                         "pt_order": {0: "atomic", 1: "fixed (time order per pixel, hot runs in fixed chunks, "
+                                      "no atomics)", 2: "exact (time order per pixel)"}[T.pt_mode]}
             stages["P tiles (k_P_tiles)"] = (ev_time(lambda: call(
                 "cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()), reps),
                 28.0 * nt + map_bytes / 2, (2.0 + ang + 8.0) * nv + map_bytes / 2)

@@ -422,7 +422,8 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     t->ntiles = (npix + tile_pixels - 1) / tile_pixels;
     t->plan_id = next_plan_id();
     // order of the per-pixel sums of P^T: fixed (time order, reproducible; default) or atomic
-    if (const char *e = getenv("CM2_PT_ORDER")) t->pt_fixed = strcmp(e, "atomic") != 0;
+    if (const char *e = getenv("CM2_PT_ORDER"))          // atomic | exact | fixed (default)
+        t->pt_fixed = !strcmp(e, "atomic") ? 0 : (!strcmp(e, "exact") ? 2 : 1);
 
     DevTemp<uint32_t> keys_in, keys_out, vals_in, tb_src;
     DevTemp<int64_t> d_off;
@@ -628,7 +629,7 @@ extern "C" int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream_)
 extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 {
     CM2_CHECK(t, "cm2_tiles_set_pt_order: NULL argument");
-    t->pt_fixed = fixed ? 1 : 0;
+    t->pt_fixed = fixed == 2 ? 2 : (fixed ? 1 : 0);
     return 0;
 }
 

@@ -48,6 +48,18 @@ constexpr int kFxT = 512;               // threads = groups per slice handled in
 constexpr int kFxDepth = 2;             // slices fetched ahead of the one being reduced
 constexpr uint32_t kFxNull = 0xFFFFFFFFu;
 constexpr int kFxMaxLevel = 14;         // pieces of 4: runs up to 60 samples go into groups
+// Hot pixels.  A run longer than `chunk_min` entries inside one slice (a pixel that takes a large
+// share of a tile's samples: a stare at a source, a tile that is one pixel) is not walked term by
+// term by one thread -- 1536 dependent additions per slice while 511 threads wait -- but cut into
+// chunks of kFxChunk consecutive entries: one thread per chunk sums its terms in time order in
+// registers, the chunk sums of a run are added in time order by one thread, and the result joins
+// the pixel's accumulator.  The chunk boundaries and both orders are fixed by the plan, so the
+// result is reproducible bit for bit and independent of the hit map; it differs from the serial
+// sum by the rounding of a regrouped sum (~1e-16 relative per level).  cm2_tiles_set_pt_order(t, 2)
+// / CM2_PT_ORDER=exact keep the pure time order for every run.
+constexpr int kFxChunk = 32;
+constexpr int kFxChunkMinDefault = 256;
+constexpr int kFxMaxChunks = 128;       // per slice: S / kFxChunk + long runs <= 64 + 8
 
 // ------------------------------------------------------------------- kernel --------
 template <int POL, bool HALF, int VPT>
@@ -57,7 +69,8 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     const uint4 *__restrict__ gent, const double2 *__restrict__ ga,
     const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
     const uint32_t *__restrict__ tent, const double *__restrict__ ta,
-    const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out)
+    const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out,
+    uint32_t chunk_min)
 {
     constexpr int D = kFxDepth;
     constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
@@ -65,6 +78,7 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     extern __shared__ double sm[];
     double *tile = sm;                                   // tp * POL accumulators
     double *vbuf = sm + (int64_t)tp * POL;               // VPT * kFxT values of the slice, TB order
+    double *part = vbuf + VPT * kFxT;                    // 3 x kFxMaxChunks chunk sums of hot runs
     const int tid = threadIdx.x;
     const int b = tile0 + blockIdx.x;
     const int64_t p0 = tile_p0[b];
@@ -207,11 +221,12 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
                     terms(w[m], a[m], bs[m], v[m], t1[m], t2[m]);
                 }
                 const int level = mine ? (int)((w[0] >> 28) & 15u) : 0;
-                if (g0 == 0) {
-                    // runs too long for the groups: one thread walks a whole run
+                if (g0 == 0 && ntail > 0) {
+                    const int64_t tr0 = (int64_t)(m0.y & 0x0FFFFFFFu);
+                    // runs too long for the groups: one thread walks a whole run ...
                     for (uint32_t r = tid; r < ntail; r += kFxT) {
-                        const uint2 r0 = trun[(int64_t)(m0.y & 0x0FFFFFFFu) + r],
-                                    r1 = trun[(int64_t)(m0.y & 0x0FFFFFFFu) + r + 1];
+                        const uint2 r0 = trun[tr0 + r], r1 = trun[tr0 + r + 1];
+                        if (r1.x - r0.x > chunk_min) continue;
                         const int q = (int)r0.y;
                         for (uint32_t e = r0.x; e < r1.x; ++e) {
                             const uint32_t we = tent[e];
@@ -219,6 +234,53 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
                             double u1 = 0.0, u2 = 0.0;
                             terms(we, ANG ? ta[e] : 0.0, TWO ? tb[e] : 0.0, ve, u1, u2);
                             tile_add(q, ve, u1, u2);
+                        }
+                    }
+                    // ... unless it is a hot run: chunk sums by one thread per chunk (the walk over
+                    // the runs is the same for every thread: trun is read uniformly), then the
+                    // chunk sums of a run added in time order by the thread of its first chunk
+                    int cbase = 0, my_first = -1, my_n = 0, my_q = 0;
+                    for (uint32_t r = 0; r < ntail; ++r) {
+                        const uint2 r0 = trun[tr0 + r], r1 = trun[tr0 + r + 1];
+                        const uint32_t len = r1.x - r0.x;
+                        if (len <= chunk_min) continue;
+                        const int nch = (int)((len + kFxChunk - 1) / kFxChunk);
+                        const int c = tid - cbase;
+                        if (c >= 0 && c < nch && tid < kFxMaxChunks) {
+                            const uint32_t e0 = r0.x + (uint32_t)c * kFxChunk;
+                            const uint32_t e1 = e0 + kFxChunk < r1.x ? e0 + kFxChunk : r1.x;
+                            double sv = 0.0, s1 = 0.0, s2 = 0.0;
+                            for (uint32_t e = e0; e < e1; ++e) {
+                                const uint32_t we = tent[e];
+                                const double ve = vbuf[(we >> 16) & 0xFFFu];
+                                double u1 = 0.0, u2 = 0.0;
+                                terms(we, ANG ? ta[e] : 0.0, TWO ? tb[e] : 0.0, ve, u1, u2);
+                                sv += ve;
+                                s1 += u1;
+                                s2 += u2;
+                            }
+                            part[tid] = sv;
+                            part[kFxMaxChunks + tid] = s1;
+                            part[2 * kFxMaxChunks + tid] = s2;
+                            if (c == 0) {
+                                my_first = tid;
+                                my_n = nch;
+                                my_q = (int)r0.y;
+                            }
+                        }
+                        cbase += nch;
+                    }
+                    if (cbase > 0) {                      // (uniform: some run of this slice is hot)
+                        __syncthreads();
+                        if (my_first >= 0) {
+                            double sv = part[my_first], s1 = part[kFxMaxChunks + my_first],
+                                   s2 = part[2 * kFxMaxChunks + my_first];
+                            for (int k = 1; k < my_n; ++k) {
+                                sv += part[my_first + k];
+                                s1 += part[kFxMaxChunks + my_first + k];
+                                s2 += part[2 * kFxMaxChunks + my_first + k];
+                            }
+                            tile_add(my_q, sv, s1, s2);
                         }
                     }
                 }
@@ -347,7 +409,7 @@ size_t fx_lds_bytes(const cm2_tiles *t, int S)
 {
     int vpt = (S + kFxT - 1) / kFxT;
     vpt = vpt <= 2 ? 2 : vpt;
-    return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT);
+    return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT + 3 * (size_t)kFxMaxChunks);
 }
 
 void fx_release(cm2_tiles *t)
@@ -500,7 +562,8 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
         t->tp, t->d_tile_p0, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
-        t->d_fx_tb, d_tod_tb, d_out);
+        t->d_fx_tb, d_tod_tb, d_out,
+        t->pt_fixed == 2 ? 0xFFFFFFFFu : (uint32_t)kFxChunkMinDefault);
     CM2_LAUNCH_OK();
     return 0;
 }

@@ -186,10 +186,12 @@ _PANEL = 32          # basis vectors per row-major panel of the block Gram-Schmi
 class _BasisPanels(object):
     """The Arnoldi basis kept twice: as a list of contiguous vectors (for the matvec) and as
     row-major n x 32 panels (for cm2_Zt_apply / cm2_Z_apply, which read 32 basis vectors in
-    one pass).  Unused columns of the last panel are zero."""
+    one pass).  Unused columns of the last panel are zero.  With row-sharded vectors ``n`` is
+    the number of local rows and ``allreduce`` sums the inner products over ranks in place."""
 
-    def __init__(self, n):
+    def __init__(self, n, allreduce=None):
         self.n = n
+        self.allreduce = allreduce
         self.vecs = []
         self.panels = []
 
@@ -201,14 +203,18 @@ class _BasisPanels(object):
         self.vecs.append(v)
 
     def dots(self, w):
-        """[<v_j, w>] for all basis vectors: one kernel per panel, one host copy."""
+        """[<v_j, w>] for all basis vectors: one kernel per panel (and one all-reduce of the
+        whole coefficient vector when the rows are sharded)."""
         outs = []
         for pnl in self.panels:
             o = D.empty(_PANEL)
             _hip.call("cm2_Zt_apply", self.n, _PANEL, D.ptr(pnl), D.ptr(w), D.ptr(o),
                       D.ptr(D.reduce_work()), D.stream())
             outs.append(o)
-        return D.torch.cat(outs) if len(outs) > 1 else outs[0]
+        out = D.torch.cat(outs) if len(outs) > 1 else outs[0]
+        if self.allreduce is not None:
+            self.allreduce(out)
+        return out
 
     def subtract(self, w, coeff_dev):
         """w -= sum_j coeff_j v_j."""
@@ -217,7 +223,42 @@ class _BasisPanels(object):
                       D.ptr(coeff_dev[i * _PANEL:(i + 1) * _PANEL]), -1.0, D.ptr(w), D.stream())
 
 
-def _arnoldi_M(A, x0d, M, nmax):
+class _DeviceOps(object):
+    """Vector operations of :func:`_arnoldi_M` on HBM tensors (the shipped path).  The CPU test of
+    the row-sharded build injects a NumPy stand-in with the same methods to exercise the
+    recurrence and the placement of the all-reduces over gloo."""
+
+    def __init__(self, allreduce=None):
+        self.allreduce = allreduce
+
+    def basis(self, n):
+        return _BasisPanels(n, self.allreduce)
+
+    def apply(self, op, v):
+        return _own(_apply(op, v), v)
+
+    def scaled(self, alpha, v):
+        return D.scaled(alpha, v)
+
+    def clone(self, v):
+        return v.clone()
+
+    def dot_dev(self, x, y):
+        """<x, y> summed over ranks, left where the data lives (no synchronisation)."""
+        out = D.dot_dev(x, y)
+        if self.allreduce is not None:
+            self.allreduce(out)
+        return out
+
+    def dot(self, x, y):
+        return float(self.dot_dev(x, y).item())
+
+    def column(self, hk, k, ss):
+        """Host copy of the k + 1 orthogonalisation coefficients and the squared norm."""
+        return D.to_host(D.torch.cat([hk[:k + 1], ss]))
+
+
+def _arnoldi_M(A, x0d, M, nmax, ops=None):
     """Device-resident Arnoldi in the M inner product: returns (V basis, P basis -- both as
     _BasisPanels, the same object when M is None --, Hessenberg matrix (nmax+1 x nmax, NumPy),
     number of completed steps); A V_m = P_{m+1} H[:m+1, :m] and V^T P = I.
@@ -226,25 +267,30 @@ def _arnoldi_M(A, x0d, M, nmax):
     map-making spectra are tightly clustered, the new direction is soon tiny and a single
     pass loses orthogonality): per sweep one pass over the dual basis for all inner products
     and one over the primal basis for the update, with one host synchronisation, instead of
-    2(k+1) synchronised dot products of a modified Gram-Schmidt loop."""
-    n = x0d.numel()
-    Pb, Vb = _BasisPanels(n), None
+    2(k+1) synchronised dot products of a modified Gram-Schmidt loop.
+
+    Row-sharded vectors (``ops`` built with an all-reduce): ``x0d``, ``A`` and ``M`` act on this
+    rank's rows; every inner product is a local sum followed by an all-reduce -- per step two
+    coefficient vectors (one per sweep) and one scalar -- so every rank builds the same H."""
+    ops = ops or _DeviceOps()
+    n = len(x0d)
+    Pb, Vb = ops.basis(n), None
     if M is None:
-        p0 = x0d.clone()
-        nrm = _norm(p0)
-        Pb.append(D.scaled(1.0 / nrm, p0))
+        p0 = ops.clone(x0d)
+        nrm = math.sqrt(ops.dot(p0, p0))
+        Pb.append(ops.scaled(1.0 / nrm, p0))
         Vb = Pb
     else:
-        Vb = _BasisPanels(n)
-        Mv = _apply(M, x0d)
-        nrm = math.sqrt(abs(D.dot(x0d, Mv)))
-        Pb.append(D.scaled(1.0 / nrm, x0d))
-        Vb.append(D.scaled(1.0 / nrm, Mv))
+        Vb = ops.basis(n)
+        Mv = ops.apply(M, x0d)
+        nrm = math.sqrt(abs(ops.dot(x0d, Mv)))
+        Pb.append(ops.scaled(1.0 / nrm, x0d))
+        Vb.append(ops.scaled(1.0 / nrm, Mv))
     H = np.zeros((nmax + 1, nmax))
     k_done = 0
     hmax = 0.0                                         # largest |H| entry seen so far
     for k in range(nmax):
-        Av = _own(_apply(A, Vb.vecs[k]), Vb.vecs[k])
+        Av = ops.apply(A, Vb.vecs[k])
         h = Vb.dots(Av)                                # duals V: <v_j, Av> = <p_j, Av>_M
         Pb.subtract(Av, h)
         h2 = Vb.dots(Av)                               # second sweep on the corrected vector
@@ -252,11 +298,11 @@ def _arnoldi_M(A, x0d, M, nmax):
         hk = h + h2                                    # stays in HBM: the column is fetched with
         if M is None:                                  # the norm below, one synchronisation a step
             MAv = Av
-            ss = D.dot_dev(Av, Av)
+            ss = ops.dot_dev(Av, Av)
         else:
-            MAv = _apply(M, Av)
-            ss = D.dot_dev(Av, MAv)
-        col = D.to_host(D.torch.cat([hk[:k + 1], ss]))
+            MAv = ops.apply(M, Av)
+            ss = ops.dot_dev(Av, MAv)
+        col = ops.column(hk, k, ss)
         H[:k + 1, k] = col[:k + 1]
         nrm = math.sqrt(abs(float(col[k + 1])))
         H[k + 1, k] = nrm
@@ -265,9 +311,9 @@ def _arnoldi_M(A, x0d, M, nmax):
         if nrm <= 1e-10 * max(hmax, 1e-300):           # Krylov space exhausted
             break
         hmax = max(hmax, nrm)
-        Pb.append(D.scaled(1.0 / nrm, Av))
+        Pb.append(ops.scaled(1.0 / nrm, Av))
         if M is not None:
-            Vb.append(D.scaled(1.0 / nrm, MAv))
+            Vb.append(ops.scaled(1.0 / nrm, MAv))
     return Vb, Pb, H, k_done
 
 
@@ -287,7 +333,7 @@ def _panels_times(basis, W):
     return out
 
 
-def ritz_deflation_basis(A, M, x0, r, maxiter, with_AZ=False):
+def ritz_deflation_basis(A, M, x0, r, maxiter, with_AZ=False, shards=None):
     """
     Deflation basis for the two-level preconditioner without leaving HBM: ``maxiter`` steps
     of the M-inner-product Arnoldi of :func:`run_krypy_arnoldi` on ``A`` (preconditioner
@@ -301,10 +347,19 @@ def ritz_deflation_basis(A, M, x0, r, maxiter, with_AZ=False):
     of the r further applications of ``A`` the reference spends on it (``Az[:, i] = A * Z[:, i]``,
     src/test_M2_precond_onto_real_data.py:98-101; :func:`apply_to_columns` does that).  The two
     agree to the rounding of the recurrence (tested to 1e-10).
+
+    ``shards`` (a :class:`cosmomap2_amd.sharding.RowShards`): row-sharded build.  ``A`` and ``M``
+    are the operators on this rank's rows (``RowShardedNormalLO``, ``row_sharded_bd``), ``x0`` its
+    rows of the start vector; the returned ``Z`` (and ``AZ``) are this rank's rows.  The Arnoldi
+    basis (``maxiter`` + 1 vectors: 1.8 GB at nside 256 with 96 steps) and the three passes over it
+    per step shrink by the number of ranks; what crosses the wire per step is two coefficient
+    vectors of (steps so far) doubles and one scalar, on top of the matvec's all-gather and
+    reduce-scatter.  Every rank computes the same small eigenproblem on the same H.
     """
     D.require_gpu()
     x0d = D.f64(x0).reshape(-1)
-    Vb, Pb, H, m = _arnoldi_M(A, x0d, M, int(maxiter))
+    ops = _DeviceOps(shards.allreduce_) if shards is not None else None
+    Vb, Pb, H, m = _arnoldi_M(A, x0d, M, int(maxiter), ops=ops)
     if m < r:
         raise RuntimeError("Arnoldi stopped after %d steps, cannot extract %d Ritz vectors" % (m, r))
     Hm = H[:m, :m]

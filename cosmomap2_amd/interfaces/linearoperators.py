@@ -198,6 +198,7 @@ class _TileHandle(object):
         self.nt, self.nvalid, self.tile_pixels, self.ntiles, self.nitems = [int(v) for v in info[:5]]
         self.half_angle = bool(info[5])
         self.pt_fixed = bool(info[6])
+        self.pt_mode = int(info[6])              # 0 atomic, 1 fixed (hot runs chunked), 2 exact
         self.plan_id = int(info[7])
 
     def _info(self):
@@ -219,9 +220,13 @@ class _TileHandle(object):
         return int(r[0]), int(r[1])
 
     def set_pt_order(self, fixed):
-        """True: P^T sums every pixel in time order (default); False: LDS atomics."""
-        _hip.call("cm2_tiles_set_pt_order", self.h, 1 if fixed else 0)
-        self.pt_fixed = bool(fixed)
+        """True / 1: P^T sums every pixel in time order, hot pixels (more than 256 hits inside one
+        slice of a tile) in fixed chunks of 32 terms (default: reproducible and independent of the
+        hit map); "exact" / 2: pure time order for every pixel; False / 0: LDS atomics."""
+        mode = 2 if fixed in ("exact", 2) else (1 if fixed else 0)
+        _hip.call("cm2_tiles_set_pt_order", self.h, mode)
+        self.pt_fixed = bool(mode)
+        self.pt_mode = mode
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -107,8 +107,14 @@ int cm2_tiles_destroy(cm2_tiles *t);
  * fixed-order lists (0 until the first P^T builds them) and the bytes one fixed-order P^T is
  * designed to read (TOD + padded lists) */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
-/* fixed != 0: P^T adds each pixel's terms in time order (reference order, reproducible);
- * fixed == 0: LDS / global atomics */
+/* fixed == 1 (default): P^T adds each pixel's terms in time order (the reference's order,
+ * reproducible bit for bit), except that a pixel hit more than 256 times inside one slice of a
+ * tile's samples (hot pixels: a stare at a source) is summed in chunks of 32 consecutive terms
+ * whose sums are then added in time order -- a fixed regrouping, still reproducible bit for bit
+ * and independent of the hit map, ~1e-16 relative away from the serial sum;
+ * fixed == 2 ("exact", CM2_PT_ORDER=exact): pure time order for every pixel whatever its hit count
+ * (one thread walks a hot run: 1e5 hits in one pixel cost milliseconds);
+ * fixed == 0 (CM2_PT_ORDER=atomic): LDS / global atomics, term order not fixed */
 int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
 /* Builds the per-slice (pixel, time) lists of the fixed-order P^T now (allocations, sorts, one
  * synchronisation) instead of inside the first cm2_Pt_tiles_apply: afterwards an application only

@@ -122,9 +122,33 @@ def main():
     assert info2 == 0 and info2r == 0 and len(its2r) == len(its2), (len(its2r), len(its2))
     e7 = float((sh.gather(x2r) - x2).norm() / x2.norm())
     assert e7 < 1e-12, ("row-sharded vs replicated two-level solution", e7)
+    # ---- the deflation space built on row-sharded vectors (local rows of the Arnoldi basis,
+    #      all-reduced coefficients): same Ritz values, same space, same two-level solve
+    Zl, thl, AZl = ritz_deflation_basis(Ar, Mr, b_loc, r, 24, with_AZ=True, shards=sh)
+    assert Zl.shape == (sh.rows, r) and AZl.shape == (sh.rows, r)
+    e8 = float(np.abs(np.asarray(thl) - np.asarray(theta)).max() / np.abs(theta).max())
+    assert e8 < 1e-10, ("Ritz values of the row-sharded build", e8)
+    Zg = torch.zeros(sh.rows * world, r, dtype=torch.float64, device=Zl.device)
+    dist.all_gather_into_tensor(Zg, Zl.contiguous())
+    Zg = Zg[:pol * n]
+    # same space: the replicated Ritz vectors are reproduced by projecting onto the sharded ones
+    G = torch.linalg.lstsq(Zg, Z).solution
+    e9 = float((Zg @ G - Z).norm() / Z.norm())
+    assert e9 < 1e-8, ("span of the row-sharded Ritz vectors", e9)
+    AZl_ref = rows_of(apply_to_columns(A, Zg))
+    e10 = float((AZl - AZl_ref).norm() / AZl_ref.norm())
+    assert e10 < 1e-9, ("A Z from the Arnoldi relation on local rows", e10)
+    M2s = row_sharded_two_level(Mr, Zl, AZl, sh, apply='eig')
+    its2s = []
+    x2s, info2s = cosmomap2_amd.cg(Ar, b_loc, M=M2s, rtol=1e-8, maxiter=200,
+                                   callback=lambda v: its2s.append(1), dot_reduce=sh.allreduce_)
+    assert info2s == 0 and len(its2s) == len(its2), (len(its2s), len(its2))
+    e11 = float((sh.gather(x2s) - x2).norm() / x2.norm())
+    assert e11 < 1e-9, ("two-level solve with the row-sharded deflation space", e11)
     if rank == 0:
-        print("ROWSHARDED-OK matvec %.1e, PCG %d its (%.1e), M2 %.1e, two-level %d its (%.1e)"
-              % (e4, len(its_r), e5, e6, len(its2r), e7), flush=True)
+        print("ROWSHARDED-OK matvec %.1e, PCG %d its (%.1e), M2 %.1e, two-level %d its (%.1e); "
+              "row-sharded build: Ritz values %.1e, span %.1e, AZ %.1e, two-level %d its (%.1e)"
+              % (e4, len(its_r), e5, e6, len(its2r), e7, e8, e9, e10, len(its2s), e11), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -760,6 +760,85 @@ def test_tiled_path_pcg_iteration_count_equals_oracle(cm, oracle, monkeypatch, p
         L.set_pointing_mode("auto")
 
 
+def test_hot_pixel_is_summed_in_fixed_chunks(cm, oracle):
+    """One pixel holds 5 % of 2^21 samples (a stare at a source).  Summing its terms one after
+    the other is a chain of 1e5 dependent additions; the default fixed-order P^T cuts such a run
+    (more than 256 hits inside one slice of a tile) into chunks of 32 consecutive terms, adds each
+    chunk in time order and the chunk sums in time order: reproducible bit for bit, independent
+    of the hit map, equal to the serial sum to rounding -- the PCG iteration count is the
+    oracle's, strictly -- and much faster than the one-thread walk that "exact" keeps."""
+    from cosmomap2_amd.interfaces import linearoperators as L
+    from cosmomap2_amd import _hip, device as D
+    t = cm.torch
+    pol, lam = 3, 16
+    nt, npix, nb = 1 << 21, 12 * 32 * 32, 8
+    rng = np.random.default_rng(2024)
+    d, pairs, phi, tt, diag = oracle.system_setup(rng, nt, npix, nb)
+    hot_pix = 777
+    pairs[rng.random(nt) < 0.05] = hot_pix
+    pairs[rng.random(nt) < 0.01] = -1
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.03 * b) * np.where(kk == 0, 1.0, -0.22 * np.exp(-kk / 9.0)) for b in range(nb)]
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    ces = cm.U.ProcessTimeSamples(pairs, npix, pol=pol, phi=phi)
+    n = ces.get_new_pixel[0]
+    assert n == ro.new_npix and np.array_equal(pairs, po)
+    assert int((po == hot_pix).sum()) > 0.04 * nt
+    P = cm.I.SparseLO(n, nt, pairs, pol=pol, angle_processed=ces)
+    M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
+    N = cm.I.BlockLO(nt // nb, bands, offdiag=True, method=3)
+    c, s = ro.cos, ro.sin
+
+    def A_o(x):
+        return oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(
+            nt // nb, bands, True, oracle.sparse_mult(pol, po, c, s, x)))
+    M_o = lambda x: oracle.bd_precond_mult(pol, ro, x)
+    b_o = oracle.sparse_rmult(pol, n, po, c, s, oracle.blocklo_mult(nt // nb, bands, True, d))
+    L.set_pointing_mode("tiled")
+    try:
+        A = P.T * N * P
+        T = L._sparse_tiles(P)
+        assert T.pt_mode == 1                               # default: fixed order, hot runs chunked
+        # P^T alone: chunked (default) against the pure time order, bits and time
+        v_tb = D.f64(rng.standard_normal(T.nvalid))
+        out = {}
+        ms = {}
+        for mode in (1, 2):
+            T.set_pt_order(mode)
+            o = D.empty(pol * n)
+            call = lambda: _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(o), D.stream())
+            call()
+            t.cuda.synchronize()
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                call()
+            e1.record()
+            t.cuda.synchronize()
+            ms[mode] = e0.elapsed_time(e1) / 5
+            out[mode] = o.clone()
+            call()
+            assert t.equal(o, out[mode])                     # reproducible bit for bit
+        T.set_pt_order(1)
+        err = float((out[1] - out[2]).norm() / out[2].norm())
+        assert err < 1e-14, err                             # a regrouped sum, nothing else
+        assert not t.equal(out[1], out[2])                  # (and it IS regrouped: the hot run is chunked)
+        assert ms[1] < 0.5 * ms[2], ms                       # one-thread walk of 1e5 terms vs chunks
+        # the whole solve on the default path: the oracle's iteration count, strictly
+        b = P.T * (N * d)
+        assert rel_l2(b, b_o) < 1e-12
+        its_g, its_o = [], []
+        xg, info_g = cm.cg(A, b, M=M, rtol=1e-6, maxiter=300, callback=lambda x: its_g.append(1))
+        xo, info_o = oracle.cg(A_o, b_o, M=M_o, rtol=1e-6, maxiter=300, callback=lambda x: its_o.append(1))
+        assert info_g == 0 and info_o == 0 and len(its_g) == len(its_o), (len(its_g), len(its_o))
+        assert rel_l2(xg, xo) < 1e-9
+        xg2, _ = cm.cg(A, b, M=M, rtol=1e-6, maxiter=300)
+        np.testing.assert_array_equal(xg2, xg)
+    finally:
+        L.set_pointing_mode("auto")
+
+
 def test_ritz_deflation_basis_speeds_up_pcg(cm, oracle):
     """Arnoldi (M inner product) -> Ritz vectors -> CoarseLO -> fused M2, all in HBM."""
     nt, npix, nb, pol = 60000, 400, 4, 3

@@ -191,6 +191,78 @@ def _worker(rank, world, port, out_dir):
             nit += 1
         assert nit == len(its)                                           # same count as replicated
         assert np.linalg.norm(sh.gather(xr) - xs) <= 1e-10 * np.linalg.norm(xs)
+        # ---- row-sharded deflation build: the shipped Arnoldi recurrence (_arnoldi_M: block
+        #      Gram-Schmidt in the M inner product, Hessenberg matrix, stop on an exhausted space)
+        #      with its vector operations supplied in NumPy, each rank holding its rows only and
+        #      every inner product all-reduced -- against the same recurrence on whole vectors
+        from cosmomap2_amd.interfaces.deflationlib import _arnoldi_M
+
+        class _NpBasis(object):
+            def __init__(self, n, allreduce):
+                self.n, self.allreduce, self.vecs = n, allreduce, []
+
+            def append(self, v):
+                self.vecs.append(np.array(v))
+
+            def dots(self, w):
+                out = np.array([np.dot(v, w) for v in self.vecs] + [0.0] * 3)   # padded like a panel
+                if self.allreduce is not None:
+                    self.allreduce(out)
+                return out
+
+            def subtract(self, w, coeff):
+                for v, c in zip(self.vecs, coeff):
+                    w -= c * v
+
+        class _NpOps(object):
+            def __init__(self, allreduce=None):
+                self.allreduce, self.reduced = allreduce, 0
+
+            def basis(self, n):
+                return _NpBasis(n, self._count if self.allreduce else None)
+
+            def _count(self, t):
+                self.reduced += 1
+                return self.allreduce(t)
+
+            def apply(self, op, v):
+                return np.array(op(v))
+
+            def scaled(self, a, v):
+                return a * v
+
+            def clone(self, v):
+                return v.copy()
+
+            def dot_dev(self, x, y):
+                out = np.array([np.dot(x, y)])
+                if self.allreduce is not None:
+                    self._count(out)
+                return out
+
+            def dot(self, x, y):
+                return float(self.dot_dev(x, y)[0])
+
+            def column(self, hk, k, ss):
+                return np.concatenate([hk[:k + 1], ss])
+
+        steps = 10
+        full = _arnoldi_M(lambda v: normal(pairs, c, s, bands, sizes, v), b, Mfull, steps, ops=_NpOps())
+        ops_sh = _NpOps(sh.allreduce_)
+        part = _arnoldi_M(lambda v: np.asarray(Ar * v), b_rows, M_loc, steps, ops=ops_sh)
+        assert part[3] == full[3] == steps
+        assert np.allclose(part[2], full[2], rtol=1e-10, atol=1e-12 * np.abs(full[2]).max())
+        # per step: two coefficient vectors and one scalar; two scalars for the start vector's norm
+        assert ops_sh.reduced == 3 * steps + 1, ops_sh.reduced
+        for j in (0, 3, steps):                             # basis vectors: this rank's rows
+            assert np.allclose(part[0].vecs[j][:sh.hi - sh.lo], full[0].vecs[j][sh.lo:sh.hi],
+                               rtol=1e-9, atol=1e-11)
+            assert np.all(part[0].vecs[j][sh.hi - sh.lo:] == 0.0)
+        hs = torch.from_numpy(part[2].copy())               # every rank holds the same H, bit for bit
+        lo_h, hi_h = hs.clone(), hs.clone()
+        dist.all_reduce(lo_h, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_h, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo_h, hi_h)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("%d" % len(its))
     finally:
         dist.destroy_process_group()
