@@ -682,6 +682,32 @@ def main():
                   "ms_per_step": round(med_u, 4), "value": round(nt / (med_u * 1e-3), 1),
                   "unit": "TOD samples/s"}
         del A_u, P_u, ces_u, pix_u, x_u, T_u
+        # a stare at a source: 5 % of the samples on ONE pixel.  The default fixed-order P^T sums
+        # such a run in fixed chunks (reproducible); "exact" walks it term by term with one thread.
+        pix_h = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
+        pix_h[torch.rand(nt, generator=gen_u, device=dev) < 0.05] = npix // 3
+        phi_h = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+        ces_h = ProcessTimeSamples(pix_h, npix, pol=pol, phi=phi_h)
+        del phi_h
+        n_h = ces_h.get_new_pixel[0]
+        P_h = SparseLO(n_h, nt, pix_h, pol=pol, angle_processed=ces_h)
+        A_h = P_h.T * N * P_h
+        x_h = torch.rand(pol * n_h, generator=torch.Generator(device=dev).manual_seed(10), device=dev,
+                         dtype=torch.float64)
+        _, med_h = ev_time(lambda: A_h * x_h, reps)
+        T_h = L._sparse_tiles(P_h)
+        tb_h, out_h = D.empty(T_h.nvalid), D.empty(pol * n_h)
+        _hip.call("cm2_P_tiles_apply", T_h.h, D.ptr(x_h), D.ptr(tb_h), D.stream())
+        pt_ms = {}
+        for mode, name in ((1, "fixed_chunks"), (2, "exact_time_order")):
+            T_h.set_pt_order(mode)
+            _, pt_ms[name] = ev_time(lambda: _hip.call("cm2_Pt_tiles_apply", T_h.h, D.ptr(tb_h),
+                                                       D.ptr(out_h), D.stream()), 3)
+        T_h.set_pt_order(1)
+        uneven["hot_pixel"] = {"pointing": "5 % of the samples on one pixel, the rest uniform",
+                               "ms_per_step": round(med_h, 4),
+                               "PT_ms": {k: round(v, 4) for k, v in pt_ms.items()}}
+        del A_h, P_h, ces_h, pix_h, x_h, T_h, tb_h, out_h
 
     fft_len = N.noise_info()["fft_len"] if lam else 0
 

@@ -568,6 +568,8 @@ static void os_choice(int *pt, bool *rc)
         if (!strcmp(e, "plain")) *rc = false;
 }
 
+static int ensure_pair_state(FusedOS *f, hipStream_t stream);
+
 static int ensure_real(FusedOS *f, hipStream_t stream)
 {
     int pt;
@@ -625,6 +627,7 @@ int fused_os_apply(const FusedOS *f_, const double *d_v, double *d_out, hipStrea
     FusedOS *f = const_cast<FusedOS *>(f_);
     if (int rc = ensure_real(f, stream)) return rc;
     if (f->real) return real_os_apply(f->real, d_v, d_out, stream);
+    if (int rc = ensure_pair_state(f, stream)) return rc;
     return launch_reg<false>(f, d_v, d_out, stream);
 }
 
@@ -685,11 +688,12 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
     return 0;
 }
 
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, const double *d_v,
-                           double *d_out, hipStream_t stream)
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles,
+                           const double *d_v, double *d_out, hipStream_t stream)
 {
     if (int rc = ensure_real(f, stream)) return rc;
-    if (f->real) return real_os_apply_indexed(f->real, d_idx, plan_id, f->real_rc, d_v, d_out, stream);
+    if (f->real) return real_os_apply_indexed(f->real, d_idx, plan_id, ntiles, f->real_rc, d_v, d_out, stream);
+    if (int rc = ensure_pair_state(f, stream)) return rc;
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
     // again to a later plan of the same size)
     if (f->list_plan != plan_id || (f->npairs > 0 && !f->d_lst_k))
@@ -697,19 +701,13 @@ int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, 
     return launch_reg<true>(f, d_v, d_out, stream);
 }
 
-int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
-                    const std::vector<int64_t> &off, hipStream_t stream)
+// segment pairs, permuted spectra and twiddles of the segment-pair kernel: built when that kernel
+// is the one selected (CM2_OS_KERNEL=pair), not for every operator
+static int ensure_pair_state(FusedOS *f, hipStream_t stream)
 {
-    CM2_CHECK(out != nullptr, "fused_os_create: out is NULL");
-    *out = nullptr;
-    CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
-              (long long)lambda);
-    FusedOS *f = new FusedOS();
-    struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};   // early returns
-    f->halo = (int)(lambda - 1);
-    f->d_bands = const_cast<double *>(d_bands);
-    f->lambda = lambda;
-    f->off = off;
+    if (f->d_pairs) return 0;
+    const std::vector<int64_t> &off = f->off;
+    const int64_t lambda = f->lambda;
     const int64_t nb = (int64_t)off.size() - 1;
     // segment pairs: fixed geometry (hop 4096, halo 2048 whatever lambda is)
     std::vector<PairDesc> pairs;
@@ -735,13 +733,33 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
     CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * (nb > 0 ? nb : 1) * kRegN));
     if (nb > 0) {
         k_spectrum_perm<<<grid_for(nb * kRegN), kBlock, 0, stream>>>((int)nb, lambda, kRegN, 32, 16, 16,
-                                                                    d_bands, f->d_Hperm);
+                                                                    f->d_bands, f->d_Hperm);
         CM2_LAUNCH_OK();
     }
     CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * kRegN));
     k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
+                    const std::vector<int64_t> &off, hipStream_t stream)
+{
+    CM2_CHECK(out != nullptr, "fused_os_create: out is NULL");
+    *out = nullptr;
+    CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
+              (long long)lambda);
+    FusedOS *f = new FusedOS();
+    struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};   // early returns
+    f->halo = (int)(lambda - 1);
+    f->d_bands = const_cast<double *>(d_bands);
+    f->lambda = lambda;
+    f->off = off;
+    // the selected kernel's plan (windows, spectra) is built now, so that a bad band fails here
+    if (int rc = ensure_real(f, stream)) return rc;
+    if (!f->real)
+        if (int rc = ensure_pair_state(f, stream)) return rc;
     guard.f = nullptr;
     *out = f;
     return 0;

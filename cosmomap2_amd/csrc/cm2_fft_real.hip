@@ -793,78 +793,60 @@ struct RealListOffset {
 };
 
 // run structure of one sorted list per workgroup: a run starts where the address is not the
-// previous address + 1.  PASS 0 counts the runs (for the table stride), PASS 1 writes the 16-bit
-// words (bit 15 = run start), the header and the run table delta[r] = address - slot.
-template <int PT, int PASS>
+// previous address + 1.  One pass over the list in pieces of 256 consecutive entries (coalesced):
+// the 16-bit words get their run-start bit, the run table delta[r] = address - slot and the header
+// are written.  A list has at most one run per pixel tile (a window's samples in a tile are
+// consecutive addresses, and two adjacent tiles' runs can only merge), so the table stride is
+// known from the tile count and no counting pass is needed; *max_runs receives the largest count.
+template <int PT>
 __global__ __launch_bounds__(256) void k_real_rc(int64_t nlists, const uint32_t *__restrict__ lk,
                                                   uint16_t *__restrict__ lq, ListHdr *__restrict__ hdrs,
                                                   uint32_t *__restrict__ tabs, int rmax,
                                                   uint32_t *__restrict__ max_runs)
 {
     using G = Geo<PT>;
-    __shared__ int wsum[4];
-    __shared__ int csum[4];
+    __shared__ int wsum[4], vsum[4];
     const int64_t lid = blockIdx.x;
     if (lid >= nlists) return;
     const int l = (int)(lid % G::NLIST);
     const int64_t win = lid / G::NLIST;
     const int64_t e0 = win * G::PER + G::list_off(l);
     const int len = G::list_len(l);
-    const int per = len / 256;                          // consecutive entries per thread
-    const int t = threadIdx.x;
-    const int s0 = t * per;
-    // flags and valid counts of this thread's entries
-    int nflag = 0, nval = 0;
-    uint32_t prev = s0 > 0 ? lk[e0 + s0 - 1] : kInvalidSample;
-    for (int i = 0; i < per; ++i) {
-        const uint32_t k = lk[e0 + s0 + i];
-        const bool valid = k != kInvalidSample;
-        const bool flag = valid && (s0 + i == 0 || k != prev + 1u);
-        nflag += flag ? 1 : 0;
-        nval += valid ? 1 : 0;
-        prev = k;
-    }
-    // block-wide exclusive scan of nflag (fixed order), total of nval
-    int incl = nflag, vincl = nval;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int a = __shfl_up(incl, off, 64), b = __shfl_up(vincl, off, 64);
-        if ((t & 63) >= off) { incl += a; vincl += b; }
-    }
-    if ((t & 63) == 63) { wsum[t >> 6] = incl; csum[t >> 6] = vincl; }
-    __syncthreads();
-    int base = 0, total = 0, vtotal = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (w < (t >> 6)) base += wsum[w];
-        total += wsum[w];
-        vtotal += csum[w];
-    }
-    const int excl = base + incl - nflag;
-    if (PASS == 0) {
-        if (t == 0) atomicMax(max_runs, (uint32_t)total);
-        return;
-    }
-    // second walk: write words and table entries
-    int r = excl - 1;
-    prev = s0 > 0 ? lk[e0 + s0 - 1] : kInvalidSample;
-    for (int i = 0; i < per; ++i) {
-        const int s = s0 + i;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int runs = 0, nvalid = 0;                          // in front of the current piece (uniform)
+    for (int s0 = 0; s0 < len; s0 += 256) {
+        const int s = s0 + t;
         const uint32_t k = lk[e0 + s];
+        const uint32_t prev = s > 0 ? lk[e0 + s - 1] : kInvalidSample;
         const bool valid = k != kInvalidSample;
         const bool flag = valid && (s == 0 || k != prev + 1u);
+        const uint64_t fm = __ballot(flag), vm = __ballot(valid);
+        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+        if (lane == 0) { wsum[wave] = __popcll(fm); vsum[wave] = __popcll(vm); }
+        __syncthreads();
+        int wbase = 0, tot = 0, vtot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wbase += wsum[w];
+            tot += wsum[w];
+            vtot += vsum[w];
+        }
+        __syncthreads();
+        const int r = runs + wbase + below + (flag ? 1 : 0) - 1;     // run of this entry (-1: none yet)
         if (flag) {
-            ++r;
-            tabs[lid * rmax + r] = k - (uint32_t)s;
+            if (r < rmax) tabs[lid * rmax + r] = k - (uint32_t)s;
         }
         const uint16_t q = lq[e0 + s];
         lq[e0 + s] = (uint16_t)((q & 0x7FFFu) | (flag ? 0x8000u : 0u));
-        prev = k;
         // run index in front of each wave's first slot (waves own len / 4 consecutive slots)
         if (s % (len / 4) == 0) hdrs[lid].wbase[s / (len / 4)] = flag ? r - 1 : r;
+        runs += tot;
+        nvalid += vtot;
     }
     if (t == 0) {
-        hdrs[lid].nvalid = (uint32_t)vtotal;
-        hdrs[lid].nruns = (uint32_t)total;
+        hdrs[lid].nvalid = (uint32_t)nvalid;
+        hdrs[lid].nruns = (uint32_t)runs;
+        atomicMax(max_runs, (uint32_t)runs);
     }
 }
 
@@ -1062,7 +1044,8 @@ int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t
 }
 
 template <int PT>
-static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, bool want_rc, hipStream_t stream)
+static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, bool want_rc,
+                            hipStream_t stream)
 {
     using G = Geo<PT>;
     real_free_lists(f);
@@ -1109,27 +1092,27 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
     if (want_rc) {
         const int64_t nlists = f->nwin * G::NLIST;
         CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
-        DevTemp<uint32_t> d_max;
-        CM2_HIP(d_max.alloc(1));
-        CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
-        k_real_rc<PT, 0><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, nullptr, nullptr, 0, d_max);
-        CM2_LAUNCH_OK();
-        uint32_t h_max = 0;
-        CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        CM2_HIP(hipStreamSynchronize(stream));
-        int rmax = (int)((h_max + 63) / 64 * 64);
+        // one run per pixel tile at most (k_real_rc): the run-table stride follows from the tile count
+        int64_t bound = ntiles > 0 ? ntiles : G::N;
+        if (bound > G::N) bound = G::N;
+        int rmax = (int)((bound + 63) / 64 * 64);
         if (rmax < 64) rmax = 64;
-        // the two window-half tables live in LDS beside the exchange buffer: keep the kernel at its
-        // occupancy (PT = 16: 40 KB per workgroup) when they fit, run-coded lists only up to 8 words
-        // per thread
+        // the two window-half tables live in LDS beside the exchange buffer; run-coded lists only
+        // up to 8 table words per thread (2048 runs a list), plain lists beyond that
         if (rmax <= 8 * kT) {
+            DevTemp<uint32_t> d_max;
+            CM2_HIP(d_max.alloc(1));
+            CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
             CM2_HIP(hipMalloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
             CM2_HIP(hipMalloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
-            CM2_HIP(hipMemsetAsync(f->d_hdrs, 0, sizeof(ListHdr) * nlists, stream));
-            k_real_rc<PT, 1><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, f->d_hdrs,
-                                                                   f->d_tabs, rmax, nullptr);
+            k_real_rc<PT><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, f->d_hdrs,
+                                                               f->d_tabs, rmax, d_max);
             CM2_LAUNCH_OK();
+            uint32_t h_max = 0;
+            CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM2_HIP(hipStreamSynchronize(stream));
+            CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel "
+                      "tiles allow", h_max, rmax);
             (void)hipFree(f->d_lst_k);                      // the addresses are now in the run tables
             f->d_lst_k = nullptr;
             f->rmax = rmax;
@@ -1142,12 +1125,12 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
     return 0;
 }
 
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, bool want_rc,
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, bool want_rc,
                           const double *d_v, double *d_out, hipStream_t stream)
 {
     if (f->list_plan != plan_id || f->list_mode == 0 || f->want_rc != want_rc) {
-        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, plan_id, want_rc, stream)
-                                  : real_build_lists<32>(f, d_idx, plan_id, want_rc, stream)))
+        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, plan_id, ntiles, want_rc, stream)
+                                  : real_build_lists<32>(f, d_idx, plan_id, ntiles, want_rc, stream)))
             return rc;
         f->want_rc = want_rc;          // (a plan whose run tables do not fit stays on plain lists)
     }

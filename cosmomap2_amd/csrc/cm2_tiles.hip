@@ -634,6 +634,7 @@ extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 }
 
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t) { return t ? t->plan_id : 0; }
+extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t) { return t ? t->ntiles : 0; }
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid : 0; }
 
 // Tile indices bounding `ngroups` consecutive groups of tiles whose PIXEL boundaries are the same on

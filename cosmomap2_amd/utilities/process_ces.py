@@ -31,6 +31,29 @@ _FIELDS = ("counts", "cosine", "sine", "cos2", "sin2", "sincos")
 _NEED = {1: ("counts",), 2: ("cos2", "sin2", "sincos"), 3: _FIELDS}
 
 
+class _NewPixel(tuple):
+    """``(npix, obspix)`` whose second element is produced on first access."""
+
+    def __new__(cls, npix, owner):
+        self = tuple.__new__(cls, (npix, None))
+        self._owner = owner
+        return self
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self)[i]
+        return self._owner.obspix if i in (1, -1) else tuple.__getitem__(self, i)
+
+    def __iter__(self):
+        yield tuple.__getitem__(self, 0)
+        yield self._owner.obspix
+
+    def __eq__(self, other):
+        return tuple(iter(self)) == tuple(other)
+
+    __hash__ = None
+
+
 class ProcessTimeSamples(object):
     """
     ``ProcessTimeSamples(pixs, npix, obspix=None, pol=1, phi=None, w=None, ground=None,
@@ -58,11 +81,10 @@ class ProcessTimeSamples(object):
         self.threshold = threshold_cond
         self._allreduce = allreduce
         self._host = {}
-        if obspix is None:
-            # the reference sizes this by samples (:67-68); the pixel count is what the
-            # compaction indexes, so that is what is used here
-            obspix = np.arange(self.oldnpix)
-        self.obspix = np.asarray(obspix)
+        # (obspix=None: the reference sizes the default by samples, :67-68; the pixel count is what
+        # the compaction indexes, so arange(npix) is what stands in -- materialised on first use)
+        self._obspix = None if obspix is None else np.asarray(obspix)
+        self._obspix_pending = False
         if ground is not None:                             # :70-73
             neg = np.asarray(ground) < 0
             ground[neg] = -1
@@ -110,7 +132,36 @@ class ProcessTimeSamples(object):
                 self._allreduce(out[k])
         return out
 
+    # Host copies of per-pixel results (mask, old2new, obspix) are made when they are first read:
+    # the device-resident pipeline (SparseLO, M_BD, the tile plan) never needs them, and at nside
+    # 256 fetching and re-indexing them costs more than the kernels that produced them.
+    @property
+    def obspix(self):
+        if self._obspix is None:
+            self._obspix = np.arange(self.oldnpix)
+        if self._obspix_pending:
+            self._obspix = self._obspix[:self.oldnpix][D.to_host(self._d_keep) != 0]
+            self._obspix_pending = False
+        return self._obspix
+
+    @obspix.setter
+    def obspix(self, value):
+        self._obspix = np.asarray(value)
+        self._obspix_pending = False
+
     def __getattr__(self, name):
+        if name == "mask":                                  # :491, :544-555
+            keep = self.__dict__.get("_d_keep")
+            if keep is None:
+                raise AttributeError(name)
+            self.__dict__["mask"] = np.where(D.to_host(keep) != 0)[0]
+            return self.__dict__["mask"]
+        if name == "old2new":
+            o2n = self.__dict__.get("_d_old2new")
+            if o2n is None:
+                raise AttributeError(name)
+            self.__dict__["old2new"] = D.to_host(o2n).astype(np.int64)
+            return self.__dict__["old2new"]
         # lazily fetched NumPy views of device-side results
         if name in _FIELDS:
             dw = self.__dict__.get("_dev_weights", {})
@@ -132,8 +183,9 @@ class ProcessTimeSamples(object):
 
     @property
     def get_new_pixel(self):
-        """(number of pixels kept, their external ids) -- process_ces.py:90-92."""
-        return self.__new_npix, self.obspix
+        """(number of pixels kept, their external ids) -- process_ces.py:90-92.  The ids are
+        fetched from the device when the second element is read."""
+        return _NewPixel(self.__new_npix, self)
 
     # ----------------------------------------------------------- reference steps ---
     def initializeweights(self, phi=None, w=None):
@@ -145,7 +197,7 @@ class ProcessTimeSamples(object):
                   D.ptr(sums["cos2"]), D.ptr(sums["sin2"]), D.ptr(sums["sincos"]),
                   float(self.threshold), D.ptr(keep), D.stream())
         self._d_keep = keep
-        self.mask = np.where(D.to_host(keep) != 0)[0]
+        self.__dict__.pop("mask", None)
 
     def new_repixelization(self):
         """Compact the pixel numbering to the masked set, preserving order (:192-349)."""
@@ -155,7 +207,7 @@ class ProcessTimeSamples(object):
                   ctypes.byref(newn), D.stream())
         self._d_old2new = o2n
         self.__new_npix = int(newn.value)
-        self.old2new = D.to_host(o2n).astype(np.int64)
+        self.__dict__.pop("old2new", None)
         dw = {}
         for k in _FIELDS:
             src = self._raw_weights[k]
@@ -170,7 +222,7 @@ class ProcessTimeSamples(object):
         self._dev_weights = dw
         self._raw_weights = None
         self._host = {k: v for k, v in self._host.items() if k in ("cos", "sin")}
-        self.obspix = self.obspix[:self.oldnpix][D.to_host(self._d_keep) != 0]
+        self._obspix_pending = True                         # compacted when first read
         self.n_removed_pix = self.oldnpix - self.__new_npix
 
     repixelization = new_repixelization
