@@ -51,6 +51,15 @@ struct cm2_tiles {
     uint32_t *d_fx_tent = nullptr;      // [ntail entries] entries of the runs kept out of the groups
     double *d_fx_ta = nullptr, *d_fx_tb = nullptr;
     int64_t fx_ngroups = 0, fx_nslices = 0;
+    // hot tiles of the fixed-order P^T: a tile that is ONE pixel with very many samples (a stare at
+    // a source; the balanced tiling makes such a pixel a tile of its own) is reduced by many
+    // workgroups, each summing a fixed range of kHotChunk consecutive samples of the bucket, and
+    // the range sums are added in time order (cm2_tiles_fixed.hip)
+    std::vector<int64_t> hot_tile, hot_chunk0;   // tile index, first chunk of every hot tile (+ total)
+    uint8_t *d_hot_flag = nullptr;               // [ntiles]
+    int64_t *d_hot_range = nullptr;              // [chunks][2] first / one-past-last TB position
+    int64_t *d_hot_tiles = nullptr;              // [nhot][3] first pixel, first chunk, chunk count
+    double *d_hot_partial = nullptr;             // [chunks][3]
 };
 
 namespace cm2 {

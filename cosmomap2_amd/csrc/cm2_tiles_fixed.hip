@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
     const uint32_t *__restrict__ tent, const double *__restrict__ ta,
     const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out,
-    uint32_t chunk_min)
+    uint32_t chunk_min, const uint8_t *__restrict__ hot)
 {
     constexpr int D = kFxDepth;
     constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     double *part = vbuf + VPT * kFxT;                    // 3 x kFxMaxChunks chunk sums of hot runs
     const int tid = threadIdx.x;
     const int b = tile0 + blockIdx.x;
+    if (hot && hot[b]) return;                           // reduced by k_Pt_hot (many workgroups)
     const int64_t p0 = tile_p0[b];
     const int64_t np = tile_p0[b + 1] - p0;
     const int nvals = (int)(np * POL);
@@ -297,6 +298,91 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     for (int i = tid; i < nvals; i += kFxT) o[i] = tile[i];
 }
 
+// ------------------------------------------------------------------- hot tiles ------
+// A tile that is one pixel with very many samples: its bucket is cut into ranges of kHotChunk
+// consecutive samples; one workgroup per range, thread t adding the terms at positions t, t + 256,
+// ... of the range in that order, the 256 thread sums combined by a fixed halving tree; k_hot_combine
+// then adds the range sums of a tile in time order and writes the pixel.  Every boundary and every
+// order depends on the bucket's length only: reproducible bit for bit, independent of the rest of
+// the hit map; a regrouping of the serial sum, ~1e-16 relative per level away from it.
+constexpr int kHotChunk = 16384, kHotT = 256;
+constexpr int64_t kHotMin = 2 * kHotChunk;              // samples that make a one-pixel tile hot
+
+template <int POL, bool HALF>
+__global__ __launch_bounds__(kHotT) void k_Pt_hot(const int64_t *__restrict__ range, int64_t c0,
+                                                   const uint16_t *__restrict__ pl,
+                                                   const double *__restrict__ a_tb,
+                                                   const double *__restrict__ b_tb,
+                                                   const double *__restrict__ v_tb,
+                                                   double *__restrict__ partial)
+{
+    __shared__ double red[3][kHotT];
+    const int64_t c = c0 + blockIdx.x;
+    const int64_t k0 = range[2 * c], k1 = range[2 * c + 1];
+    const int t = threadIdx.x;
+    double sv = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t k = k0 + t; k < k1; k += kHotT) {
+        const double v = v_tb[k];
+        sv += v;
+        if (POL > 1) {
+            double cc, ss;
+            if (HALF) {
+                const double h = a_tb[k], h2 = h * h, inv = 1.0 / (1.0 + h2);
+                cc = (1.0 - h2) * inv;
+                ss = (h + h) * inv;
+                if (pl[k] & 0x8000u) cc = -cc;
+            } else {
+                cc = a_tb[k];
+                ss = b_tb[k];
+            }
+            s1 += v * cc;
+            s2 += v * ss;
+        }
+    }
+    red[0][t] = sv;
+    red[1][t] = s1;
+    red[2][t] = s2;
+    __syncthreads();
+    for (int h = kHotT / 2; h >= 1; h >>= 1) {
+        if (t < h) {
+            red[0][t] += red[0][t + h];
+            red[1][t] += red[1][t + h];
+            red[2][t] += red[2][t + h];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        partial[3 * c] = red[0][0];
+        partial[3 * c + 1] = red[1][0];
+        partial[3 * c + 2] = red[2][0];
+    }
+}
+
+template <int POL>
+__global__ void k_hot_combine(const int64_t *__restrict__ tiles, int64_t h0, int64_t nh,
+                              const double *__restrict__ partial, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh) return;
+    const int64_t p0 = tiles[3 * (h0 + i)], c0 = tiles[3 * (h0 + i) + 1], nc = tiles[3 * (h0 + i) + 2];
+    double sv = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t c = c0; c < c0 + nc; ++c) {               // range sums in time order
+        sv += partial[3 * c];
+        s1 += partial[3 * c + 1];
+        s2 += partial[3 * c + 2];
+    }
+    if (POL == 1) {
+        out[p0] = sv;
+    } else if (POL == 2) {
+        out[2 * p0] = s1;
+        out[2 * p0 + 1] = s2;
+    } else {
+        out[3 * p0] = sv;
+        out[3 * p0 + 1] = s1;
+        out[3 * p0 + 2] = s2;
+    }
+}
+
 // ------------------------------------------------------------------- plan -----------
 // keys of the per-slice sort: (global slice number << 16) | pixel in tile; value = list entry
 __global__ __launch_bounds__(256) void k_fx_keys(int64_t nvalid, int64_t ntiles, int S, uint32_t qmask,
@@ -412,8 +498,74 @@ size_t fx_lds_bytes(const cm2_tiles *t, int S)
     return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT + 3 * (size_t)kFxMaxChunks);
 }
 
+void hot_release(cm2_tiles *t)
+{
+    void **ptrs[] = {(void **)&t->d_hot_flag, (void **)&t->d_hot_range, (void **)&t->d_hot_tiles,
+                     (void **)&t->d_hot_partial};
+    for (void **q : ptrs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    t->hot_tile.clear();
+    t->hot_chunk0.clear();
+}
+
+// one-pixel tiles with at least kHotMin samples, their sample ranges and the scratch of range sums
+int hot_plan(cm2_tiles *t, hipStream_t st)
+{
+    hot_release(t);
+    std::vector<uint8_t> flag((size_t)t->ntiles, 0);
+    std::vector<int64_t> range, tiles;
+    t->hot_chunk0.assign(1, 0);
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        const int64_t n = t->tile_off[(size_t)b + 1] - t->tile_off[(size_t)b];
+        if (t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b] != 1 || n < kHotMin) continue;
+        flag[(size_t)b] = 1;
+        const int64_t c0 = (int64_t)range.size() / 2;
+        for (int64_t k = t->tile_off[(size_t)b]; k < t->tile_off[(size_t)b + 1]; k += kHotChunk) {
+            range.push_back(k);
+            range.push_back(k + kHotChunk < t->tile_off[(size_t)b + 1] ? k + kHotChunk : t->tile_off[(size_t)b + 1]);
+        }
+        tiles.push_back(t->tile_p0[(size_t)b]);
+        tiles.push_back(c0);
+        tiles.push_back((int64_t)range.size() / 2 - c0);
+        t->hot_tile.push_back(b);
+        t->hot_chunk0.push_back((int64_t)range.size() / 2);
+    }
+    if (t->hot_tile.empty()) return 0;
+    CM2_HIP(hipMalloc(&t->d_hot_flag, flag.size()));
+    CM2_HIP(hipMalloc(&t->d_hot_range, sizeof(int64_t) * range.size()));
+    CM2_HIP(hipMalloc(&t->d_hot_tiles, sizeof(int64_t) * tiles.size()));
+    CM2_HIP(hipMalloc(&t->d_hot_partial, sizeof(double) * 3 * (range.size() / 2)));
+    CM2_HIP(hipMemcpyAsync(t->d_hot_flag, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(hipMemcpyAsync(t->d_hot_range, range.data(), sizeof(int64_t) * range.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(hipMemcpyAsync(t->d_hot_tiles, tiles.data(), sizeof(int64_t) * tiles.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <int POL, bool HALF>
+int hot_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
+               int64_t tile_hi, hipStream_t stream)
+{
+    // hot tiles inside [tile_lo, tile_hi): they are listed in ascending tile order
+    int64_t h0 = 0, h1 = (int64_t)t->hot_tile.size();
+    while (h0 < h1 && t->hot_tile[(size_t)h0] < tile_lo) ++h0;
+    while (h1 > h0 && t->hot_tile[(size_t)h1 - 1] >= tile_hi) --h1;
+    if (h1 <= h0) return 0;
+    const int64_t c0 = t->hot_chunk0[(size_t)h0], c1 = t->hot_chunk0[(size_t)h1];
+    k_Pt_hot<POL, HALF><<<(unsigned)(c1 - c0), kHotT, 0, stream>>>(
+        t->d_hot_range, c0, t->d_pl, HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, t->d_hot_partial);
+    CM2_LAUNCH_OK();
+    k_hot_combine<POL><<<(unsigned)((h1 - h0 + 63) / 64), 64, 0, stream>>>(t->d_hot_tiles, h0, h1 - h0,
+                                                                           t->d_hot_partial, d_out);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
 void fx_release(cm2_tiles *t)
 {
+    hot_release(t);
     void **ptrs[] = {(void **)&t->d_fx_slice0, (void **)&t->d_fx_meta, (void **)&t->d_fx_gent,
                      (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
                      (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb};
@@ -563,8 +715,11 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
         t->d_fx_tb, d_tod_tb, d_out,
-        t->pt_fixed == 2 ? 0xFFFFFFFFu : (uint32_t)kFxChunkMinDefault);
+        t->pt_fixed == 2 ? 0xFFFFFFFFu : (uint32_t)kFxChunkMinDefault,
+        t->pt_fixed == 2 ? nullptr : t->d_hot_flag);
     CM2_LAUNCH_OK();
+    if (t->pt_fixed != 2 && t->d_hot_flag)
+        return hot_launch<POL, HALF>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
     return 0;
 }
 
@@ -641,6 +796,8 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
             }
         }
     }
+    if (!t->d_hot_flag && t->hot_chunk0.empty())
+        if (int rc = hot_plan(t, st)) return rc;
     mark.ok = true;
     *use = true;
     return 0;
