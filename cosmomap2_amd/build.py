@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=
 
 
 # translation units whose results are not compared bit for bit (FFT butterflies): FMA allowed
-FMA_OK = {"cm2_fft.hip"}
+FMA_OK = {"cm2_fft.hip", "cm2_fft_real.hip"}
 
 
 def _newer(target, deps):
