@@ -113,9 +113,37 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
     # launches.  When the value says "converged", x is returned as it is and the speculative
     # work is simply dropped (it wrote z, p, q and two scalars only), so callback invocations,
     # return values and iteration counts are those of scipy's recurrence.
-    rr_pinned = torch.empty(1, dtype=torch.float64).pin_memory()
-    rr_event = torch.cuda.Event()
+    rr_pinned, rr_event = _deferred_acquire()
     reduce_dev = getattr(sync, "reduce_", None) if sync is not None else None
+    try:
+        return _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callback, host_io,
+                        sync, dot_reduce, reduce_dev, rr_pinned, rr_event)
+    finally:
+        _deferred_release(rr_pinned, rr_event)
+
+
+# Pinned 8-byte buffers and events of the deferred reads: allocating page-locked memory costs from
+# 0.1 ms to tens of milliseconds, so they are kept and reused; a pool rather than one buffer because
+# a solve may run inside another one's operator (InverseLO inside a product).
+_deferred_pool = []
+
+
+def _deferred_acquire():
+    if _deferred_pool:
+        return _deferred_pool.pop()
+    return torch.empty(1, dtype=torch.float64).pin_memory(), torch.cuda.Event()
+
+
+def _deferred_release(buf, ev):
+    if len(_deferred_pool) < 8:
+        _deferred_pool.append((buf, ev))
+
+
+def _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callback, host_io, sync,
+             dot_reduce, reduce_dev, rr_pinned, rr_event):
+    """The iteration of :func:`cg` (see there)."""
+    rho = [scal[0:1], scal[1:2]]
+    pq, rr = scal[2:3], scal[3:4]
 
     def post_rr():
         if reduce_dev is not None:
