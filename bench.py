@@ -680,10 +680,18 @@ def main():
                          dtype=torch.float64)
         _, med_u = ev_time(lambda: A_u * x_u, reps)
         T_u = L._sparse_tiles(P_u)
+        tb_u, tb2_u, out_u = D.empty(T_u.nvalid), D.empty(T_u.nvalid), D.empty(pol * n_u)
+        st_u = {}
+        _, st_u["P"] = ev_time(lambda: _hip.call("cm2_P_tiles_apply", T_u.h, D.ptr(x_u), D.ptr(tb_u), D.stream()), 5)
+        if args.toeplitz == "fused":
+            _, st_u["N^-1"] = ev_time(lambda: _hip.call("cm2_noise_apply_tiles", N._noise.h, T_u.h, D.ptr(tb_u),
+                                                        D.ptr(tb2_u), D.stream()), 5)
+        _, st_u["P^T"] = ev_time(lambda: _hip.call("cm2_Pt_tiles_apply", T_u.h, D.ptr(tb_u), D.ptr(out_u), D.stream()), 5)
+        del tb_u, tb2_u, out_u
         uneven = {"pointing": "50 % of the samples on the first tenth of the map, the rest uniform",
                   "tiles": int(T_u.ntiles), "widest_tile_pixels": int(T_u.tile_pixels),
                   "ms_per_step": round(med_u, 4), "value": round(nt / (med_u * 1e-3), 1),
-                  "unit": "TOD samples/s"}
+                  "unit": "TOD samples/s", "stages_ms": {k: round(v, 4) for k, v in st_u.items()}}
         del A_u, P_u, ces_u, pix_u, x_u, T_u
         # a stare at a source: 5 % of the samples on ONE pixel.  The default fixed-order P^T sums
         # such a run in fixed chunks (reproducible); "exact" walks it term by term with one thread.

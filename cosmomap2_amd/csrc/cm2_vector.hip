@@ -246,32 +246,36 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
     if (int rc = cm2_dot(n, r.p, r.p, rr, work, stream)) return rc;
     if (int rc = post(rr)) return rc;
     int cur = 0;
-    // z = M r, rho, p, q = A p, p.q of iteration `it`: nothing here writes x or r
-    auto ahead = [&](int64_t it) -> int {
+    // z = M r, rho, p of iteration `it` (cheap: always queued ahead of the stop test) and
+    // q = A p, p.q (the matvec: queued ahead unless convergence is predicted); nothing here writes
+    // x or r
+    auto ahead_cheap = [&](int64_t it) -> int {
         const double *zz = r.p;
         if (M) {
             if (M(M_ctx, r.p, z.p, stream_)) { set_error("cm2_pcg: the preconditioner callback failed"); return 1; }
             zz = z.p;
         }
         if (int rc = cm2_dot(n, r.p, zz, rho[cur], work, stream)) return rc;
-        if (it > 0) {
-            if (int rc = cm2_pcg_update_p(n, rho[cur], rho[1 - cur], zz, p.p, stream_)) return rc;
-        } else {
-            CM2_HIP(hipMemcpyAsync(p.p, zz, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
-        }
+        if (it > 0) return cm2_pcg_update_p(n, rho[cur], rho[1 - cur], zz, p.p, stream_);
+        CM2_HIP(hipMemcpyAsync(p.p, zz, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+        return 0;
+    };
+    auto ahead_matvec = [&]() -> int {
         if (A(A_ctx, p.p, q.p, stream_)) { set_error("cm2_pcg: the operator callback failed"); return 1; }
         return cm2_dot(n, p.p, q.p, pq, work, stream);
     };
-    // Running ahead costs one iteration of GPU time when the stop test then says "converged", so it
-    // is skipped when the last two residuals the host has seen predict convergence at this test
-    // (geometric extrapolation, a factor 10 in the norm to spare); results never depend on it.
+    // Running ahead with the matvec costs one iteration of GPU time when the stop test then says
+    // "converged", so it is skipped when the last two residuals the host has seen predict
+    // convergence at this test (geometric extrapolation, a factor 10 in the norm to spare); results
+    // never depend on it.
     double known1 = -1.0, known2 = -1.0;                   // the last two ||r||^2 seen (newest first)
     for (int64_t it = 0; it < maxiter; ++it) {
         double predicted = INFINITY;
         if (known1 >= 0.0) predicted = (known2 > 0.0) ? known1 * (known1 / known2) : known1;
         const bool run_ahead = !(predicted <= 100.0 * atol * atol);
+        if (int rc = ahead_cheap(it)) return rc;
         if (run_ahead)
-            if (int rc = ahead(it)) return rc;
+            if (int rc = ahead_matvec()) return rc;
         // ---- the state before this iteration: report it, then the stop test
         CM2_HIP(hipEventSynchronize(df.ev));
         h = *df.host;
@@ -283,7 +287,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         }
         if (sqrt(h) < atol) return 0;
         if (!run_ahead)
-            if (int rc = ahead(it)) return rc;
+            if (int rc = ahead_matvec()) return rc;
         if (int rc = cm2_pcg_update_xr(n, rho[cur], pq, p.p, q.p, d_x, r.p, rr, work, stream_)) return rc;
         cur = 1 - cur;
         if (int rc = post(rr)) return rc;

@@ -161,8 +161,9 @@ def _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callba
     dot_into(rr, r, r)
     post_rr()
 
-    def ahead():
-        """z = M r, rho, p, q = A p, p.q of iteration `iteration` (nothing here writes x or r)."""
+    def ahead_cheap():
+        """z = M r, rho, p of iteration `iteration`: per-pixel and vector kernels (a few per cent of
+        an iteration), always queued before the stop test's value is waited for."""
         nonlocal p
         z = _apply(M, r) if M is not None else r
         dot_into(rho[cur], r, z)
@@ -171,15 +172,20 @@ def _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callba
                                             D.ptr(p), st()))
         else:
             p = z.clone()
+
+    def ahead_matvec():
+        """q = A p, p.q of iteration `iteration` (nothing here or above writes x or r)."""
         q = _apply(A, p)
         dot_into(pq, p, q)
         return q
 
-    # Running ahead costs one iteration's worth of GPU time when the stop test then says
-    # "converged" (the queued kernels cannot be recalled), so it is skipped when the two last
+    # Running ahead with the matvec costs one iteration's worth of GPU time when the stop test then
+    # says "converged" (the queued kernels cannot be recalled), so it is skipped when the two last
     # residuals known to the host predict convergence at this test (geometric extrapolation, with a
-    # factor 10 in the norm to spare): that iteration waits first, as a plain loop would.  The
-    # prediction only chooses between two orders of the same operations; results never depend on it.
+    # factor 10 in the norm to spare): that iteration queues only the cheap kernels ahead and the
+    # matvec after the wait -- what the GPU then waits for is one launch, not the whole host side
+    # of an iteration.  The prediction only chooses between two orders of the same operations;
+    # results never depend on it.
     p = None
     cur = 0
     known = []                                       # ||r||^2 values the host has seen
@@ -187,13 +193,14 @@ def _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callba
         predicted = known[-1] * (known[-1] / known[-2]) if len(known) >= 2 and known[-2] > 0 \
             else (known[-1] if known else float("inf"))
         run_ahead = not (predicted <= 100.0 * atol * atol)
-        q = ahead() if run_ahead else None
+        ahead_cheap()
+        q = ahead_matvec() if run_ahead else None
         rr_host = wait_rr()                          # ||r||^2 of the state before this iteration
         known.append(rr_host)
         if math.sqrt(rr_host) < atol:
             return (D.to_host(x) if host_io else x), 0
         if q is None:
-            q = ahead()
+            q = ahead_matvec()
         _hip.check(lib.cm2_pcg_update_xr(n, D.ptr(rho[cur]), D.ptr(pq), D.ptr(p), D.ptr(q),
                                          D.ptr(x), D.ptr(r), D.ptr(rr), D.ptr(work), st()))
         cur = 1 - cur

@@ -1267,6 +1267,42 @@ def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
     assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12
 
 
+@pytest.mark.parametrize("kernel,lists", [("pair", "plain"), ("real16", "rc"), ("real16", "plain"),
+                                          ("real32", "plain"), ("real32", "rc")])
+@pytest.mark.parametrize("tp,lam,npix", [(1024, 300, 70000), (2048, 2049, 70000), (64, 40, 200000)])
+def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp, lam, npix):
+    """Every overlap-save kernel behind the switches (CM2_OS_KERNEL = pair | real16 | real32,
+    CM2_OS_LISTS = rc | plain) on the tile order AND on the time order against the direct sum /
+    rocFFT: the segment-pair kernel of round 2, the one-real-window kernel with 16 and 32 points
+    per thread, run-coded and plain lists; the last case has 3125 tiles, more address runs per list
+    than the run tables hold, where run-coding falls back to plain lists by itself."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    monkeypatch.setenv("CM2_OS_KERNEL", kernel)
+    monkeypatch.setenv("CM2_OS_LISTS", lists)
+    pol, nt, nblk = 3, 240000, 5
+    d, pairs, phi, t, diag = make_problem(oracle, 900 + lam, nt, npix, nblk, pol, flag_frac=0.07)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+    L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+    sizes = [100000, 60000, 70000, 7000, 3000]
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
+    x = np.random.default_rng(1).standard_normal(pol * npix)
+    Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+    Nd = cm.I.BlockLO(sizes, bands, offdiag=True, method=(1 if lam <= 300 else 2))
+    tod = P * x
+    want = Nd * tod
+    assert rel_l2(Nf * tod, want) < 1e-12                                  # time order
+    exact = P.T * want
+    assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12              # tile order
+    info = Nf.tile_kernel_info()
+    assert info["os_kernel"] == kernel
+    many_tiles = npix // tp > 2048
+    assert info["os_lists"] == ("plain" if lists == "plain" or kernel == "pair" or many_tiles
+                                else "run-coded")
+
+
 def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
     """The address lists are sorted in chunks of at most 2^30 entries (hipCUB counts in int);
     with the chunk forced down to 3 segment pairs the operator must not change."""
