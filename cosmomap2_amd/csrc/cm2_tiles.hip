@@ -499,7 +499,6 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         // not spill a 513th tile; a tile ends when the next pixel would exceed the target or the
         // width tile_pixels (a single pixel heavier than the target is a tile of its own)
         const int64_t nvalid = off[(size_t)t->ntiles];
-        const int64_t target = (int64_t)(1.02 * (double)nvalid / (double)t->ntiles) + 1;
         // cuts every rank of a sharded run has in common, whatever its own hit map: the group
         // boundaries of cm2_tiles_group_tiles (the pieces of the map that are all-reduced while
         // the next piece is back-projected) -- the uniform tiling's tile boundaries nearest to
@@ -510,21 +509,34 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
             forced[c] = (ntu * c / 8) * tile_pixels;
             if (forced[c] > npix || c == 8) forced[c] = npix;
         }
-        int fc = 1;
-        std::vector<int64_t> p0v(1, 0);
-        int64_t acc = 0, start = 0;
-        for (int64_t p = 0; p < npix; ++p) {
-            const int64_t h = hits[(size_t)p];
-            while (fc < 8 && forced[fc] < p) ++fc;
-            const bool at_cut = fc < 8 && forced[fc] == p;
-            if (p > start && (acc + h > target || p - start >= tile_pixels || at_cut)) {
-                p0v.push_back(p);
-                start = p;
-                acc = 0;
+        // The fixed-order P^T keeps 512 workgroups resident (two per CU): tiles of equal load
+        // finish in whole rounds of 512, so 737 tiles cost as much as 1024.  The width limit makes
+        // a sparse region take more tiles than its load asks for; the target load is therefore
+        // lowered (n = 1, 2, 3, 4 times the uniform count) until the cut fits n x the uniform
+        // count, with 2 % slack so that rounding does not spill one more tile; a tile ends when the
+        // next pixel would exceed the target or the width tile_pixels (a single pixel heavier than
+        // the target is a tile of its own).
+        std::vector<int64_t> p0v;
+        const int64_t base = t->ntiles;
+        for (int mult = 1; mult <= 4; ++mult) {
+            const int64_t target = (int64_t)(1.02 * (double)nvalid / (double)(base * mult)) + 1;
+            int fc = 1;
+            p0v.assign(1, 0);
+            int64_t acc = 0, start = 0;
+            for (int64_t p = 0; p < npix; ++p) {
+                const int64_t h = hits[(size_t)p];
+                while (fc < 8 && forced[fc] < p) ++fc;
+                const bool at_cut = fc < 8 && forced[fc] == p;
+                if (p > start && (acc + h > target || p - start >= tile_pixels || at_cut)) {
+                    p0v.push_back(p);
+                    start = p;
+                    acc = 0;
+                }
+                acc += h;
             }
-            acc += h;
+            p0v.push_back(npix);
+            if ((int64_t)p0v.size() - 1 <= base * mult || base % 512 != 0) break;
         }
-        p0v.push_back(npix);
         t->ntiles = (int64_t)p0v.size() - 1;
         t->tile_p0 = p0v;
         CM2_HIP(d_p0.alloc(p0v.size()));
