@@ -17,7 +17,8 @@ int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream
 // same, with input and output TODs addressed through d_idx[t] (tile-bucketed order of the tile
 // plan `plan_id`; the address lists are rebuilt when the plan changes)
 // ntiles: pixel tiles of the plan (bounds the address runs of a list; 0 = unknown)
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles,
+// nvalid: doubles in the two tile-order buffers (0 = unknown)
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
                            const double *d_v, double *d_out, hipStream_t stream);
 int64_t fused_os_length(const FusedOS *f);
 void fused_os_destroy(FusedOS *f);
@@ -31,8 +32,8 @@ struct RealOS;
 int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
                    const std::vector<int64_t> &off, hipStream_t stream);
 int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream);
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, bool want_rc,
-                          const double *d_v, double *d_out, hipStream_t stream);
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
+                          bool want_rc, const double *d_v, double *d_out, hipStream_t stream);
 double real_os_tile_bytes_per_sample(const RealOS *f);
 int real_os_list_mode(const RealOS *f);
 int64_t real_os_window(const RealOS *f);

@@ -416,16 +416,41 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
 }
 
 // MODE 0: time order; 1: plain lists; 2: run-coded lists.  TPT: run-table words per thread (RC).
-template <int PT, int MODE, int TPT>
+// BUF: the TOD buffers are addressed through buffer descriptors of `nbytes` bytes -- an entry
+// without a sample carries the address 0xFFFFFFFF, whose byte offset lies outside the descriptor:
+// such a load returns 0 and such a store is dropped by the hardware, so the gathers need no
+// address clamp and no zeroing select and the result stores no branch (48 exec-masked blocks in
+// the flat form).  Flat addressing is kept for buffers of 4 GB and more.
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+
+template <int PT, int MODE, int TPT, bool BUF>
 __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const WinDesc *__restrict__ wins, int nwin, const double2 *__restrict__ Wtw,
     const double2 *Wtw_inv, const double2 *__restrict__ AB, const uint32_t *__restrict__ lst_k,
     const uint16_t *__restrict__ lst_q, const ListHdr *__restrict__ hdrs,
     const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v,
-    double *__restrict__ out OS_STAMP_PARAM)
+    double *__restrict__ out, uint32_t nbytes OS_STAMP_PARAM)
 {
     using G = Geo<PT>;
     constexpr int N = G::N, H = PT / 2;
+    __amdgpu_buffer_rsrc_t v_rs, o_rs;
+    if constexpr (BUF) {
+        v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(v), 0, (int)nbytes, 0x00020000);
+        o_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)nbytes, 0x00020000);
+    }
+    // sample at tile-order address k (0xFFFFFFFF: none)
+    auto gather = [&](uint32_t k) -> double {
+        if constexpr (BUF) {
+            const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(v_rs, k * 8u, 0, 0);
+            return __builtin_bit_cast(double, r);
+        } else {
+            return ld_gather(v + (k != kInvalidSample ? k : 0u));
+        }
+    };
+    auto keep = [&](uint32_t k, double x) -> double {        // value staged for entry k
+        if constexpr (BUF) return x;
+        return k != kInvalidSample ? x : 0.0;
+    };
     extern __shared__ double buf[];
     uint32_t *__restrict__ tab_lds = reinterpret_cast<uint32_t *>(buf + G::LDSD);   // RC: 2 x rmax words
     const int t = threadIdx.x;
@@ -512,7 +537,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < PT; ++u) va[u] = ld_gather(v + ((qa[u] & 0x8000u) ? 0u : ka[u]));
+            for (int u = 0; u < PT; ++u) va[u] = gather((qa[u] & 0x8000u) ? kInvalidSample : ka[u]);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < PT; ++u) vb[u] = ld_gather(v + ((qb[u] & 0x8000u) ? 0u : kb[u]));
+            for (int u = 0; u < PT; ++u) vb[u] = gather((qb[u] & 0x8000u) ? kInvalidSample : kb[u]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -592,14 +617,14 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         __builtin_amdgcn_sched_barrier(0);
         double vv[PT];
 #pragma unroll
-        for (int u = 0; u < PT; ++u) vv[u] = ld_gather(v + (ka[u] != kInvalidSample ? ka[u] : 0u));
+        for (int u = 0; u < PT; ++u) vv[u] = gather(ka[u]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = ka[u] != kInvalidSample ? vv[u] : 0.0;
+        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = keep(ka[u], vv[u]);
         if constexpr (MODE == 2) rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PT; ++u) vv[u] = ld_gather(v + (kb[u] != kInvalidSample ? kb[u] : 0u));
+        for (int u = 0; u < PT; ++u) vv[u] = gather(kb[u]);
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
@@ -612,7 +637,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = kb[u] != kInvalidSample ? vv[u] : 0.0;
+        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = keep(kb[u], vv[u]);
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
@@ -739,8 +764,13 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
 #pragma unroll
             for (int u = 0; u < ER; ++u) rv[u] = buf[qs[u] & 0x7FFFu];
 #pragma unroll
-            for (int u = 0; u < ER; ++u)
-                if (ks[u] != kInvalidSample) st_result(out + ks[u], rv[u]);
+            for (int u = 0; u < ER; ++u) {
+                if constexpr (BUF) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, rv[u]), o_rs, ks[u] * 8u, 0, 0);
+                } else {
+                    if (ks[u] != kInvalidSample) st_result(out + ks[u], rv[u]);
+                }
+            }
         }
     }
     OS_STAMP(5);
@@ -1010,37 +1040,47 @@ int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
     return 0;
 }
 
-template <int PT, int MODE, int TPT>
-static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream)
+template <int PT, int MODE, int TPT, bool BUF>
+static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, uint32_t nbytes, hipStream_t stream)
 {
     using G = Geo<PT>;
     const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE == 2 ? sizeof(uint32_t) * 2 * (size_t)f->rmax : 0);
     static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<PT, MODE, TPT>, lds, granted));
+    CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<PT, MODE, TPT, BUF>, lds, granted));
     if (f->nwin == 0) return 0;
     const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
-    k_os_real<PT, MODE, TPT><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
-                                                        f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out OS_STAMP_ARG);
+    k_os_real<PT, MODE, TPT, BUF><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
+                                                             f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out,
+                                                             nbytes OS_STAMP_ARG);
     CM2_LAUNCH_OK();
     return 0;
 }
 
+// nvalid: doubles in the tile-order buffers (0 = unknown: flat addressing)
 template <int PT>
-static int real_launch(const RealOS *f, int mode, const double *d_v, double *d_out, hipStream_t stream)
+static int real_launch(const RealOS *f, int mode, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream)
 {
-    if (mode == 0) return real_launch_t<PT, 0, 1>(f, d_v, d_out, stream);
-    if (mode == 1) return real_launch_t<PT, 1, 1>(f, d_v, d_out, stream);
+    if (mode == 0) return real_launch_t<PT, 0, 1, false>(f, d_v, d_out, 0, stream);
+    // (CM2_OS_FLAT: flat addressing for A/B timing)
+    const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !getenv("CM2_OS_FLAT");
+    const uint32_t nbytes = buf ? (uint32_t)(nvalid * 8) : 0u;
+    if (mode == 1)
+        return buf ? real_launch_t<PT, 1, 1, true>(f, d_v, d_out, nbytes, stream)
+                   : real_launch_t<PT, 1, 1, false>(f, d_v, d_out, 0, stream);
     const int tpt = (f->rmax + kT - 1) / kT;
-    if (tpt <= 2) return real_launch_t<PT, 2, 2>(f, d_v, d_out, stream);
-    if (tpt <= 4) return real_launch_t<PT, 2, 4>(f, d_v, d_out, stream);
-    if (tpt <= 8) return real_launch_t<PT, 2, 8>(f, d_v, d_out, stream);
+    if (tpt <= 2)
+        return buf ? real_launch_t<PT, 2, 2, true>(f, d_v, d_out, nbytes, stream)
+                   : real_launch_t<PT, 2, 2, false>(f, d_v, d_out, 0, stream);
+    if (tpt <= 8)
+        return buf ? real_launch_t<PT, 2, 8, true>(f, d_v, d_out, nbytes, stream)
+                   : real_launch_t<PT, 2, 8, false>(f, d_v, d_out, 0, stream);
     set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
     return 2;
 }
 
 int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
-    return f->pt == 16 ? real_launch<16>(f, 0, d_v, d_out, stream) : real_launch<32>(f, 0, d_v, d_out, stream);
+    return f->pt == 16 ? real_launch<16>(f, 0, 0, d_v, d_out, stream) : real_launch<32>(f, 0, 0, d_v, d_out, stream);
 }
 
 template <int PT>
@@ -1125,8 +1165,8 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
     return 0;
 }
 
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, bool want_rc,
-                          const double *d_v, double *d_out, hipStream_t stream)
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
+                          bool want_rc, const double *d_v, double *d_out, hipStream_t stream)
 {
     if (f->list_plan != plan_id || f->list_mode == 0 || f->want_rc != want_rc) {
         if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, plan_id, ntiles, want_rc, stream)
@@ -1134,8 +1174,8 @@ int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, in
             return rc;
         f->want_rc = want_rc;          // (a plan whose run tables do not fit stays on plain lists)
     }
-    return f->pt == 16 ? real_launch<16>(f, f->list_mode, d_v, d_out, stream)
-                       : real_launch<32>(f, f->list_mode, d_v, d_out, stream);
+    return f->pt == 16 ? real_launch<16>(f, f->list_mode, nvalid, d_v, d_out, stream)
+                       : real_launch<32>(f, f->list_mode, nvalid, d_v, d_out, stream);
 }
 
 // HBM bytes per output sample the tile-order kernel is built to move (lists + gathers + results)
