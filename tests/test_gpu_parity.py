@@ -1381,13 +1381,12 @@ def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
         np.testing.assert_allclose(r[bs:bs + lam].cpu().numpy(), bands[1], rtol=0,
                                    atol=1e-12 * abs(bands[1][0]))
         assert float(r[bs + lam:bs + 3 * lam].abs().max()) < 1e-12 * abs(bands[1][0])
-    del e, r, Nr
+    del e, r
     # PCG to the metric's 1e-6 with M_BD: converged, true residual at the tolerance, and the
     # count reproducible (the bench prints this number for its own seed)
     M = cm.I.BlockDiagonalPreconditionerLO(ces, n, pol=pol)
     d = t.rand(nt, generator=g, device="cuda", dtype=t.float64)
     b = P.T * (Nf * d)
-    del d
     its = []
     xs, info = cm.cg(A, b, M=M, rtol=1e-6, maxiter=200, callback=lambda v: its.append(1))
     assert info == 0 and 2 <= len(its) <= 30
@@ -1396,6 +1395,22 @@ def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
     its_b = []
     xs_b, _ = cm.cg(A, b, M=M, rtol=1e-6, maxiter=200, callback=lambda v: its_b.append(1))
     assert len(its_b) == len(its) and t.equal(xs_b, xs)
+    # the same solve on the exact-order path (time-ordered gather, rocFFT overlap-save, pixel-major
+    # P^T in the reference's order -- each piece tied to the oracle at sizes it can run): the
+    # iteration count bench.py prints for this configuration is that path's count, strictly
+    L.set_pointing_mode("exact")
+    try:
+        A_x = P.T * Nr * P
+        assert not any(isinstance(op, L._TiledNormalLO) for op in A_x._compiled())
+        b_x = P.T * (Nr * d)
+        assert float((b_x - b).norm() / b.norm()) < 1e-12
+        its_x = []
+        xs_x, info_x = cm.cg(A_x, b_x, M=M, rtol=1e-6, maxiter=200, callback=lambda v: its_x.append(1))
+        assert info_x == 0 and len(its_x) == len(its), (len(its_x), len(its))
+        assert float((xs_x - xs).norm() / xs.norm()) < 1e-9
+        del A_x, b_x, xs_x
+    finally:
+        L.set_pointing_mode("auto")
     if two_level_rank:
         # BASELINE C4: two-level preconditioner, Arnoldi-built deflation space of dimension 32;
         # its solution must be the M_BD one (1e-6) in no more iterations
