@@ -19,9 +19,12 @@
 //   program order).  A pixel is touched by one thread per pass and the slices follow each other
 //   in time, so each sum is the reference's, term by term.
 //
-// Runs of 5..60 samples are cut into pieces of 4 in consecutive groups, piece p carrying
-// level p: the workgroup makes one pass per level (the slice's highest level is known at plan
-// time), separated by a barrier, so the pieces are added in order.  Longer runs (a pixel hit
+// Runs of 5..60 samples are cut into pieces of 4 in consecutive groups of ONE wave (the packer pads
+// so that a run never straddles a multiple of 64 groups), piece p carrying level p: every wave
+// makes one pass per level (the slice's highest level is known at plan time); the LDS executes a
+// wave's instructions in issue order, so the pieces are added in order without a barrier between
+// the passes (round 2 had one per level: dense tiles, 5-6 hits per pixel and slice, paid 2-3 of
+// them per slice).  Longer runs (a pixel hit
 // > 60 times inside one slice: hot pixels) are kept out of the groups and walked by one thread
 // each from a separate list.
 //
@@ -285,11 +288,13 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
                         }
                     }
                 }
-                // one pass per level: piece p of a long run is added after piece p - 1
-                for (int p = 0; p <= maxlevel; ++p) {
+                // one pass per level: piece p of a long run is added after piece p - 1.  The pieces
+                // of a run are groups of one wave (k_fx_pack), and the LDS executes a wave's
+                // instructions in issue order, so the passes need no barrier between them; the
+                // barrier behind the last pass separates this slice's adds from the next slice's.
+                for (int p = 0; p <= maxlevel; ++p)
                     if (mine && level == p) reduce_group(w, v, t1, t2);
-                    __syncthreads();
-                }
+                __syncthreads();
             }
         }
     }
@@ -474,6 +479,9 @@ __global__ __launch_bounds__(64) void k_fx_pack(
         } else {
             if (fill > 0) close();
             if ((uint32_t)((L - 1) / 4) > maxlev) maxlev = (uint32_t)((L - 1) / 4);
+            // all pieces of a run inside ONE wave (64 consecutive groups of the slice): the kernel
+            // orders the pieces by the program order of that wave's LDS adds, not by barriers
+            while ((int)(ng % 64u) + (L + 3) / 4 > 64) close();
             for (int m = 0; m < L; ++m) {
                 put(fill, ent[k0 + i + m], (uint32_t)(m / 4));
                 if (++fill == 4) close();
