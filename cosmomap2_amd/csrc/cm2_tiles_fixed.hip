@@ -80,8 +80,13 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     constexpr uint32_t QM = HALF ? 0x7FFFu : 0xFFFFu;
     extern __shared__ double sm[];
     double *tile = sm;                                   // tp * POL accumulators
-    double *vbuf = sm + (int64_t)tp * POL;               // VPT * kFxT values of the slice, TB order
-    double *part = vbuf + VPT * kFxT;                    // 3 x kFxMaxChunks chunk sums of hot runs
+    // the slice's TOD values, TB order, in one of TWO buffers (slice j in buffer j & 1): a wave that
+    // is ahead stages the next slice while another still gathers from this one, so a slice costs ONE
+    // workgroup barrier (behind the staging; it also completes every wave's LDS adds of the slice
+    // before, which keeps the slices' adds to one pixel in time order)
+    double *vbuf0 = sm + (int64_t)tp * POL;              // VPT * kFxT values
+    double *vbuf1 = vbuf0 + VPT * kFxT;
+    double *part = vbuf1 + VPT * kFxT;                   // 3 x kFxMaxChunks chunk sums of hot runs
     const int tid = threadIdx.x;
     const int b = tile0 + blockIdx.x;
     if (hot && hot[b]) return;                           // reduced by k_Pt_hot (many workgroups)
@@ -183,8 +188,10 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
         for (int dd = 0; dd < D; ++dd) {
             const int j = jj + dd;
             if (j >= nsl) break;
-            // ---- stage the slice's TOD values (everyone is past the previous slice's last
-            //      barrier; j = 0: the barrier below also covers the zeroing of the tile) ----
+            double *vbuf = dd ? vbuf1 : vbuf0;               // (kFxDepth = 2: slot dd = j & 1)
+            // ---- stage the slice's TOD values (into the buffer slice j - 2 used: every wave left
+            //      that slice before it arrived at slice j - 1's barrier; j = 0: the barrier below
+            //      also covers the zeroing of the tile) ----
 #pragma unroll
             for (int u = 0; u < VPT; ++u) vbuf[tid + u * kFxT] = pv[dd][u];
             const uint2 m0 = pm[dd][0], m1 = pm[dd][1];
@@ -291,10 +298,10 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
                 // one pass per level: piece p of a long run is added after piece p - 1.  The pieces
                 // of a run are groups of one wave (k_fx_pack), and the LDS executes a wave's
                 // instructions in issue order, so the passes need no barrier between them; the
-                // barrier behind the last pass separates this slice's adds from the next slice's.
+                // next slice's staging barrier separates this slice's adds from the next slice's.
                 for (int p = 0; p <= maxlevel; ++p)
                     if (mine && level == p) reduce_group(w, v, t1, t2);
-                __syncthreads();
+                if (g0 + kFxT < G) __syncthreads();          // (a further round of groups of this slice)
             }
         }
     }
@@ -503,7 +510,7 @@ size_t fx_lds_bytes(const cm2_tiles *t, int S)
 {
     int vpt = (S + kFxT - 1) / kFxT;
     vpt = vpt <= 2 ? 2 : vpt;
-    return sizeof(double) * ((size_t)t->tp * t->pol + (size_t)vpt * kFxT + 3 * (size_t)kFxMaxChunks);
+    return sizeof(double) * ((size_t)t->tp * t->pol + 2 * (size_t)vpt * kFxT + 3 * (size_t)kFxMaxChunks);
 }
 
 void hot_release(cm2_tiles *t)
