@@ -887,24 +887,51 @@ __global__ void k_real_twiddles(int N, double2 *__restrict__ W)
     if (t < N) W[t] = make_double2(cospi(2.0 * t / N), -sinpi(2.0 * t / N));
 }
 
-// H[b][k] = a0 + 2 sum_{j>=1} a_j cos(2 pi j k / (2N)),  k = 0..N  (real, even: symmetric band)
+// ct[m] = cos(pi m / N), m = 0..N
+__global__ void k_real_cos_table(int N, double *__restrict__ ct)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m <= N) ct[m] = cospi((double)m / (double)N);
+}
+
+// H[b][k] = a0 + 2 sum_{j>=1} a_j cos(2 pi j k / (2N)),  k = 0..N  (real, even: symmetric band).
+// The cosines come from the table ct staged in LDS (cos(pi m / N) for m = j k mod 2N, folded to
+// m <= N by the cosine's symmetry) instead of one cospi per term: the sum over j is the same sum in
+// the same order (j = lambda - 1 down to 1).  One workgroup: kSpecK bins of one block.
+constexpr int kSpecK = 1024;                             // bins per workgroup (4 per thread)
 __global__ __launch_bounds__(256) void k_real_spectrum(int nb, int64_t lambda, int N,
                                                         const double *__restrict__ bands,
+                                                        const double *__restrict__ ct_g,
                                                         double *__restrict__ Hs)
 {
-    const int64_t total = (int64_t)nb * (N + 1);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t b = e / (N + 1);
-        const int64_t k = e - b * (N + 1);
-        const double *band = bands + b * lambda;
-        double acc = 0.0;
-        for (int64_t j = lambda - 1; j >= 1; --j) {
-            const int64_t m = (j * k) % (2 * (int64_t)N);
-            acc += band[j] * cospi((double)m / (double)N);
-        }
-        Hs[e] = band[0] + 2.0 * acc;
+    extern __shared__ double ct[];                       // N + 1 cosines
+    constexpr int PER = kSpecK / 256;
+    const int chunks = (N + 1 + kSpecK - 1) / kSpecK;
+    const int b = blockIdx.x / chunks, c = blockIdx.x % chunks;
+    for (int m = threadIdx.x; m <= N; m += 256) ct[m] = ct_g[m];
+    __syncthreads();
+    const double *band = bands + (int64_t)b * lambda;
+    const int mask = 2 * N - 1;                          // N is a power of two
+    int k[PER], m[PER];
+    double acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        k[u] = c * kSpecK + u * 256 + (int)threadIdx.x;
+        m[u] = (int)(((lambda - 1) * (int64_t)k[u]) & mask);
+        acc[u] = 0.0;
     }
+    for (int64_t j = lambda - 1; j >= 1; --j) {
+        const double a = band[j];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = m[u] <= N ? m[u] : 2 * N - m[u];
+            acc[u] += a * ct[f];
+            m[u] = (m[u] - k[u]) & mask;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (k[u] <= N) Hs[(int64_t)b * (N + 1) + k[u]] = band[0] + 2.0 * acc[u];
 }
 
 // AB[b][a] = (alpha_k, beta_k), a = d1 256 + d2 16 + d3 the P3 position holding k = d1 + PT d2 + 16 PT d3
@@ -1008,7 +1035,15 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
     if (nb > 0) {
         DevTemp<double> Hs;
         CM2_HIP(Hs.alloc(nb * (G::N + 1)));
-        k_real_spectrum<<<grid_for(nb * (G::N + 1)), kBlock, 0, stream>>>((int)nb, lambda, G::N, d_bands, Hs);
+        DevTemp<double> ct;
+        CM2_HIP(ct.alloc(G::N + 1));
+        k_real_cos_table<<<(G::N + 256) / 256, 256, 0, stream>>>(G::N, ct);
+        CM2_LAUNCH_OK();
+        const size_t ct_lds = sizeof(double) * (G::N + 1);
+        static size_t ct_granted[64] = {0};
+        CM2_HIP(ensure_dynamic_lds((const void *)k_real_spectrum, ct_lds, ct_granted));
+        const int chunks = (G::N + 1 + kSpecK - 1) / kSpecK;
+        k_real_spectrum<<<(int)nb * chunks, 256, ct_lds, stream>>>((int)nb, lambda, G::N, d_bands, ct, Hs);
         CM2_LAUNCH_OK();
         k_real_alpha_beta<PT><<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_AB);
         CM2_LAUNCH_OK();
