@@ -16,10 +16,12 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda,
 int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream);
 // same, with input and output TODs addressed through d_idx[t] (tile-bucketed order of the tile
 // plan `plan_id`; the address lists are rebuilt when the plan changes)
+// d_tile_off: first address of every pixel tile, [ntiles + 1] (NULL = unknown: the lists are then
+// sorted instead of written directly)
 // ntiles: pixel tiles of the plan (bounds the address runs of a list; 0 = unknown)
 // nvalid: doubles in the two tile-order buffers (0 = unknown)
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
-                           const double *d_v, double *d_out, hipStream_t stream);
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                           int64_t ntiles, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream);
 int64_t fused_os_length(const FusedOS *f);
 void fused_os_destroy(FusedOS *f);
 // what the tile-order application uses: kernel[0] = 0 segment-pair kernel (cm2_fft.hip), 16 / 32 =
@@ -32,8 +34,9 @@ struct RealOS;
 int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
                    const std::vector<int64_t> &off, hipStream_t stream);
 int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream);
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
-                          bool want_rc, const double *d_v, double *d_out, hipStream_t stream);
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                          int64_t ntiles, int64_t nvalid, bool want_rc, const double *d_v, double *d_out,
+                          hipStream_t stream);
 double real_os_tile_bytes_per_sample(const RealOS *f);
 int real_os_list_mode(const RealOS *f);
 int64_t real_os_window(const RealOS *f);

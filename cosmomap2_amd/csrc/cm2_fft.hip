@@ -688,11 +688,13 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
     return 0;
 }
 
-int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
-                           const double *d_v, double *d_out, hipStream_t stream)
+int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                           int64_t ntiles, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream)
 {
     if (int rc = ensure_real(f, stream)) return rc;
-    if (f->real) return real_os_apply_indexed(f->real, d_idx, plan_id, ntiles, nvalid, f->real_rc, d_v, d_out, stream);
+    if (f->real)
+        return real_os_apply_indexed(f->real, d_idx, d_tile_off, plan_id, ntiles, nvalid, f->real_rc, d_v, d_out,
+                                     stream);
     if (int rc = ensure_pair_state(f, stream)) return rc;
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out
     // again to a later plan of the same size)

@@ -34,6 +34,7 @@
 #include "cm2_fft.h"
 
 #include <hipcub/hipcub.hpp>
+#include <cstring>
 
 using namespace cm2;
 
@@ -880,6 +881,164 @@ __global__ __launch_bounds__(256) void k_real_rc(int64_t nlists, const uint32_t 
     }
 }
 
+// ---- the lists without a sort ------------------------------------------------------------------
+// The tile order is a STABLE partition of the time samples by pixel tile: the samples of one tile
+// that fall into any contiguous time range have consecutive addresses, in time order.  A list
+// sorted by address is therefore: tiles ascending, inside a tile address - (lowest address of the
+// tile in this list).  One workgroup per list: count and lowest address per tile with LDS atomics
+// (integer add / min: the result does not depend on their order), a scan over the tiles, then
+//   slot(entry) = base[tile] + address - lowest[tile]
+// and the entries without a sample behind the valid ones in list order.  The run table falls out
+// of the same numbers: every tile with samples starts a run, delta = lowest[tile] - base[tile].
+// (k_real_rc merges the runs of two adjacent tiles when their addresses happen to be contiguous;
+// this kernel does not: at most one run per tile either way.)
+// RC: bit 15 of a word = run start, headers and run tables written; otherwise bit 15 = no sample
+// and the addresses go to lk (plain lists).
+template <int PT, bool RC>
+__global__ __launch_bounds__(256) void k_real_lists(const WinDesc *__restrict__ wins, int64_t nlists,
+                                                     const uint32_t *__restrict__ idx,
+                                                     const int64_t *__restrict__ tile_off, int ntiles,
+                                                     uint16_t *__restrict__ lq, uint32_t *__restrict__ lk,
+                                                     ListHdr *__restrict__ hdrs, uint32_t *__restrict__ tabs,
+                                                     int rmax, uint32_t *__restrict__ max_runs)
+{
+    using G = Geo<PT>;
+    constexpr int E = G::N / 256;                        // rows of 64 entries a wave handles at most
+    extern __shared__ uint32_t sm_l[];
+    uint32_t *toff = sm_l;                               // [ntiles + 1] first address of every tile
+    uint32_t *cnt = toff + ntiles + 1;                   // [ntiles] entries, then: base slot
+    uint32_t *mn = cnt + ntiles;                         // [ntiles] lowest address
+    uint32_t *ridx = mn + ntiles;                        // [ntiles] run index of the tile
+    uint32_t *misc = ridx + ntiles;                      // [4] waves' scan sums, [4] entries without sample, [4] wbase counts
+    uint16_t *stage = reinterpret_cast<uint16_t *>(misc + 12);   // [len] the list's 16-bit words
+    const int64_t lid = blockIdx.x;
+    if (lid >= nlists) return;
+    const int l = (int)(lid % G::NLIST);
+    const int64_t win = lid / G::NLIST;
+    const int64_t e0 = win * G::PER + G::list_off(l);
+    const int len = G::list_len(l), quarter = len / 4, rows = quarter / 64;
+    const WinDesc wd = wins[win];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int b = t; b <= ntiles; b += 256) toff[b] = (uint32_t)tile_off[b];
+    for (int b = t; b < ntiles; b += 256) {
+        cnt[b] = 0;
+        mn[b] = 0xFFFFFFFFu;
+    }
+    if (t < 12) misc[t] = 0;
+    __syncthreads();
+    // ---- pass 1: addresses, tiles, counts ----
+    uint32_t a[E];
+    uint16_t tl[E];
+    int ninv = 0;                                        // entries without a sample of this wave so far
+    uint32_t inv_rank[E / 2];                            // (two 16-bit ranks a word)
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        a[i] = kInvalidSample;
+        tl[i] = 0;
+        if (i < rows) {
+            const int e = wave * quarter + 64 * i + lane;
+            if (l < 2) {
+                const int64_t ts = wd.start - kHalo + (int64_t)l * G::N + e;
+                if (ts >= wd.lo && ts < wd.hi) a[i] = idx[ts];
+            } else {
+                const int64_t o = (int64_t)(l - 2) * G::RLEN + e;
+                if (o < wd.len) a[i] = idx[wd.start + o];
+            }
+            const bool valid = a[i] != kInvalidSample;
+            if (valid) {
+                int lo = 0, hi = ntiles;                 // largest b with toff[b] <= a
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (toff[mid] <= a[i]) lo = mid; else hi = mid;
+                }
+                tl[i] = (uint16_t)lo;
+                atomicAdd(&cnt[lo], 1u);
+                atomicMin(&mn[lo], a[i]);
+            }
+            const uint64_t im = __ballot(!valid);
+            const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            const uint32_t r = (uint32_t)(ninv + below);
+            if (i & 1) inv_rank[i / 2] |= r << 16; else inv_rank[i / 2] = r;
+            ninv += __popcll(im);
+        }
+    }
+    if (lane == 0) misc[4 + wave] = (uint32_t)ninv;
+    __syncthreads();
+    // ---- scan over the tiles: base slot and run index (packed: runs << 16 | entries) ----
+    const int per = (ntiles + 255) / 256;
+    uint32_t mine = 0;
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) mine += cnt[b] | (cnt[b] ? 0x10000u : 0u);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) misc[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += misc[w];
+        total += misc[w];
+    }
+    const int nvalid = (int)(total & 0xFFFFu), nruns = (int)(total >> 16);
+    // (len <= 8192 entries and at most 2^15 tiles: both halves of the packed word are exact)
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) {
+        const uint32_t c = cnt[b];
+        const uint32_t base = before & 0xFFFFu, r = before >> 16;
+        cnt[b] = base;
+        ridx[b] = r;
+        if (c) {
+            if (RC) {
+                if ((int)r < rmax) tabs[lid * rmax + r] = mn[b] - base;
+#pragma unroll
+                for (int w = 1; w < 4; ++w)
+                    if ((int)base < w * quarter) atomicAdd(&misc[8 + w], 1u);
+            }
+            before += c | 0x10000u;
+        }
+    }
+    int inv_before = nvalid;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) inv_before += (int)misc[4 + w];
+    __syncthreads();
+    // ---- pass 2: every entry to its slot ----
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (i < rows) {
+            const int e = wave * quarter + 64 * i + lane;
+            const bool valid = a[i] != kInvalidSample;
+            int slot;
+            uint16_t word = (uint16_t)e;
+            if (valid) {
+                const uint32_t low = mn[tl[i]];
+                slot = (int)(cnt[tl[i]] + (a[i] - low));
+                if (RC && a[i] == low) word |= 0x8000u;
+            } else {
+                slot = inv_before + (int)((inv_rank[i / 2] >> (16 * (i & 1))) & 0xFFFFu);
+                if (!RC) word |= 0x8000u;
+            }
+            stage[slot] = word;
+            if (!RC) lk[e0 + slot] = a[i];
+        }
+    }
+    if (RC && t == 0) {
+        ListHdr h;
+        h.nvalid = (uint32_t)nvalid;
+        h.nruns = (uint32_t)nruns;
+        h.wbase[0] = -1;
+        for (int w = 1; w < 4; ++w) h.wbase[w] = (int32_t)misc[8 + w] - 1;
+        hdrs[lid] = h;
+        atomicMax(max_runs, (uint32_t)nruns);
+    }
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lq + e0);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(stage);
+    for (int i = t; i < len / 2; i += 256) dst[i] = src[i];
+}
+
 // W[t] = exp(-2 pi i t / N)
 __global__ void k_real_twiddles(int N, double2 *__restrict__ W)
 {
@@ -1118,9 +1277,73 @@ int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t
     return f->pt == 16 ? real_launch<16>(f, 0, 0, d_v, d_out, stream) : real_launch<32>(f, 0, 0, d_v, d_out, stream);
 }
 
+// run-table words per list: one run per pixel tile at most (k_real_rc / k_real_lists)
 template <int PT>
-static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, bool want_rc,
-                            hipStream_t stream)
+static int real_rmax(int64_t ntiles)
+{
+    using G = Geo<PT>;
+    int64_t bound = ntiles > 0 ? ntiles : G::N;
+    if (bound > G::N) bound = G::N;
+    const int rmax = (int)((bound + 63) / 64 * 64);
+    return rmax < 64 ? 64 : rmax;
+}
+
+// The lists straight from the tile plan's offsets (k_real_lists): no keys, no sort, no temporaries.
+template <int PT>
+static int real_build_lists_direct(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                                   int64_t ntiles, bool want_rc, hipStream_t stream)
+{
+    using G = Geo<PT>;
+    const int64_t total = f->nwin * G::PER;
+    const int64_t nlists = f->nwin * G::NLIST;
+    CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
+    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
+    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    const int rmax = real_rmax<PT>(ntiles);
+    // run-coded lists up to 8 table words per thread (2048 runs a list), plain lists beyond that
+    const bool rc = want_rc && rmax <= 8 * kT;
+    const size_t lds = sizeof(uint32_t) * (size_t)(4 * ntiles + 1 + 12) + sizeof(uint16_t) * (size_t)G::N;
+    static size_t granted[64] = {0};
+    DevTemp<uint32_t> d_max;
+    CM2_HIP(d_max.alloc(1));
+    CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
+    if (rc) {
+        CM2_HIP(hipMalloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
+        CM2_HIP(hipMalloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, true>, lds, granted));
+        k_real_lists<PT, true><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
+                                                                      f->d_lst_q, nullptr, f->d_hdrs, f->d_tabs, rmax, d_max);
+    } else {
+        CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
+        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, false>, lds, granted));
+        k_real_lists<PT, false><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
+                                                                       f->d_lst_q, f->d_lst_k, nullptr, nullptr, rmax, d_max);
+    }
+    CM2_LAUNCH_OK();
+    uint32_t h_max = 0;
+    CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(hipStreamSynchronize(stream));
+    if (rc) {
+        CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel "
+                  "tiles allow", h_max, rmax);
+        f->rmax = rmax;
+        f->list_mode = 2;
+        f->list_bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
+    } else {
+        f->list_mode = 1;
+        f->list_bytes_per_window = 6.0 * G::PER;
+    }
+    guard.f = nullptr;
+    f->list_plan = plan_id;
+    return 0;
+}
+
+// d_tile_off: first address of every pixel tile ([ntiles + 1], NULL = unknown).  With it the lists
+// are written directly; without it (or CM2_OS_LIST_BUILD=sort, or more tiles than k_real_lists
+// keeps in LDS) they come from a segmented sort of (address, position) pairs.
+template <int PT>
+static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                            int64_t ntiles, bool want_rc, hipStream_t stream)
 {
     using G = Geo<PT>;
     real_free_lists(f);
@@ -1128,6 +1351,12 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
         f->list_plan = plan_id;
         f->list_mode = 1;
         return 0;
+    }
+    {
+        const char *e = getenv("CM2_OS_LIST_BUILD");         // direct (default) | sort
+        const bool sort = e && strcmp(e, "sort") == 0;
+        if (!sort && d_tile_off && ntiles > 0 && ntiles <= 4096)
+            return real_build_lists_direct<PT>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream);
     }
     const int64_t total = f->nwin * G::PER;
     struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
@@ -1168,10 +1397,7 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
         const int64_t nlists = f->nwin * G::NLIST;
         CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
         // one run per pixel tile at most (k_real_rc): the run-table stride follows from the tile count
-        int64_t bound = ntiles > 0 ? ntiles : G::N;
-        if (bound > G::N) bound = G::N;
-        int rmax = (int)((bound + 63) / 64 * 64);
-        if (rmax < 64) rmax = 64;
+        const int rmax = real_rmax<PT>(ntiles);
         // the two window-half tables live in LDS beside the exchange buffer; run-coded lists only
         // up to 8 table words per thread (2048 runs a list), plain lists beyond that
         if (rmax <= 8 * kT) {
@@ -1200,12 +1426,13 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, 
     return 0;
 }
 
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, uint64_t plan_id, int64_t ntiles, int64_t nvalid,
-                          bool want_rc, const double *d_v, double *d_out, hipStream_t stream)
+int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                          int64_t ntiles, int64_t nvalid, bool want_rc, const double *d_v, double *d_out,
+                          hipStream_t stream)
 {
     if (f->list_plan != plan_id || f->list_mode == 0 || f->want_rc != want_rc) {
-        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, plan_id, ntiles, want_rc, stream)
-                                  : real_build_lists<32>(f, d_idx, plan_id, ntiles, want_rc, stream)))
+        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream)
+                                  : real_build_lists<32>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream)))
             return rc;
         f->want_rc = want_rc;          // (a plan whose run tables do not fit stays on plain lists)
     }

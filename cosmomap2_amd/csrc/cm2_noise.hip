@@ -509,6 +509,7 @@ extern "C" int64_t cm2_tiles_nt(const cm2_tiles *t);
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t);
+extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t);
 
 extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
                                      double *d_out_tb, void *stream_)
@@ -526,9 +527,9 @@ extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const
               "or CM2_TOEPLITZ_AUTO");
     CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
               (long long)n->nt, (long long)cm2_tiles_nt(tiles));
-    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), cm2_tiles_plan_id(tiles),
-                                       cm2_tiles_ntiles(tiles), cm2_tiles_nvalid(tiles), d_in_tb, d_out_tb,
-                                       as_stream(stream_));
+    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), cm2_tiles_offsets(tiles),
+                                       cm2_tiles_plan_id(tiles), cm2_tiles_ntiles(tiles), cm2_tiles_nvalid(tiles),
+                                       d_in_tb, d_out_tb, as_stream(stream_));
 }
 
 // One call for the whole tile-order chain y = P^T N^-1 P x (SURVEY 8b's fused cm2_PtNP_apply):

@@ -648,6 +648,8 @@ extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t) { return t ? t->plan_id : 0; }
 extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t) { return t ? t->ntiles : 0; }
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid : 0; }
+// first tile-order address of every tile, [ntiles + 1] on the device (internal: cm2_noise.hip)
+extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t) { return t ? t->d_tile_off : nullptr; }
 
 // Tile indices bounding `ngroups` consecutive groups of tiles whose PIXEL boundaries are the same on
 // every rank of a sharded run (ranks with different hit maps may have cut their tiles differently):

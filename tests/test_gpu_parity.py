@@ -1316,6 +1316,7 @@ def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
     bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
     x = np.random.default_rng(1).standard_normal(pol * npix)
     outs = []
+    monkeypatch.setenv("CM2_OS_LIST_BUILD", "sort")
     for chunk in (None, "3"):
         if chunk:
             monkeypatch.setenv("CM2_OS_LIST_CHUNK_PAIRS", chunk)
@@ -1324,6 +1325,41 @@ def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
         Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
         outs.append(np.asarray(L._TiledNormalLO(P, Nf) * x))
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kernel,lists,tp", [("real32", "rc", 1024), ("real32", "plain", 1024),
+                                             ("real16", "rc", 1024), ("real32", "rc", 64),
+                                             ("real16", "plain", 256)])
+def test_overlap_save_lists_written_directly_equal_the_sorted_ones(cm, oracle, monkeypatch, kernel, lists, tp):
+    """The address lists of the tile-order overlap-save kernel are written straight from the tile
+    plan's offsets (k_real_lists: count / lowest address per tile, a scan, slot = base + address -
+    lowest).  They must describe the same gather / scatter as the lists that come out of the
+    segmented sort (CM2_OS_LIST_BUILD=sort): the operator is bit-identical, with flagged samples,
+    ragged noise blocks shorter than a window, run-coded and plain lists, and more tiles (tp = 64:
+    1094 tiles) than a window has samples per tile."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    pol, nt, npix, nblk, lam = 3, 240000, 70000, 5, 300
+    d, pairs, phi, t, diag = make_problem(oracle, 4321, nt, npix, nblk, pol, flag_frac=0.05)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    sizes = [100000, 60000, 70000, 7000, 3000]
+    kk = np.arange(lam)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
+    x = np.random.default_rng(2).standard_normal(pol * npix)
+    monkeypatch.setenv("CM2_OS_KERNEL", kernel)
+    monkeypatch.setenv("CM2_OS_LISTS", lists)
+    outs = []
+    for build in ("direct", "sort"):
+        monkeypatch.setenv("CM2_OS_LIST_BUILD", build)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+        Nf = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+        outs.append(np.asarray(L._TiledNormalLO(P, Nf) * x))
+        assert Nf.tile_kernel_info()["os_lists"] == ("plain" if lists == "plain" else "run-coded")
+    assert np.array_equal(outs[0], outs[1])
+    Nd = cm.I.BlockLO(sizes, bands, offdiag=True, method=1)          # direct band sum
+    tod = np.asarray(P * x)
+    assert rel_l2(outs[0], np.asarray(P.T * (Nd * tod))) < 1e-12
 
 
 def _full_size_toeplitz_properties(cm, nside, nt, nb, seed, two_level_rank=0):
