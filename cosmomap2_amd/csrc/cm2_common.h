@@ -12,6 +12,12 @@ namespace cm2 {
 
 void set_error(const char *fmt, ...);
 
+// device memory of the library (cm2_core.hip): hipMalloc / hipFree semantics, freed blocks cached
+hipError_t dev_malloc_bytes(void **p, size_t bytes);
+hipError_t dev_free(void *p);
+template <typename T>
+static inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
+
 #define CM2_HIP(call)                                                                  \
     do {                                                                               \
         hipError_t e__ = (call);                                                       \
@@ -71,10 +77,10 @@ struct DevTemp {
     DevTemp() = default;
     DevTemp(const DevTemp &) = delete;
     DevTemp &operator=(const DevTemp &) = delete;
-    ~DevTemp() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * (count ? count : 1)); }
+    ~DevTemp() { if (p) (void)dev_free(p); }
+    hipError_t alloc(size_t count) { return dev_malloc(&p, sizeof(T) * (count ? count : 1)); }
     T *keep() { T *q = p; p = nullptr; return q; }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    void release() { if (p) (void)dev_free(p); p = nullptr; }
     operator T *() const { return p; }
 };
 

@@ -2,6 +2,11 @@
 #include "cm2_common.h"
 
 #include <cstdarg>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace cm2 {
 static thread_local char g_err[1024] = "";
@@ -13,7 +18,139 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- device memory of the library ---------------------------------------------------------------
+// Plans are built from many large temporaries (hundreds of MB each) and hold GBs of lists.  The
+// driver's hipMalloc / hipFree cost 0.1 .. 0.6 ms a call at these sizes and, when an allocation
+// follows a large release closely (a second plan built after the first was destroyed), one
+// hipMalloc was measured at 156 ms (profiles/r03_setup_slow_calls.txt).  Freed blocks are
+// therefore kept per device and handed out again: a request takes the smallest cached block of at
+// least its size and at most 25 % (+ 1 MB) more.  dev_free waits for the device like hipFree does,
+// so a block is never reused while a kernel that was given it may still run.  The cache is capped
+// (CM2_DEVICE_CACHE_MB, default 32768; 0 = no caching): beyond the cap the largest cached blocks go
+// back to the driver.  cm2_release_cached_memory() returns everything.
+namespace {
+struct DevCache {
+    std::mutex lock;
+    std::unordered_map<void *, std::pair<int, size_t>> live;            // block -> (device, bytes)
+    std::multimap<std::pair<int, size_t>, void *> cached;               // (device, bytes) -> block
+    size_t cached_bytes = 0, live_bytes = 0, cap = 0;
+    int64_t hits = 0, misses = 0;
+    bool cap_read = false;
+};
+DevCache &dev_cache()
+{
+    static DevCache *c = new DevCache();      // never destroyed: frees at process exit race the runtime's teardown
+    return *c;
+}
+size_t round_size(size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    const size_t q = bytes < ((size_t)1 << 20) ? 512 : ((size_t)1 << 16);
+    return (bytes + q - 1) / q * q;
+}
+}  // namespace
+
+hipError_t dev_malloc_bytes(void **p, size_t bytes)
+{
+    DevCache &c = dev_cache();
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t want = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> hold(c.lock);
+        if (!c.cap_read) {
+            const char *env = getenv("CM2_DEVICE_CACHE_MB");
+            c.cap = (size_t)(env ? atoll(env) : 32768) << 20;
+            c.cap_read = true;
+        }
+        auto it = c.cached.lower_bound({dev, want});
+        if (it != c.cached.end() && it->first.first == dev &&
+            it->first.second <= want + want / 4 + ((size_t)1 << 20)) {
+            *p = it->second;
+            c.live[*p] = it->first;
+            c.cached_bytes -= it->first.second;
+            c.live_bytes += it->first.second;
+            c.cached.erase(it);
+            ++c.hits;
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(p, want);
+    if (e != hipSuccess) {                    // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        cm2_release_cached_memory();
+        e = hipMalloc(p, want);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> hold(c.lock);
+    c.live[*p] = {dev, want};
+    c.live_bytes += want;
+    ++c.misses;
+    return hipSuccess;
+}
+
+hipError_t dev_free(void *p)
+{
+    if (!p) return hipSuccess;
+    DevCache &c = dev_cache();
+    std::pair<int, size_t> key;
+    {
+        std::lock_guard<std::mutex> hold(c.lock);
+        auto it = c.live.find(p);
+        if (it == c.live.end()) return hipFree(p);       // not ours (never happens inside the library)
+        key = it->second;
+        c.live.erase(it);
+        c.live_bytes -= key.second;
+        if (c.cap == 0) key.second = 0;                  // caching switched off
+    }
+    if (key.second == 0) return hipFree(p);
+    // what hipFree guarantees: no work that may touch the block is still running
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    std::vector<void *> evict;
+    {
+        std::lock_guard<std::mutex> hold(c.lock);
+        c.cached.insert({key, p});
+        c.cached_bytes += key.second;
+        while (c.cached_bytes > c.cap && !c.cached.empty()) {
+            auto big = std::prev(c.cached.end());        // (largest block of the highest device id)
+            evict.push_back(big->second);
+            c.cached_bytes -= big->first.second;
+            c.cached.erase(big);
+        }
+    }
+    for (void *q : evict) (void)hipFree(q);
+    return hipSuccess;
+}
 }  // namespace cm2
+
+extern "C" int cm2_release_cached_memory(void)
+{
+    cm2::DevCache &c = cm2::dev_cache();
+    std::vector<void *> all;
+    {
+        std::lock_guard<std::mutex> hold(c.lock);
+        for (auto &kv : c.cached) all.push_back(kv.second);
+        c.cached.clear();
+        c.cached_bytes = 0;
+    }
+    for (void *q : all) CM2_HIP(hipFree(q));
+    return 0;
+}
+
+extern "C" int cm2_device_memory_info(int64_t *h_info)
+{
+    CM2_CHECK(h_info != nullptr, "cm2_device_memory_info: h_info is NULL");
+    cm2::DevCache &c = cm2::dev_cache();
+    std::lock_guard<std::mutex> hold(c.lock);
+    h_info[0] = (int64_t)c.live_bytes;
+    h_info[1] = (int64_t)c.cached_bytes;
+    h_info[2] = c.hits;
+    h_info[3] = c.misses;
+    return 0;
+}
 
 extern "C" const char *cm2_last_error(void) { return cm2::g_err; }
 

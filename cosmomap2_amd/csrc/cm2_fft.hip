@@ -586,8 +586,8 @@ static int ensure_real(FusedOS *f, hipStream_t stream)
 
 static void free_lists(FusedOS *f)
 {
-    if (f->d_lst_k) (void)hipFree(f->d_lst_k);
-    if (f->d_lst_q) (void)hipFree(f->d_lst_q);
+    if (f->d_lst_k) (void)cm2::dev_free(f->d_lst_k);
+    if (f->d_lst_q) (void)cm2::dev_free(f->d_lst_q);
     f->d_lst_k = nullptr;
     f->d_lst_q = nullptr;
     f->list_plan = 0;
@@ -600,7 +600,7 @@ void fused_os_destroy(FusedOS *f)
     if (f->real) real_os_destroy(f->real);
     void *ptrs[] = {f->d_pairs, f->d_W, f->d_Hperm};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     delete f;
 }
 
@@ -651,8 +651,8 @@ static int build_lists(FusedOS *f, const uint32_t *d_idx, uint64_t plan_id, hipS
     }
     const int64_t total = f->npairs * kRegPer;
     struct Guard { FusedOS *f; ~Guard() { if (f) free_lists(f); } } guard{f};     // early returns
-    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
-    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_k, sizeof(uint32_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
     // One segment per list, 32-bit keys: every segment (4096 or 8192 entries) is sorted inside one
     // workgroup -- 4 ms at 1e8 samples where a global sort on (pair, list, address) keys took 12.
     // hipCUB counts items in int: pairs go through in chunks of at most 2^30 entries.
@@ -728,17 +728,17 @@ static int ensure_pair_state(FusedOS *f, hipStream_t stream)
         }
     }
     f->npairs = (int64_t)pairs.size();
-    CM2_HIP(hipMalloc(&f->d_pairs, sizeof(PairDesc) * (pairs.size() ? pairs.size() : 1)));
+    CM2_HIP(cm2::dev_malloc(&f->d_pairs, sizeof(PairDesc) * (pairs.size() ? pairs.size() : 1)));
     if (!pairs.empty())
         CM2_HIP(hipMemcpy(f->d_pairs, pairs.data(), sizeof(PairDesc) * pairs.size(),
                           hipMemcpyHostToDevice));
-    CM2_HIP(hipMalloc(&f->d_Hperm, sizeof(double) * (nb > 0 ? nb : 1) * kRegN));
+    CM2_HIP(cm2::dev_malloc(&f->d_Hperm, sizeof(double) * (nb > 0 ? nb : 1) * kRegN));
     if (nb > 0) {
         k_spectrum_perm<<<grid_for(nb * kRegN), kBlock, 0, stream>>>((int)nb, lambda, kRegN, 32, 16, 16,
                                                                     f->d_bands, f->d_Hperm);
         CM2_LAUNCH_OK();
     }
-    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * kRegN));
+    CM2_HIP(cm2::dev_malloc(&f->d_W, sizeof(double2) * kRegN));
     k_twiddles<<<(kRegN + 255) / 256, 256, 0, stream>>>(kRegN, f->d_W);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));

@@ -115,7 +115,7 @@ static unsigned long long *os_stamp_buf()                   // never NULL: a dum
 {
     static unsigned long long *dummy = nullptr;
     if (g_os_stamps_host) return g_os_stamps_host;
-    if (!dummy && hipMalloc(&dummy, sizeof(unsigned long long) * 8 * (1 << 20)) != hipSuccess) abort();
+    if (!dummy && cm2::dev_malloc(&dummy, sizeof(unsigned long long) * 8 * (1 << 20)) != hipSuccess) abort();
     return dummy;
 }
 #define OS_STAMP_PARAM , unsigned long long *__restrict__ stamps
@@ -1145,7 +1145,7 @@ static void real_free_lists(RealOS *f)
 {
     void *ptrs[] = {f->d_lst_k, f->d_lst_q, f->d_hdrs, f->d_tabs};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     f->d_lst_k = nullptr;
     f->d_lst_q = nullptr;
     f->d_hdrs = nullptr;
@@ -1161,7 +1161,7 @@ void real_os_destroy(RealOS *f)
     real_free_lists(f);
     void *ptrs[] = {f->d_wins, f->d_AB, f->d_W};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     delete f;
 }
 
@@ -1187,10 +1187,10 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
             wins.push_back(wd);
         }
     f->nwin = (int64_t)wins.size();
-    CM2_HIP(hipMalloc(&f->d_wins, sizeof(WinDesc) * (wins.size() ? wins.size() : 1)));
+    CM2_HIP(cm2::dev_malloc(&f->d_wins, sizeof(WinDesc) * (wins.size() ? wins.size() : 1)));
     if (!wins.empty())
         CM2_HIP(hipMemcpy(f->d_wins, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice));
-    CM2_HIP(hipMalloc(&f->d_AB, sizeof(double2) * (nb > 0 ? nb : 1) * G::N));
+    CM2_HIP(cm2::dev_malloc(&f->d_AB, sizeof(double2) * (nb > 0 ? nb : 1) * G::N));
     if (nb > 0) {
         DevTemp<double> Hs;
         CM2_HIP(Hs.alloc(nb * (G::N + 1)));
@@ -1208,7 +1208,7 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
         CM2_LAUNCH_OK();
         CM2_HIP(hipStreamSynchronize(stream));
     }
-    CM2_HIP(hipMalloc(&f->d_W, sizeof(double2) * G::N));
+    CM2_HIP(cm2::dev_malloc(&f->d_W, sizeof(double2) * G::N));
     k_real_twiddles<<<(G::N + 255) / 256, 256, 0, stream>>>(G::N, f->d_W);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
@@ -1298,7 +1298,7 @@ static int real_build_lists_direct(RealOS *f, const uint32_t *d_idx, const int64
     const int64_t nlists = f->nwin * G::NLIST;
     CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
     struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
-    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
     const int rmax = real_rmax<PT>(ntiles);
     // run-coded lists up to 8 table words per thread (2048 runs a list), plain lists beyond that
     const bool rc = want_rc && rmax <= 8 * kT;
@@ -1308,13 +1308,13 @@ static int real_build_lists_direct(RealOS *f, const uint32_t *d_idx, const int64
     CM2_HIP(d_max.alloc(1));
     CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
     if (rc) {
-        CM2_HIP(hipMalloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
-        CM2_HIP(hipMalloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+        CM2_HIP(cm2::dev_malloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
+        CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
         CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, true>, lds, granted));
         k_real_lists<PT, true><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
                                                                       f->d_lst_q, nullptr, f->d_hdrs, f->d_tabs, rmax, d_max);
     } else {
-        CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
+        CM2_HIP(cm2::dev_malloc(&f->d_lst_k, sizeof(uint32_t) * total));
         CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, false>, lds, granted));
         k_real_lists<PT, false><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
                                                                        f->d_lst_q, f->d_lst_k, nullptr, nullptr, rmax, d_max);
@@ -1360,8 +1360,8 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
     }
     const int64_t total = f->nwin * G::PER;
     struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
-    CM2_HIP(hipMalloc(&f->d_lst_k, sizeof(uint32_t) * total));
-    CM2_HIP(hipMalloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_k, sizeof(uint32_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
     int64_t chunk_w = ((int64_t)1 << 30) / G::PER;             // hipCUB counts items in int
     if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS"))      // test hook: force several chunks
         if (atoll(e) > 0 && atoll(e) < chunk_w) chunk_w = atoll(e);
@@ -1404,8 +1404,8 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
             DevTemp<uint32_t> d_max;
             CM2_HIP(d_max.alloc(1));
             CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
-            CM2_HIP(hipMalloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
-            CM2_HIP(hipMalloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+            CM2_HIP(cm2::dev_malloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
+            CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
             k_real_rc<PT><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, f->d_hdrs,
                                                                f->d_tabs, rmax, d_max);
             CM2_LAUNCH_OK();
@@ -1414,7 +1414,7 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
             CM2_HIP(hipStreamSynchronize(stream));
             CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel "
                       "tiles allow", h_max, rmax);
-            (void)hipFree(f->d_lst_k);                      // the addresses are now in the run tables
+            (void)cm2::dev_free(f->d_lst_k);                      // the addresses are now in the run tables
             f->d_lst_k = nullptr;
             f->rmax = rmax;
             f->list_mode = 2;

@@ -516,7 +516,7 @@ extern "C" void cm2_filter_destroy(cm2_filter *f)
     void *bufs[] = {f->d_start, f->d_len, f->d_prev_end, f->d_toff, f->d_kind, f->d_table, f->d_coef,
                     f->d_wins, f->d_win_k, f->d_win_q};
     for (void *p : bufs)
-        if (p) (void)hipFree(p);
+        if (p) (void)cm2::dev_free(p);
     delete f;
 }
 
@@ -525,7 +525,7 @@ namespace {
 template <typename T>
 int upload(T **dst, const T *src, size_t count, hipStream_t st)
 {
-    CM2_HIP(hipMalloc(dst, sizeof(T) * (count ? count : 1)));
+    CM2_HIP(cm2::dev_malloc(dst, sizeof(T) * (count ? count : 1)));
     if (count) CM2_HIP(hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, st));
     return 0;
 }
@@ -533,8 +533,8 @@ int upload(T **dst, const T *src, size_t count, hipStream_t st)
 template <int K>
 int setup_poly(cm2_filter *f, hipStream_t st)
 {
-    CM2_HIP(hipMalloc(&f->d_coef, sizeof(OrthoCoef<K>) * (size_t)(f->nseg ? f->nseg : 1)));
-    CM2_HIP(hipMalloc(&f->d_kind, (size_t)(f->nseg ? f->nseg : 1)));
+    CM2_HIP(cm2::dev_malloc(&f->d_coef, sizeof(OrthoCoef<K>) * (size_t)(f->nseg ? f->nseg : 1)));
+    CM2_HIP(cm2::dev_malloc(&f->d_kind, (size_t)(f->nseg ? f->nseg : 1)));
     if (f->nseg == 0) return 0;
     const int64_t blocks = (f->nseg + 3) / 4;
     k_filter_setup<K><<<dim3((unsigned)blocks), 256, 0, st>>>(
@@ -692,7 +692,7 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, uint64_t plan_id,
 {
     void **old[] = {(void **)&f->d_wins, (void **)&f->d_win_k, (void **)&f->d_win_q};
     for (void **q : old) {
-        if (*q) (void)hipFree(*q);
+        if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
     }
     f->win_plan = 0;                                  // set once the lists are complete
@@ -732,7 +732,7 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, uint64_t plan_id,
         return 0;
     }
     CM2_CHECK(f->nseg < ((int64_t)1 << 31) && f->nwin < ((int64_t)1 << 31), "too many chunks");
-    CM2_HIP(hipMalloc(&f->d_wins, sizeof(FilterWin) * wins.size()));
+    CM2_HIP(cm2::dev_malloc(&f->d_wins, sizeof(FilterWin) * wins.size()));
     CM2_HIP(hipMemcpyAsync(f->d_wins, wins.data(), sizeof(FilterWin) * wins.size(),
                            hipMemcpyHostToDevice, st));
     const int64_t total = f->nwin * kWinLen;
@@ -742,8 +742,8 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, uint64_t plan_id,
     CM2_HIP(keys_in.alloc(total));
     CM2_HIP(keys_out.alloc(total));
     CM2_HIP(vals_in.alloc(total));
-    CM2_HIP(hipMalloc(&f->d_win_k, sizeof(uint32_t) * total));
-    CM2_HIP(hipMalloc(&f->d_win_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_win_k, sizeof(uint32_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_win_q, sizeof(uint16_t) * total));
     k_win_keys<<<grid_for(total), kBlock, 0, st>>>(f->d_wins, f->nwin, d_idx, keys_in, vals_in);
     CM2_LAUNCH_OK();
     int end_bit = 33;

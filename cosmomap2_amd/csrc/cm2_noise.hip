@@ -245,7 +245,7 @@ static int noise_common(cm2_noise *n, const int64_t *h_sizes, int64_t nb,
     n->nb = nb;
     n->nt = off[nb];
     n->bsize = h_sizes[0];
-    CM2_HIP(hipMalloc(&n->d_off, sizeof(int64_t) * (nb + 1)));
+    CM2_HIP(cm2::dev_malloc(&n->d_off, sizeof(int64_t) * (nb + 1)));
     CM2_HIP(hipMemcpy(n->d_off, off.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice));
     return 0;
 }
@@ -260,7 +260,7 @@ extern "C" int cm2_noise_destroy(cm2_noise *n)
     void *ptrs[] = {n->d_off, n->d_t, n->d_seg, n->d_seg_blk, n->d_X, n->d_F, n->d_H, n->d_fftwork,
                     n->d_dirtiles};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     delete n;
     return 0;
 }
@@ -275,7 +275,7 @@ extern "C" int cm2_noise_create_diag(cm2_noise **out, const double *h_t, const i
     if (int rc = noise_common(n, h_sizes, nblocks, off)) { cm2_noise_destroy(n); return rc; }
     n->lambda = 0;
     n->method = 0;
-    CM2_HIP(hipMalloc(&n->d_t, sizeof(double) * nblocks));
+    CM2_HIP(cm2::dev_malloc(&n->d_t, sizeof(double) * nblocks));
     CM2_HIP(hipMemcpy(n->d_t, h_t, sizeof(double) * nblocks, hipMemcpyHostToDevice));
     *out = n;
     return 0;
@@ -316,7 +316,7 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
                                 : (cm2::fused_os_supported(lambda) ? CM2_TOEPLITZ_FUSED
                                                                    : CM2_TOEPLITZ_FFT);
     n->method = method;
-    CM2_HIP(hipMalloc(&n->d_t, sizeof(double) * nblocks * lambda));
+    CM2_HIP(cm2::dev_malloc(&n->d_t, sizeof(double) * nblocks * lambda));
     CM2_HIP(hipMemcpy(n->d_t, h_bands, sizeof(double) * nblocks * lambda, hipMemcpyHostToDevice));
     if (method == CM2_TOEPLITZ_DIRECT) {
         *out = n;
@@ -354,14 +354,14 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
     }
     n->nseg = (int64_t)seg_blk.size();
     CM2_CHECK(n->nseg < 65536LL * 32768LL, "too many FFT segments (%lld)", (long long)n->nseg);
-    CM2_HIP(hipMalloc(&n->d_seg, sizeof(int64_t) * seg.size()));
-    CM2_HIP(hipMalloc(&n->d_seg_blk, sizeof(int32_t) * seg_blk.size()));
+    CM2_HIP(cm2::dev_malloc(&n->d_seg, sizeof(int64_t) * seg.size()));
+    CM2_HIP(cm2::dev_malloc(&n->d_seg_blk, sizeof(int32_t) * seg_blk.size()));
     CM2_HIP(hipMemcpy(n->d_seg, seg.data(), sizeof(int64_t) * seg.size(), hipMemcpyHostToDevice));
     CM2_HIP(hipMemcpy(n->d_seg_blk, seg_blk.data(), sizeof(int32_t) * seg_blk.size(),
                       hipMemcpyHostToDevice));
-    CM2_HIP(hipMalloc(&n->d_X, sizeof(double) * n->nseg * n->L));
-    CM2_HIP(hipMalloc(&n->d_F, sizeof(double2) * n->nseg * n->nfreq));
-    CM2_HIP(hipMalloc(&n->d_H, sizeof(double) * nblocks * n->nfreq));
+    CM2_HIP(cm2::dev_malloc(&n->d_X, sizeof(double) * n->nseg * n->L));
+    CM2_HIP(cm2::dev_malloc(&n->d_F, sizeof(double2) * n->nseg * n->nfreq));
+    CM2_HIP(cm2::dev_malloc(&n->d_H, sizeof(double) * nblocks * n->nfreq));
     k_spectrum<<<grid_for(nblocks * n->nfreq), kBlock, 0, stream>>>((int)nblocks, lambda, n->L,
                                                                    n->nfreq, n->d_t, n->d_H);
     CM2_LAUNCH_OK();
@@ -384,7 +384,7 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
     n->fftwork_bytes = w1 > w2 ? w1 : w2;
     CM2_FFT(rocfft_execution_info_create(&n->info));
     if (n->fftwork_bytes) {
-        CM2_HIP(hipMalloc(&n->d_fftwork, n->fftwork_bytes));
+        CM2_HIP(cm2::dev_malloc(&n->d_fftwork, n->fftwork_bytes));
         CM2_FFT(rocfft_execution_info_set_work_buffer(n->info, n->d_fftwork, n->fftwork_bytes));
     }
     CM2_HIP(hipStreamSynchronize(stream));
@@ -454,7 +454,7 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
                     tl.push_back(d);
                 }
             n->ndirtiles = (int64_t)tl.size();
-            CM2_HIP(hipMalloc(&n->d_dirtiles, sizeof(DirTile) * (tl.size() ? tl.size() : 1)));
+            CM2_HIP(cm2::dev_malloc(&n->d_dirtiles, sizeof(DirTile) * (tl.size() ? tl.size() : 1)));
             if (!tl.empty())
                 CM2_HIP(hipMemcpy(n->d_dirtiles, tl.data(), sizeof(DirTile) * tl.size(),
                                   hipMemcpyHostToDevice));

@@ -7,8 +7,8 @@ namespace cm2 {
 
 void PixIndex::release()
 {
-    if (d_sorted_t) (void)hipFree(d_sorted_t);
-    if (d_ptr) (void)hipFree(d_ptr);
+    if (d_sorted_t) (void)cm2::dev_free(d_sorted_t);
+    if (d_ptr) (void)cm2::dev_free(d_ptr);
     d_sorted_t = nullptr;
     d_ptr = nullptr;
 }
@@ -53,7 +53,7 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
     ix.nt = nt;
     ix.npix = npix;
     ix.nvalid = 0;
-    CM2_HIP(hipMalloc(&ix.d_ptr, sizeof(int64_t) * (npix + 1)));
+    CM2_HIP(cm2::dev_malloc(&ix.d_ptr, sizeof(int64_t) * (npix + 1)));
     if (nt == 0) {
         CM2_HIP(hipMemsetAsync(ix.d_ptr, 0, sizeof(int64_t) * (npix + 1), stream));
         CM2_HIP(hipStreamSynchronize(stream));
@@ -65,7 +65,7 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
     CM2_HIP(keys_in.alloc(nt));
     CM2_HIP(keys_out.alloc(nt));
     CM2_HIP(vals_in.alloc(nt));
-    CM2_HIP(hipMalloc(&ix.d_sorted_t, sizeof(uint32_t) * nt));
+    CM2_HIP(cm2::dev_malloc(&ix.d_sorted_t, sizeof(uint32_t) * nt));
     CM2_HIP(d_bad.alloc(1));
     CM2_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream));
     k_make_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, keys_in, vals_in, d_bad);

@@ -311,7 +311,7 @@ static void free_plan(cm2_pointing *p)
     void *ptrs[] = {p->d_sell_pix, p->d_sell_cnt, p->d_slice_ptr, p->d_sell_t,
                     p->d_sell_cos, p->d_sell_sin, p->d_sell_w};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     delete p;
 }
 
@@ -399,7 +399,7 @@ static int ensure_sell(const cm2_pointing *cp, hipStream_t stream)
                 void *ptrs[] = {plan->d_sell_pix, plan->d_sell_cnt, plan->d_slice_ptr, plan->d_sell_t,
                                 plan->d_sell_cos, plan->d_sell_sin};
                 for (void *q : ptrs)
-                    if (q) (void)hipFree(q);
+                    if (q) (void)cm2::dev_free(q);
                 plan->d_sell_pix = plan->d_sell_cnt = nullptr;
                 plan->d_slice_ptr = nullptr;
                 plan->d_sell_t = nullptr;
@@ -414,9 +414,9 @@ static int ensure_sell(const cm2_pointing *cp, hipStream_t stream)
     size_t tb1 = 0, tb2 = 0;
     CM2_HIP(cnt_in.alloc(npix));
     CM2_HIP(ids_in.alloc(npix));
-    CM2_HIP(hipMalloc(&p->d_sell_pix, sizeof(int32_t) * p->nslots));
-    CM2_HIP(hipMalloc(&p->d_sell_cnt, sizeof(int32_t) * p->nslots));
-    CM2_HIP(hipMalloc(&p->d_slice_ptr, sizeof(int64_t) * (p->nslices + 1)));
+    CM2_HIP(cm2::dev_malloc(&p->d_sell_pix, sizeof(int32_t) * p->nslots));
+    CM2_HIP(cm2::dev_malloc(&p->d_sell_cnt, sizeof(int32_t) * p->nslots));
+    CM2_HIP(cm2::dev_malloc(&p->d_slice_ptr, sizeof(int64_t) * (p->nslices + 1)));
     CM2_HIP(d_len.alloc(p->nslices + 1));
     k_counts<<<grid_for(npix), kBlock, 0, stream>>>(ix.d_ptr, npix, cnt_in, ids_in);
     CM2_LAUNCH_OK();
@@ -444,10 +444,10 @@ static int ensure_sell(const cm2_pointing *cp, hipStream_t stream)
     CM2_HIP(hipStreamSynchronize(stream));
 
     const int64_t L = p->sell_len > 0 ? p->sell_len : 1;
-    CM2_HIP(hipMalloc(&p->d_sell_t, sizeof(uint32_t) * L));
+    CM2_HIP(cm2::dev_malloc(&p->d_sell_t, sizeof(uint32_t) * L));
     if (pol > 1) {
-        CM2_HIP(hipMalloc(&p->d_sell_cos, sizeof(double) * L));
-        CM2_HIP(hipMalloc(&p->d_sell_sin, sizeof(double) * L));
+        CM2_HIP(cm2::dev_malloc(&p->d_sell_cos, sizeof(double) * L));
+        CM2_HIP(cm2::dev_malloc(&p->d_sell_sin, sizeof(double) * L));
     }
     const int g = (int)((p->nslots + kBlock - 1) / kBlock);
 #define CM2_FILL(POL)                                                                       \
@@ -526,7 +526,7 @@ extern "C" int cm2_pointing_set_weights(cm2_pointing *p, const double *d_w, void
     hipStream_t stream = as_stream(stream_);
     if (int rc = ensure_sell(p, stream)) return rc;
     const int64_t L = p->sell_len > 0 ? p->sell_len : 1;
-    if (!p->d_sell_w) CM2_HIP(hipMalloc(&p->d_sell_w, sizeof(double) * L));
+    if (!p->d_sell_w) CM2_HIP(cm2::dev_malloc(&p->d_sell_w, sizeof(double) * L));
     if (p->sell_len > 0) {
         k_gather_w<<<grid_for(p->sell_len), kBlock, 0, stream>>>(p->sell_len, p->d_sell_t, d_w,
                                                                  p->d_sell_w);

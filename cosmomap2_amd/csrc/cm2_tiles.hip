@@ -33,6 +33,7 @@
 #include "cm2_tiles.h"
 
 #include <hipcub/hipcub.hpp>
+#include <cstring>
 
 using namespace cm2;
 
@@ -97,6 +98,106 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict_
         if (keys[mid] < (uint32_t)b) lo = mid + 1; else hi = mid;
     }
     off[b] = lo;
+}
+
+// ---- stable partition by tile without a sort ("multisplit") -----------------------------------
+// Every wave owns kSplitChunk consecutive time samples.  Pass 1 (k_tile_rank): per sample its tile
+// and its rank among the EARLIER samples of the same tile in the chunk -- 64 samples at a time:
+// rank inside the row by comparing with every lower lane, plus the tile's running count in a
+// wave-private LDS histogram (read by all lanes of the row, advanced by the last lane of each
+// tile) -- and the chunk's count of every tile, stored tile-major.  One exclusive scan over the
+// tile-major counts IS the tile order: base[tile][chunk] = first address of that chunk's samples
+// of that tile.  Pass 2 (k_tile_place): address = base[tile][chunk] + rank.  The addresses are
+// those of a stable sort by tile; nothing here depends on the order in which waves run.
+constexpr int kSplitChunk = 8192;                        // samples per wave (rank fits 16 bits)
+constexpr int64_t kSplitMaxTiles = 8192;                 // 4 wave histograms of u16 in 64 KB of LDS
+
+__global__ __launch_bounds__(256) void k_tile_rank(const int32_t *__restrict__ pix, int64_t nt, int tp,
+                                                    const int64_t *__restrict__ p0, uint32_t ntiles,
+                                                    int64_t npix, int64_t nchunks,
+                                                    uint32_t *__restrict__ packed,
+                                                    uint32_t *__restrict__ cnt_t,
+                                                    unsigned int *__restrict__ bad)
+{
+    extern __shared__ uint16_t hist_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t *hist = hist_all + (size_t)wave * ntiles;
+    for (uint32_t b = lane; b < ntiles; b += 64) hist[b] = 0;
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= nchunks) return;
+    const int64_t i0 = c * kSplitChunk, i1 = i0 + kSplitChunk < nt ? i0 + kSplitChunk : nt;
+    unsigned int b_ = 0;
+    for (int64_t i = i0; i < i1; i += 64) {
+        const int64_t idx = i + lane;
+        const bool in = idx < i1;
+        const int32_t p = in ? pix[idx] : -1;
+        if (p < -1 || p >= npix) b_ = 1;                 // same rule as cm2_pointing_create
+        const bool valid = p >= 0 && p < npix;
+        const int tile = valid ? (int)tile_of(p, tp, p0, ntiles) : -1;
+        int rank = 0, same = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int tj = __builtin_amdgcn_readlane(tile, j);
+            const int eq = tj == tile ? 1 : 0;
+            same += eq;
+            rank += j < lane ? eq : 0;
+        }
+        if (valid) {
+            const uint32_t r = (uint32_t)hist[tile] + (uint32_t)rank;
+            packed[idx] = ((uint32_t)tile << 16) | r;
+            if (rank == same - 1) hist[tile] = (uint16_t)(r + 1);
+        } else if (in) {
+            packed[idx] = 0xFFFFFFFFu;
+        }
+    }
+    for (uint32_t b = lane; b < ntiles; b += 64) cnt_t[(int64_t)b * nchunks + c] = hist[b];
+    if (b_) atomicOr(bad, 1u);
+}
+
+// off[b] = first address of tile b (b <= ntiles: the last one is the number of valid samples)
+__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ base, int64_t nchunks,
+                                                       int64_t ntiles, int64_t *__restrict__ off)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= ntiles) off[b] = base[b * nchunks];
+}
+
+template <int POL, bool HALF>
+__global__ __launch_bounds__(256) void k_tile_place(
+    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t nchunks,
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ base,
+    const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
+    uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb,
+    double *__restrict__ stb)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
+        const uint32_t pk = packed[i];
+        if (pk == 0xFFFFFFFFu) {
+            tb_dst[i] = kInvalidSample;                  // flagged samples sort behind every tile
+            continue;
+        }
+        const int64_t tile = pk >> 16;
+        const uint32_t k = base[tile * nchunks + i / kSplitChunk] + (pk & 0xFFFFu);
+        tb_dst[i] = k;
+        const int32_t px = pix[i];
+        uint16_t w = p0 ? (uint16_t)(px - p0[tile]) : (uint16_t)(px - (int32_t)tile * tp);
+        if (POL > 1) {
+            if (HALF) {
+                const double cv = c[i], sv = s[i];
+                if (cv < 0.0) {
+                    w |= 0x8000;
+                    ctb[k] = sv / (1.0 - cv);
+                } else {
+                    ctb[k] = sv / (1.0 + cv);
+                }
+            } else {
+                ctb[k] = c[i];
+                stb[k] = s[i];
+            }
+        }
+        pl[k] = w;
+    }
 }
 
 // 1 if some (cos, sin) pair is not on the unit circle to rounding: then the half-angle form
@@ -396,7 +497,7 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t)
     void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
                     t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off, t->d_tile_p0};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) (void)cm2::dev_free(q);
     cm2::fx_free(t);
     delete t;
     return 0;
@@ -425,21 +526,28 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     if (const char *e = getenv("CM2_PT_ORDER"))          // atomic | exact | fixed (default)
         t->pt_fixed = !strcmp(e, "atomic") ? 0 : (!strcmp(e, "exact") ? 2 : 1);
 
-    DevTemp<uint32_t> keys_in, keys_out, vals_in, tb_src;
+    // Stable partition of the samples by tile.  Default: the multisplit above (k_tile_rank, one
+    // scan, k_tile_place).  With more tiles than its LDS histograms hold, or CM2_TILE_BUILD=sort:
+    // a radix sort of (tile, time) pairs and a gather (k_tile_fill).  Same addresses either way.
+    bool use_sort = false;
+    if (const char *e = getenv("CM2_TILE_BUILD")) use_sort = strcmp(e, "sort") == 0;
+    DevTemp<uint32_t> keys_in, keys_out, vals_in, tb_src;      // sort path
+    DevTemp<uint32_t> packed, cnt_t;                           // multisplit: tile << 16 | rank; counts -> bases
+    const int64_t nchunks = (nt + kSplitChunk - 1) / kSplitChunk;
     DevTemp<int64_t> d_off;
     DevTemp<char> d_temp;
-    CM2_HIP(keys_in.alloc(nt));
-    CM2_HIP(keys_out.alloc(nt));
-    CM2_HIP(vals_in.alloc(nt));
-    CM2_HIP(tb_src.alloc(nt));
     DevTemp<unsigned int> d_bad;
     CM2_HIP(d_bad.alloc(1));
     CM2_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), stream));
     std::vector<int64_t> off;
-    // stable partition of the samples by tile; p0 == nullptr: uniform tiles of tile_pixels
-    auto partition = [&](const int64_t *d_p0) -> int {
-        d_off.release();
-        CM2_HIP(d_off.alloc(t->ntiles + 1));
+    bool sorted = false;                                       // which path the last partition took
+    auto partition_sort = [&](const int64_t *d_p0) -> int {
+        if (!keys_in.p) {
+            CM2_HIP(keys_in.alloc(nt));
+            CM2_HIP(keys_out.alloc(nt));
+            CM2_HIP(vals_in.alloc(nt));
+            CM2_HIP(tb_src.alloc(nt));
+        }
         k_tile_keys<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, tile_pixels, d_p0,
                                                          (uint32_t)t->ntiles, npix, keys_in, vals_in,
                                                          d_bad);
@@ -456,6 +564,36 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         k_tile_bounds<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
             keys_out, nt, t->ntiles, d_off);
         CM2_LAUNCH_OK();
+        return 0;
+    };
+    auto partition_split = [&](const int64_t *d_p0) -> int {
+        const int64_t ncnt = t->ntiles * nchunks + 1;          // (+1: the scan's last word = nvalid)
+        if (!packed.p) CM2_HIP(packed.alloc(nt));
+        cnt_t.release();
+        CM2_HIP(cnt_t.alloc(ncnt));
+        CM2_HIP(hipMemsetAsync(cnt_t.p + (ncnt - 1), 0, sizeof(uint32_t), stream));
+        const size_t lds = sizeof(uint16_t) * 4 * (size_t)t->ntiles;
+        static size_t granted[64] = {0};
+        CM2_HIP(ensure_dynamic_lds((const void *)k_tile_rank, lds, granted));
+        k_tile_rank<<<(unsigned)((nchunks + 3) / 4), 256, lds, stream>>>(
+            d_pix, nt, tile_pixels, d_p0, (uint32_t)t->ntiles, npix, nchunks, packed, cnt_t, d_bad);
+        CM2_LAUNCH_OK();
+        CM2_CHECK(ncnt < ((int64_t)1 << 31), "cm2_tiles_create: %lld tile x chunk counts", (long long)ncnt);
+        size_t tb = 0;
+        CM2_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt_t.p, cnt_t.p, (int)ncnt, stream));
+        d_temp.release();
+        CM2_HIP(d_temp.alloc(tb + 16));
+        CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb, cnt_t.p, cnt_t.p, (int)ncnt, stream));
+        k_tile_offsets<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            cnt_t, nchunks, t->ntiles, d_off);
+        CM2_LAUNCH_OK();
+        return 0;
+    };
+    auto partition = [&](const int64_t *d_p0) -> int {
+        d_off.release();
+        CM2_HIP(d_off.alloc(t->ntiles + 1));
+        sorted = use_sort || t->ntiles > kSplitMaxTiles || t->ntiles * nchunks + 1 >= ((int64_t)1 << 31);
+        if (int rc = sorted ? partition_sort(d_p0) : partition_split(d_p0)) return rc;
         off.assign((size_t)t->ntiles + 1, 0);
         CM2_HIP(hipMemcpyAsync(off.data(), d_off, sizeof(int64_t) * (t->ntiles + 1),
                                hipMemcpyDeviceToHost, stream));
@@ -544,18 +682,18 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         if (int rc = partition(d_p0.p)) return rc;
     }
     t->balanced = balance;
-    CM2_HIP(hipMalloc(&t->d_tile_p0, sizeof(int64_t) * (t->ntiles + 1)));
+    CM2_HIP(cm2::dev_malloc(&t->d_tile_p0, sizeof(int64_t) * (t->ntiles + 1)));
     CM2_HIP(hipMemcpy(t->d_tile_p0, t->tile_p0.data(), sizeof(int64_t) * (t->ntiles + 1),
                       hipMemcpyHostToDevice));
     t->nvalid = off[t->ntiles];
     t->tile_off = off;
-    CM2_HIP(hipMalloc(&t->d_tile_off, sizeof(int64_t) * (t->ntiles + 1)));
+    CM2_HIP(cm2::dev_malloc(&t->d_tile_off, sizeof(int64_t) * (t->ntiles + 1)));
     CM2_HIP(hipMemcpyAsync(t->d_tile_off, d_off, sizeof(int64_t) * (t->ntiles + 1),
                            hipMemcpyDeviceToDevice, stream));
 
     const int64_t nv = t->nvalid > 0 ? t->nvalid : 1;
-    CM2_HIP(hipMalloc(&t->d_tb_dst, sizeof(uint32_t) * nt));
-    CM2_HIP(hipMalloc(&t->d_pl, sizeof(uint16_t) * nv));
+    CM2_HIP(cm2::dev_malloc(&t->d_tb_dst, sizeof(uint32_t) * nt));
+    CM2_HIP(cm2::dev_malloc(&t->d_pl, sizeof(uint16_t) * nv));
     // half-angle storage (one double per sample instead of cos and sin) when every pair lies
     // on the unit circle; CM2_TILE_ANGLES=full keeps both arrays
     t->half = false;
@@ -575,17 +713,25 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     }
     if (pol > 1) {
         if (t->half) {
-            CM2_HIP(hipMalloc(&t->d_half, sizeof(double) * nv));
+            CM2_HIP(cm2::dev_malloc(&t->d_half, sizeof(double) * nv));
         } else {
-            CM2_HIP(hipMalloc(&t->d_cos, sizeof(double) * nv));
-            CM2_HIP(hipMalloc(&t->d_sin, sizeof(double) * nv));
+            CM2_HIP(cm2::dev_malloc(&t->d_cos, sizeof(double) * nv));
+            CM2_HIP(cm2::dev_malloc(&t->d_sin, sizeof(double) * nv));
         }
     }
 #define CM2_TF(POL, HALF)                                                                      \
-    k_tile_fill<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                               \
-        nt, t->nvalid, tile_pixels, balance ? t->d_tile_p0 : nullptr, (uint32_t)t->ntiles, tb_src,  \
-        d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,                                             \
-        HALF ? t->d_half : t->d_cos, t->d_sin)
+    do {                                                                                       \
+        if (sorted)                                                                            \
+            k_tile_fill<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                       \
+                nt, t->nvalid, tile_pixels, balance ? t->d_tile_p0 : nullptr,                  \
+                (uint32_t)t->ntiles, tb_src, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,        \
+                HALF ? t->d_half : t->d_cos, t->d_sin);                                        \
+        else                                                                                   \
+            k_tile_place<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                      \
+                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, nchunks, packed, cnt_t,     \
+                d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl, HALF ? t->d_half : t->d_cos,        \
+                t->d_sin);                                                                     \
+    } while (0)
     if (pol == 1) CM2_TF(1, false);
     else if (pol == 2) { if (t->half) CM2_TF(2, true); else CM2_TF(2, false); }
     else { if (t->half) CM2_TF(3, true); else CM2_TF(3, false); }
@@ -607,9 +753,9 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     t->tile_item0[(size_t)t->ntiles] = (int64_t)it_tile.size();
     t->nitems = (int64_t)it_tile.size();
     const int64_t ni = t->nitems > 0 ? t->nitems : 1;
-    CM2_HIP(hipMalloc(&t->d_item_tile, sizeof(int32_t) * ni));
-    CM2_HIP(hipMalloc(&t->d_item_k0, sizeof(int64_t) * ni));
-    CM2_HIP(hipMalloc(&t->d_item_k1, sizeof(int64_t) * ni));
+    CM2_HIP(cm2::dev_malloc(&t->d_item_tile, sizeof(int32_t) * ni));
+    CM2_HIP(cm2::dev_malloc(&t->d_item_k0, sizeof(int64_t) * ni));
+    CM2_HIP(cm2::dev_malloc(&t->d_item_k1, sizeof(int64_t) * ni));
     if (t->nitems) {
         CM2_HIP(hipMemcpy(t->d_item_tile, it_tile.data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
         CM2_HIP(hipMemcpy(t->d_item_k0, it_k0.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
@@ -818,10 +964,10 @@ static int perm_lists(const cm2_tiles *tc, hipStream_t st, bool *use)
         CM2_HIP(vals_in.alloc(total));
         uint32_t *lk = nullptr;
         uint16_t *lq = nullptr;
-        CM2_HIP(hipMalloc(&lk, sizeof(uint32_t) * total));
+        CM2_HIP(cm2::dev_malloc(&lk, sizeof(uint32_t) * total));
         DevTemp<uint32_t> guard_k;
         guard_k.p = lk;
-        CM2_HIP(hipMalloc(&lq, sizeof(uint16_t) * total));
+        CM2_HIP(cm2::dev_malloc(&lq, sizeof(uint16_t) * total));
         DevTemp<uint16_t> guard_q;
         guard_q.p = lq;
         k_perm_keys<<<grid_for(total), kBlock, 0, st>>>(t->nt, nwin, t->d_tb_dst, keys_in, vals_in);

@@ -39,6 +39,7 @@
 //     thread and slice, and no dependent round trip).
 #include "cm2_tiles.h"
 
+#include <cstring>
 #include <mutex>
 
 #include <hipcub/hipcub.hpp>
@@ -506,6 +507,273 @@ __global__ __launch_bounds__(64) void k_fx_pack(
     }
 }
 
+// ---- the same lists built by one workgroup per slice ------------------------------------------------
+// k_fx_keys + a global radix sort + one THREAD per slice walking ~1500 sorted entries (k_fx_pack) cost
+// 14 ms at C4.  k_fx_build does the whole slice in LDS: a bitonic sort of (pixel, position) keys, the
+// runs from a flag scan, and a packing that needs no walk: runs are placed by CLASS with ranks from a
+// scan --
+//   runs of 5 .. 60 entries ("long") first, each in ceil(L / 4) consecutive groups with levels 0, 1, ..;
+//     rows of 64 groups (= one wave of the P^T kernel): run i with u_i = groups of the long runs before it
+//     goes to row u_i / 50 at offset u_i - (u of the row's first run) <= 49, so it ends inside the row;
+//   then the runs of 4, the runs of 3 (slot 3 takes a single), the runs of 2 in pairs (an odd one out
+//     takes two singles), the remaining singles four to a group.
+// What the P^T kernel needs holds as before: a run's entries are in time order, the pieces of a long
+// run are consecutive groups of one wave, a pixel appears in one run per slice.  The sums per pixel
+// are the same sums in the same order as with k_fx_pack's lists; only the packing differs (a few
+// per cent fewer groups: k_fx_pack closes a group when the next run does not fit).
+// Pass 1 (WRITE = false) sorts, stores the sorted keys in ent and counts; pass 2 reads ent and writes.
+constexpr int kFbT = 256, kFbMaxS = 4 * kFxT, kFbPer = kFbMaxS / kFbT;
+constexpr int kFbMaxGroups = 1280;       // 2048 entries: <= 0.4 groups an entry (runs of 5) x 64 / 50
+constexpr int kFbRow = 64 - (kFxMaxLevel + 1) + 1;
+
+__device__ __forceinline__ uint64_t fb_exscan(uint64_t v, uint64_t *tmp, uint64_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)inc, d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint64_t before = inc - v;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < kFbT / 64; ++w) {
+        if (w < wave) before += tmp[w];
+        total += tmp[w];
+    }
+    __syncthreads();
+    return before;
+}
+
+template <bool WRITE, int NANG>
+__global__ __launch_bounds__(kFbT) void k_fx_build(
+    int64_t nslices, uint32_t qmask, const int64_t *__restrict__ slice_k0,
+    const uint16_t *__restrict__ pl, uint32_t *__restrict__ ent, const double *__restrict__ a_tb,
+    const double *__restrict__ b_tb, uint32_t *__restrict__ counts, const uint2 *__restrict__ meta,
+    const uint32_t *__restrict__ tent_off, uint32_t *__restrict__ gent, double *__restrict__ ga,
+    double *__restrict__ gb, uint2 *__restrict__ trun, uint32_t *__restrict__ tent,
+    double *__restrict__ ta, double *__restrict__ tb, unsigned int *__restrict__ overflow)
+{
+    __shared__ uint32_t keys[kFbMaxS];
+    __shared__ uint16_t rs[kFbMaxS + 1];
+    __shared__ uint64_t tmp[kFbT / 64];
+    __shared__ uint32_t rowfirst[64];
+    __shared__ uint32_t misc[2];
+    __shared__ uint32_t tails[2 * (kFbMaxS / (4 * (kFxMaxLevel + 1)) + 2)];   // (first sorted entry, first tail entry) per tail run
+    __shared__ uint32_t stage[WRITE ? 4 * kFbMaxGroups : 4];
+    const int64_t s = blockIdx.x;
+    if (s >= nslices) return;
+    const int t = threadIdx.x;
+    const int64_t k0 = slice_k0[s];
+    const int len = (int)(slice_k0[s + 1] - k0);
+    if (!WRITE) {
+        int NS = 64;
+        while (NS < len) NS <<= 1;
+        for (int i = t; i < NS; i += kFbT) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (i < len) {
+                const uint32_t w = pl[k0 + i];
+                key = ((w & qmask) << 12) | ((uint32_t)i << 1) | ((w & ~qmask & 0xFFFFu) ? 1u : 0u);
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= NS; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < NS / 2; i += kFbT) {
+                    const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                    const uint32_t a = keys[lo], b = keys[hi];
+                    const bool asc = (lo & k) == 0;
+                    if ((a > b) == asc) {
+                        keys[lo] = b;
+                        keys[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = t; i < len; i += kFbT) ent[k0 + i] = keys[i];
+    } else {
+        for (int i = t; i < len; i += kFbT) keys[i] = ent[k0 + i];
+        __syncthreads();
+    }
+    // ---- runs: rs[r] = first sorted entry of run r ----
+    int nst = 0;
+    bool st[kFbPer];
+#pragma unroll
+    for (int u = 0; u < kFbPer; ++u) {
+        const int j = kFbPer * t + u;
+        st[u] = j < len && (j == 0 || (keys[j] >> 12) != (keys[j - 1] >> 12));
+        nst += st[u] ? 1 : 0;
+    }
+    uint64_t tot = 0;
+    int r0 = (int)fb_exscan((uint64_t)nst, tmp, tot);
+    const int nruns = (int)tot;
+#pragma unroll
+    for (int u = 0; u < kFbPer; ++u)
+        if (st[u]) rs[r0++] = (uint16_t)(kFbPer * t + u);
+    if (t == 0) {
+        rs[nruns] = (uint16_t)len;
+        misc[0] = 0;
+        misc[1] = 0;
+    }
+    if (t < 64) rowfirst[t] = 0xFFFFFFFFu;
+    __syncthreads();
+    // ---- classes and ranks: A = singles | pairs << 12 | triples << 24 | fours << 36,
+    //      B = long groups | tail runs << 12 | tail entries << 24 ----
+    uint64_t sumA = 0, sumB = 0;
+    int L[kFbPer];
+#pragma unroll
+    for (int u = 0; u < kFbPer; ++u) {
+        const int r = kFbPer * t + u;
+        L[u] = r < nruns ? (int)rs[r + 1] - (int)rs[r] : 0;
+        if (L[u] == 0) continue;
+        if (L[u] <= 4) sumA += (uint64_t)1 << (12 * (L[u] - 1));
+        else if (L[u] <= 4 * (kFxMaxLevel + 1)) sumB += (uint64_t)((L[u] + 3) / 4);
+        else sumB += ((uint64_t)1 << 12) | ((uint64_t)L[u] << 24);
+    }
+    uint64_t totA = 0, totB = 0;
+    uint64_t exA = fb_exscan(sumA, tmp, totA);
+    uint64_t exB = fb_exscan(sumB, tmp, totB);
+    const int n1 = (int)(totA & 0xFFF), n2 = (int)((totA >> 12) & 0xFFF), n3 = (int)((totA >> 24) & 0xFFF),
+              n4 = (int)((totA >> 36) & 0xFFF);
+    const int ntr = (int)((totB >> 12) & 0xFFF), nte = (int)(totB >> 24);
+    // rows of the long runs
+    {
+        uint64_t b = exB;
+#pragma unroll
+        for (int u = 0; u < kFbPer; ++u) {
+            if (L[u] > 4 && L[u] <= 4 * (kFxMaxLevel + 1)) {
+                const uint32_t uu = (uint32_t)(b & 0xFFF);
+                atomicMin(&rowfirst[uu / kFbRow], uu);
+                atomicMax(&misc[1], (uint32_t)((L[u] - 1) / 4));
+                b += (uint64_t)((L[u] + 3) / 4);
+            } else if (L[u] > 4 * (kFxMaxLevel + 1)) {
+                b += ((uint64_t)1 << 12) | ((uint64_t)L[u] << 24);
+            }
+        }
+    }
+    __syncthreads();
+    int pos[kFbPer];
+    {
+        uint64_t b = exB;
+#pragma unroll
+        for (int u = 0; u < kFbPer; ++u) {
+            pos[u] = 0;
+            if (L[u] > 4 && L[u] <= 4 * (kFxMaxLevel + 1)) {
+                const uint32_t uu = (uint32_t)(b & 0xFFF), row = uu / kFbRow;
+                pos[u] = (int)(64 * row + uu - rowfirst[row]);
+                atomicMax(&misc[0], (uint32_t)(pos[u] + (L[u] + 3) / 4));
+                b += (uint64_t)((L[u] + 3) / 4);
+            } else if (L[u] > 4 * (kFxMaxLevel + 1)) {
+                b += ((uint64_t)1 << 12) | ((uint64_t)L[u] << 24);
+            }
+        }
+    }
+    __syncthreads();
+    const int GL = (int)misc[0], maxlev = (int)misc[1];
+    const int odd2 = n2 & 1;
+    const int s1 = n1 > n3 ? n1 - n3 : 0;
+    const int x2 = odd2 ? (s1 < 2 ? s1 : 2) : 0;
+    const int ng = GL + n4 + n3 + (n2 + 1) / 2 + (s1 - x2 + 3) / 4;
+    if (!WRITE) {
+        if (t == 0) {
+            counts[4 * s] = (uint32_t)ng;
+            counts[4 * s + 1] = (uint32_t)ntr;
+            counts[4 * s + 2] = (uint32_t)nte;
+            counts[4 * s + 3] = (uint32_t)maxlev;
+        }
+        return;
+    }
+    if (ng > kFbMaxGroups) {                              // (cannot happen for S <= 2048; never write past the stage)
+        if (t == 0) atomicOr(overflow, 1u);
+        return;
+    }
+    for (int i = t; i < 4 * ng; i += kFbT) stage[i] = kFxNull;
+    __syncthreads();
+    const int64_t g_base = (int64_t)meta[s].x;
+    const int64_t tr_base = (int64_t)(meta[s].y & 0x0FFFFFFFu);
+    const uint32_t te_base = tent_off[s];
+    {
+        uint64_t a = exA, b = exB;
+        const int G4 = GL, G3 = GL + n4, G2 = G3 + n3, G1 = G2 + (n2 + 1) / 2;
+#pragma unroll
+        for (int u = 0; u < kFbPer; ++u) {
+            if (L[u] == 0) continue;
+            const int j0 = (int)rs[kFbPer * t + u];
+            auto value = [&](int m) {
+                const uint32_t key = keys[j0 + m];
+                return (key >> 12) | ((key & 1u) << 15) | (((key >> 1) & 0x7FFu) << 16);
+            };
+            if (L[u] == 1) {
+                const int sr = (int)(a & 0xFFF);
+                int g, slot;
+                if (sr < n3) {
+                    g = G3 + sr;
+                    slot = 3;
+                } else if (sr - n3 < x2) {
+                    g = G2 + n2 / 2;
+                    slot = 2 + (sr - n3);
+                } else {
+                    const int q = sr - n3 - x2;
+                    g = G1 + q / 4;
+                    slot = q % 4;
+                }
+                stage[4 * g + slot] = value(0);
+                a += 1;
+            } else if (L[u] == 2) {
+                const int r2 = (int)((a >> 12) & 0xFFF);
+                const int g = G2 + r2 / 2, slot = (r2 & 1) * 2;
+                stage[4 * g + slot] = value(0);
+                stage[4 * g + slot + 1] = value(1);
+                a += (uint64_t)1 << 12;
+            } else if (L[u] == 3) {
+                const int g = G3 + (int)((a >> 24) & 0xFFF);
+                for (int m = 0; m < 3; ++m) stage[4 * g + m] = value(m);
+                a += (uint64_t)1 << 24;
+            } else if (L[u] == 4) {
+                const int g = G4 + (int)((a >> 36) & 0xFFF);
+                for (int m = 0; m < 4; ++m) stage[4 * g + m] = value(m);
+                a += (uint64_t)1 << 36;
+            } else if (L[u] <= 4 * (kFxMaxLevel + 1)) {
+                for (int m = 0; m < L[u]; ++m)
+                    stage[4 * pos[u] + m] = value(m) | ((uint32_t)(m / 4) << 28);
+                b += (uint64_t)((L[u] + 3) / 4);
+            } else {
+                const int tr = (int)((b >> 12) & 0xFFF);
+                const uint32_t e0 = te_base + (uint32_t)(b >> 24);
+                trun[tr_base + tr] = make_uint2(e0, keys[j0] >> 12);
+                tails[2 * tr] = (uint32_t)j0 | ((uint32_t)L[u] << 16);
+                tails[2 * tr + 1] = e0;
+                b += ((uint64_t)1 << 12) | ((uint64_t)L[u] << 24);
+            }
+        }
+    }
+    __syncthreads();
+    // the runs kept out of the groups: their entries, in time order
+    for (int tr = 0; tr < ntr; ++tr) {
+        const int j0 = (int)(tails[2 * tr] & 0xFFFFu), Lr = (int)(tails[2 * tr] >> 16);
+        const uint32_t e0 = tails[2 * tr + 1];
+        for (int m = t; m < Lr; m += kFbT) {
+            const uint32_t key = keys[j0 + m];
+            const uint32_t w = (key >> 12) | ((key & 1u) << 15) | (((key >> 1) & 0x7FFu) << 16);
+            tent[e0 + m] = w;
+            const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
+            if (NANG >= 1) ta[e0 + m] = a_tb[src];
+            if (NANG == 2) tb[e0 + m] = b_tb[src];
+        }
+    }
+    for (int i = t; i < 4 * ng; i += kFbT) {
+        const uint32_t w = stage[i];
+        gent[4 * g_base + i] = w;
+        const int64_t src = k0 + (int64_t)((w >> 16) & 0xFFFu);
+        if (NANG >= 1) ga[4 * g_base + i] = w == kFxNull ? 0.0 : a_tb[src];
+        if (NANG == 2) gb[4 * g_base + i] = w == kFxNull ? 0.0 : b_tb[src];
+    }
+}
+
 size_t fx_lds_bytes(const cm2_tiles *t, int S)
 {
     int vpt = (S + kFxT - 1) / kFxT;
@@ -518,7 +786,7 @@ void hot_release(cm2_tiles *t)
     void **ptrs[] = {(void **)&t->d_hot_flag, (void **)&t->d_hot_range, (void **)&t->d_hot_tiles,
                      (void **)&t->d_hot_partial};
     for (void **q : ptrs) {
-        if (*q) (void)hipFree(*q);
+        if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
     }
     t->hot_tile.clear();
@@ -548,10 +816,10 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
         t->hot_chunk0.push_back((int64_t)range.size() / 2);
     }
     if (t->hot_tile.empty()) return 0;
-    CM2_HIP(hipMalloc(&t->d_hot_flag, flag.size()));
-    CM2_HIP(hipMalloc(&t->d_hot_range, sizeof(int64_t) * range.size()));
-    CM2_HIP(hipMalloc(&t->d_hot_tiles, sizeof(int64_t) * tiles.size()));
-    CM2_HIP(hipMalloc(&t->d_hot_partial, sizeof(double) * 3 * (range.size() / 2)));
+    CM2_HIP(cm2::dev_malloc(&t->d_hot_flag, flag.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_hot_range, sizeof(int64_t) * range.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_hot_tiles, sizeof(int64_t) * tiles.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_hot_partial, sizeof(double) * 3 * (range.size() / 2)));
     CM2_HIP(hipMemcpyAsync(t->d_hot_flag, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
     CM2_HIP(hipMemcpyAsync(t->d_hot_range, range.data(), sizeof(int64_t) * range.size(), hipMemcpyHostToDevice, st));
     CM2_HIP(hipMemcpyAsync(t->d_hot_tiles, tiles.data(), sizeof(int64_t) * tiles.size(), hipMemcpyHostToDevice, st));
@@ -585,7 +853,7 @@ void fx_release(cm2_tiles *t)
                      (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
                      (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb};
     for (void **q : ptrs) {
-        if (*q) (void)hipFree(*q);
+        if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
     }
     t->fx_S = 0;
@@ -608,7 +876,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
     k0.push_back(nv);
     // (a tile's last slice ends where the next tile's first one starts: k0 is the cut list)
     CM2_CHECK(nslices < ((int64_t)1 << 31), "cm2_tiles: too many slices");
-    CM2_HIP(hipMalloc(&t->d_fx_slice0, sizeof(int64_t) * slice0.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_fx_slice0, sizeof(int64_t) * slice0.size()));
     CM2_HIP(hipMemcpyAsync(t->d_fx_slice0, slice0.data(), sizeof(int64_t) * slice0.size(),
                            hipMemcpyHostToDevice, st));
     std::vector<uint2> meta((size_t)nslices + 1, make_uint2(0, 0));
@@ -620,30 +888,44 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         DevTemp<int64_t> d_k0;
         DevTemp<uint64_t> keys_in, keys_out;
         DevTemp<uint32_t> vals_in, ent, d_counts, d_tent_off;
+        DevTemp<unsigned int> d_overflow;
         DevTemp<char> d_temp;
         CM2_HIP(d_k0.alloc(k0.size()));
         CM2_HIP(hipMemcpyAsync(d_k0, k0.data(), sizeof(int64_t) * k0.size(), hipMemcpyHostToDevice, st));
-        CM2_HIP(keys_in.alloc(nv));
-        CM2_HIP(keys_out.alloc(nv));
-        CM2_HIP(vals_in.alloc(nv));
         CM2_HIP(ent.alloc(nv));
-        const uint32_t qmask = t->half ? 0x7FFFu : 0xFFFFu;
-        k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_tile_off,
-                                                  t->d_fx_slice0, t->d_pl, keys_in, vals_in);
-        CM2_LAUNCH_OK();
-        int end_bit = 17;
-        while (((int64_t)1 << (end_bit - 16)) <= nslices && end_bit < 64) ++end_bit;
-        size_t tb = 0;
-        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                   ent.p, nv, 0, end_bit, st));
-        CM2_HIP(d_temp.alloc(tb + 16));
-        CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
-                                                   ent.p, nv, 0, end_bit, st));
         CM2_HIP(d_counts.alloc(4 * nslices));
+        CM2_HIP(d_overflow.alloc(1));
+        CM2_HIP(hipMemsetAsync(d_overflow.p, 0, sizeof(unsigned int), st));
+        const uint32_t qmask = t->half ? 0x7FFFu : 0xFFFFu;
         const int pgrid = (int)((nslices + 63) / 64);
-        k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
-                                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                               nullptr, nullptr, nullptr);
+        // one workgroup per slice (k_fx_build) unless CM2_FX_BUILD=serial asks for the radix sort and
+        // the one-thread-per-slice packer (k_fx_pack): other lists, the same sums
+        bool serial = false;
+        if (const char *e = getenv("CM2_FX_BUILD")) serial = strcmp(e, "serial") == 0;
+        if (S > kFbMaxS) serial = true;
+        if (serial) {
+            CM2_HIP(keys_in.alloc(nv));
+            CM2_HIP(keys_out.alloc(nv));
+            CM2_HIP(vals_in.alloc(nv));
+            k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_tile_off,
+                                                      t->d_fx_slice0, t->d_pl, keys_in, vals_in);
+            CM2_LAUNCH_OK();
+            int end_bit = 17;
+            while (((int64_t)1 << (end_bit - 16)) <= nslices && end_bit < 64) ++end_bit;
+            size_t tb = 0;
+            CM2_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                       ent.p, nv, 0, end_bit, st));
+            CM2_HIP(d_temp.alloc(tb + 16));
+            CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
+                                                       ent.p, nv, 0, end_bit, st));
+            k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
+                                                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                   nullptr, nullptr, nullptr);
+        } else {
+            k_fx_build<false, 0><<<(unsigned)nslices, kFbT, 0, st>>>(
+                nslices, qmask, d_k0, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr, nullptr,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_overflow);
+        }
         CM2_LAUNCH_OK();
         std::vector<uint32_t> counts((size_t)(4 * nslices));
         CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(),
@@ -673,43 +955,57 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         *over = (double)nover / (double)nslices;
         // (+1 group: a slice without groups at the very end still loads "its" group 0)
         const int64_t ng1 = ngroups + 1, nt1 = ntent ? ntent : 1;
-        CM2_HIP(hipMalloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
         CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
                                hipMemcpyHostToDevice, st));
         CM2_HIP(d_tent_off.alloc(tent_off.size()));
         CM2_HIP(hipMemcpyAsync(d_tent_off, tent_off.data(), sizeof(uint32_t) * tent_off.size(),
                                hipMemcpyHostToDevice, st));
-        CM2_HIP(hipMalloc(&t->d_fx_gent, sizeof(uint4) * ng1));
-        CM2_HIP(hipMalloc(&t->d_fx_trun, sizeof(uint2) * (ntrun + 1)));
-        CM2_HIP(hipMalloc(&t->d_fx_tent, sizeof(uint32_t) * nt1));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_gent, sizeof(uint4) * ng1));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_trun, sizeof(uint2) * (ntrun + 1)));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_tent, sizeof(uint32_t) * nt1));
         if (t->pol > 1) {
-            CM2_HIP(hipMalloc(&t->d_fx_ga, sizeof(double) * 4 * ng1));
-            CM2_HIP(hipMalloc(&t->d_fx_ta, sizeof(double) * nt1));
+            CM2_HIP(cm2::dev_malloc(&t->d_fx_ga, sizeof(double) * 4 * ng1));
+            CM2_HIP(cm2::dev_malloc(&t->d_fx_ta, sizeof(double) * nt1));
             if (!t->half) {
-                CM2_HIP(hipMalloc(&t->d_fx_gb, sizeof(double) * 4 * ng1));
-                CM2_HIP(hipMalloc(&t->d_fx_tb, sizeof(double) * nt1));
+                CM2_HIP(cm2::dev_malloc(&t->d_fx_gb, sizeof(double) * 4 * ng1));
+                CM2_HIP(cm2::dev_malloc(&t->d_fx_tb, sizeof(double) * nt1));
             }
         }
         const uint2 last = make_uint2((uint32_t)ntent, 0);
         CM2_HIP(hipMemcpyAsync(t->d_fx_trun + ntrun, &last, sizeof(uint2), hipMemcpyHostToDevice, st));
 #define CM2_FX_PACK(NANG)                                                                       \
-    k_fx_pack<true, NANG><<<pgrid, 64, 0, st>>>(                                                  \
-        nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos, t->half ? nullptr : t->d_sin,  \
-        nullptr, t->d_fx_meta, d_tent_off, reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, \
-        t->d_fx_gb, t->d_fx_trun, t->d_fx_tent, t->d_fx_ta, t->d_fx_tb)
+    do {                                                                                        \
+        if (serial)                                                                             \
+            k_fx_pack<true, NANG><<<pgrid, 64, 0, st>>>(                                          \
+                nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos,                       \
+                t->half ? nullptr : t->d_sin, nullptr, t->d_fx_meta, d_tent_off,                \
+                reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, t->d_fx_gb, t->d_fx_trun, \
+                t->d_fx_tent, t->d_fx_ta, t->d_fx_tb);                                          \
+        else                                                                                    \
+            k_fx_build<true, NANG><<<(unsigned)nslices, kFbT, 0, st>>>(                           \
+                nslices, qmask, d_k0, t->d_pl, ent, t->half ? t->d_half : t->d_cos,              \
+                t->half ? nullptr : t->d_sin, nullptr, t->d_fx_meta, d_tent_off,                \
+                reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, t->d_fx_gb, t->d_fx_trun, \
+                t->d_fx_tent, t->d_fx_ta, t->d_fx_tb, d_overflow);                              \
+    } while (0)
         if (t->pol == 1) CM2_FX_PACK(0);
         else if (t->half) CM2_FX_PACK(1);
         else CM2_FX_PACK(2);
 #undef CM2_FX_PACK
         CM2_LAUNCH_OK();
+        unsigned int h_over = 0;
+        CM2_HIP(hipMemcpyAsync(&h_over, d_overflow.p, sizeof(h_over), hipMemcpyDeviceToHost, st));
         CM2_HIP(hipStreamSynchronize(st));
+        CM2_CHECK(h_over == 0, "cm2_tiles: a slice of %d samples packs into more than %d groups", S,
+                  kFbMaxGroups);
     } else {
-        CM2_HIP(hipMalloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
         CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
                                hipMemcpyHostToDevice, st));
-        CM2_HIP(hipMalloc(&t->d_fx_gent, sizeof(uint4)));
-        CM2_HIP(hipMalloc(&t->d_fx_trun, sizeof(uint2)));
-        CM2_HIP(hipMalloc(&t->d_fx_tent, sizeof(uint32_t)));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_gent, sizeof(uint4)));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_trun, sizeof(uint2)));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_tent, sizeof(uint32_t)));
         CM2_HIP(hipStreamSynchronize(st));
     }
     t->fx_S = S;

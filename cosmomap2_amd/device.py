@@ -154,3 +154,21 @@ def dot(x, y):
     out = torch.empty(1, dtype=torch.float64, device=x.device)
     _hip.call("cm2_dot", x.numel(), ptr(x), ptr(y), ptr(out), ptr(reduce_work()), stream())
     return float(out.item())
+
+
+def memory_info():
+    """Device memory of the HIP library (not torch's): bytes held by live plans and operators,
+    bytes cached for reuse, requests served from the cache / by the driver."""
+    import ctypes
+    from . import _hip
+    info = (ctypes.c_int64 * 4)()
+    _hip.call("cm2_device_memory_info", info)
+    return dict(zip(("live_bytes", "cached_bytes", "cache_hits", "driver_allocations"), [int(v) for v in info]))
+
+
+def release_cached_memory():
+    """Returns the library's cached device blocks to the driver (the counterpart of
+    torch.cuda.empty_cache() for libcosmomap2_hip.so)."""
+    from . import _hip
+    _hip.call("cm2_release_cached_memory")
+

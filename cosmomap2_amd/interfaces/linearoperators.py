@@ -617,7 +617,27 @@ class _PixelWeights(object):
         return [D.ptr(self.d[k]) for k in self.FIELDS]
 
 
-class BlockDiagonalLO(_DeviceOp):
+class _CESFields(object):
+    """The reference's per-pixel attributes of the block-diagonal operators (``counts, cos, sin,
+    cos2, sin2, sincos``: linearoperators.py:713-722, :762-771) as host arrays read from the CES
+    object when they are first asked for: the operators themselves work on the device copies
+    (``_PixelWeights``) and never need them."""
+
+    _FIELD_OF = {1: {"counts": "counts"},
+                 2: {"sin2": "sin2", "cos2": "cos2", "sincos": "sincos"},
+                 3: {"sin2": "sin2", "cos2": "cos2", "sincos": "sincos", "counts": "counts",
+                     "cos": "cosine", "sin": "sine"}}
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        src = self._FIELD_OF.get(d.get("pol"), {}).get(name)
+        if src is None or "_ces" not in d:
+            raise AttributeError(name)
+        d[name] = getattr(d["_ces"], src)
+        return d[name]
+
+
+class BlockDiagonalLO(_CESFields, _DeviceOp):
     """
     Explicit per-pixel apply of ``P^T diag(N^-1) P`` (reference:
     linearoperators.py:700-746): pol=1 ``x*counts``; pol=2 / pol=3 the 2x2 / 3x3
@@ -629,12 +649,7 @@ class BlockDiagonalLO(_DeviceOp):
         self.pol = pol
         self.pixels = np.arange(n)
         self._w = _PixelWeights(CES, n, pol)
-        if pol == 1:
-            self.counts = CES.counts
-        elif pol > 1:
-            self.sin2, self.sincos, self.cos2 = CES.sin2, CES.sincos, CES.cos2
-            if pol == 3:
-                self.counts, self.cos, self.sin = CES.counts, CES.cosine, CES.sine
+        self._ces = CES
         super(BlockDiagonalLO, self).__init__(nargin=self.size, nargout=self.size,
                                               matvec=self.mult, symmetric=True)
 
@@ -646,7 +661,7 @@ class BlockDiagonalLO(_DeviceOp):
         return D.like_input(out, x)
 
 
-class BlockDiagonalPreconditionerLO(_DeviceOp):
+class BlockDiagonalPreconditionerLO(_CESFields, _DeviceOp):
     """
     ``M_BD = (P^T diag(N^-1) P)^-1`` per pixel (reference: linearoperators.py:749-859):
     closed-form 1x1 / 2x2 / 3x3 inverse; pixels with ``|det| <= 1e-5`` (pol>1) or
@@ -659,12 +674,7 @@ class BlockDiagonalPreconditionerLO(_DeviceOp):
         self.pixels = np.arange(n)
         self.pol = pol
         self._w = _PixelWeights(CES, n, pol)
-        if pol == 1:
-            self.counts = CES.counts
-        elif pol > 1:
-            self.sin2, self.cos2, self.sincos = CES.sin2, CES.cos2, CES.sincos
-            if pol == 3:
-                self.counts, self.cos, self.sin = CES.counts, CES.cosine, CES.sine
+        self._ces = CES
         self._d_det = D.empty(n)
         self._d_mask = D.empty(n, torch.uint8)
         _hip.call("cm2_bd_det_mask", int(pol), int(n), *(self._w.ptrs() + [

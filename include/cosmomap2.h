@@ -36,6 +36,15 @@ const char *cm2_last_error(void);
 int cm2_abi_version(void);
 /* device properties used by the bench harness (name buffer >= 256 bytes) */
 int cm2_device_info(int device, char *h_name, int *h_num_cu, double *h_hbm_gib);
+/* Device memory of the library.  Every buffer a cm2_* object owns and every temporary of a plan
+ * build comes from a per-device cache of released blocks (a released block is handed out again to
+ * a request of at most 25 % less; releasing waits for the device exactly like hipFree).  The cache
+ * holds at most CM2_DEVICE_CACHE_MB megabytes (environment, default 32768; 0 = every release goes
+ * straight back to the driver).  cm2_release_cached_memory returns all cached blocks to the
+ * driver; cm2_device_memory_info fills h_info[4] = bytes in use by live objects, bytes cached,
+ * requests served from the cache, requests that went to the driver. */
+int cm2_release_cached_memory(void);
+int cm2_device_memory_info(int64_t *h_info);
 
 /* ------------------------------------------------------------------------- *
  * a1-a3  Pointing matrix  (SparseLO, interfaces/linearoperators.py:326-557)

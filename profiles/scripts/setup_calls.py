@@ -1,6 +1,6 @@
 """Where the wall clock of the one-off setup goes at C4 size: time per C entry point (each call
 followed by a synchronisation) and the Python-side remainder."""
-import os, sys, json, time, collections
+import os, sys, json, time, collections, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cosmomap2_amd import device as D, _hip
@@ -32,19 +32,24 @@ for rep in range(2):
     for mod in (L, sys.modules["cosmomap2_amd.utilities.process_ces"]):
         pass
     t0 = time.perf_counter()
-    N = BlockLO(nt // nb, bands, offdiag=True, method=3)
-    ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi)
-    npc = ces.get_new_pixel[0]
-    P = SparseLO(npc, nt, pix, pol=pol, angle_processed=ces)
-    M = BlockDiagonalPreconditionerLO(ces, npc, pol=pol)
+    stmts = {}
+    def lap(name, t=[t0]):
+        sync(); now = time.perf_counter(); stmts[name] = round(now - t[0], 4); t[0] = now
+    N = BlockLO(nt // nb, bands, offdiag=True, method=3); lap("BlockLO")
+    ces = ProcessTimeSamples(pix, npix, pol=pol, phi=phi); lap("ProcessTimeSamples")
+    npc = ces.get_new_pixel[0]; lap("get_new_pixel")
+    P = SparseLO(npc, nt, pix, pol=pol, angle_processed=ces); lap("SparseLO")
+    M = BlockDiagonalPreconditionerLO(ces, npc, pol=pol); lap("M_BD")
     A = P.T * N * P
-    T = L._sparse_tiles(P)
-    y = A * x[:pol * npc]
+    T = L._sparse_tiles(P); lap("tile plan")
+    y = A * x[:pol * npc]; lap("first matvec")
     sync()
     total = time.perf_counter() - t0
     _hip.call = orig
     inc = sum(acc.values())
     print(json.dumps({"rep": rep, "total_s": round(total, 4), "in_C_entry_points_s": round(inc, 4),
-                      "python_and_torch_s": round(total - inc, 4),
+                      "python_and_torch_s": round(total - inc, 4), "statements_s": stmts,
                       "calls": {k: [cnt[k], round(v, 4)] for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:14]}}), flush=True)
     del N, ces, P, M, A, T, y, pix, phi, x
+    gc.collect(); sync()        # (operator graphs hold reference cycles: without this the previous
+                                #  build's plans are destroyed somewhere inside the next build's timing)

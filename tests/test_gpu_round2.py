@@ -552,6 +552,151 @@ def test_cm2_PtNP_tiles_apply_is_the_three_calls(cm, oracle):
         _hip.call("cm2_PtNP_tiles_apply", T.h, N._noise.h, D.ptr(x), D.ptr(y), D.ptr(w1), D.ptr(w1), D.stream())
 
 
+@pytest.mark.parametrize("angles", ["half", "full"])
+@pytest.mark.parametrize("nt,npix,tp,hot", [(300000, 5000, 2048, 0.0), (50000, 100, 64, 0.0),
+                                            (400000, 70000, 1024, 0.0), (40000, 20, 64, 0.0),
+                                            (300000, 40000, 1024, 0.05), (4097, 64, 64, 0.0)])
+def test_fixed_order_lists_built_per_slice_in_lds_give_the_serial_packers_sums(cm, oracle, monkeypatch, nt,
+                                                                             npix, tp, hot, angles):
+    """The fixed-order P^T lists are built by one workgroup per slice (k_fx_build: bitonic sort in
+    LDS, runs placed by class from scans) instead of a global radix sort and a one-thread-per-slice
+    walk (CM2_FX_BUILD=serial).  The packing differs, the sums may not: P^T is bit-identical between
+    the two, for singles-dominated slices, runs of 5 .. 60 (levels, rows of 64 groups), runs beyond 60
+    (tail lists), a hot pixel (chunk sums), both angle storages, and equal to the oracle's serial loop
+    bit for bit where that is promised (both angle arrays, pure time order)."""
+    from types import SimpleNamespace
+    from cosmomap2_amd import _hip, device as D
+    from cosmomap2_amd.interfaces import linearoperators as L
+    pol = 3
+    monkeypatch.setenv("CM2_TILE_ANGLES", angles)
+    # (the slice length is tuned to the groups a slice packs into, which differ between the two
+    #  packers; the chunk boundaries of a hot run follow the slice length: same length for both)
+    monkeypatch.setenv("CM2_PT_SLICE", "1280")
+    rng = np.random.default_rng(99)
+    pairs = rng.integers(0, npix, nt)
+    if hot:
+        pairs[rng.random(nt) < hot] = npix // 3
+    pairs[rng.random(nt) < 0.05] = -1
+    phi = rng.uniform(0, np.pi, nt)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    v = rng.standard_normal(nt)
+    outs, groups = [], []
+    for build in ("lds", "serial"):
+        monkeypatch.setenv("CM2_FX_BUILD", build)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+        assert T.pt_fixed
+        st = D.stream()
+        v_tb, out = D.empty(T.nvalid), D.empty(pol * npix)
+        vd = D.f64(v)
+        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(vd), D.ptr(v_tb), st)
+        for order in (True, "exact"):
+            T.set_pt_order(order)
+            out.fill_(5.0)
+            _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+            outs.append(out.cpu().numpy().copy())
+    np.testing.assert_array_equal(outs[0], outs[2])          # fixed order (chunk sums for hot runs)
+    np.testing.assert_array_equal(outs[1], outs[3])          # pure time order
+    if angles == "full":
+        np.testing.assert_array_equal(outs[1], oracle.sparse_rmult(pol, npix, pairs, c, s, v))
+
+
+def test_library_device_memory_is_cached_and_released(cm):
+    """Plans and their build temporaries come from the library's cache of released device blocks
+    (cm2_core.hip): a second build of the same plan is served from the cache, live bytes return to
+    where they were once the plan is destroyed, and cm2_release_cached_memory hands everything
+    back to the driver.  Reused blocks are not zeroed -- the operator built on them must equal the
+    first one bit for bit."""
+    import gc
+    from types import SimpleNamespace
+    from cosmomap2_amd import device as D
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(5)
+    nt, npix, pol = 200000, 30000, 3
+    pairs = rng.integers(0, npix, nt)
+    pairs[rng.random(nt) < 0.05] = -1
+    phi = rng.uniform(0, np.pi, nt)
+    ang = SimpleNamespace(cos=np.cos(2 * phi), sin=np.sin(2 * phi))
+    kk = np.arange(200)
+    bands = [np.exp(-kk / 40.0)] * 4
+    x = rng.standard_normal(pol * npix)
+
+    def build_and_apply():
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=ang)
+        L._sparse_tiles(P, tile_pixels=1024, slice_samples=4096)
+        N = cm.I.BlockLO([nt // 4] * 4, bands, offdiag=True, method=3)
+        return np.asarray(L._TiledNormalLO(P, N) * x)
+
+    gc.collect()
+    D.release_cached_memory()
+    base = D.memory_info()
+    assert base["cached_bytes"] == 0
+    y0 = build_and_apply()
+    gc.collect()
+    cm.torch.cuda.synchronize()
+    after = D.memory_info()
+    assert after["live_bytes"] == base["live_bytes"]           # everything the build took is back
+    assert after["cached_bytes"] > 0
+    y1 = build_and_apply()
+    gc.collect()
+    again = D.memory_info()
+    assert again["cache_hits"] > after["cache_hits"]
+    assert again["driver_allocations"] - after["driver_allocations"] <= 2
+    np.testing.assert_array_equal(y0, y1)
+    D.release_cached_memory()
+    assert D.memory_info()["cached_bytes"] == 0
+
+
+@pytest.mark.parametrize("nt,npix,tp,balance", [(400003, 70000, 1024, "0"), (50001, 100, 64, "0"),
+                                                (300000, 262144, 64, "0"), (400003, 70000, 1024, "1"),
+                                                (8191, 3000, 64, "0"), (70, 500, 64, "0")])
+def test_tile_plan_without_a_sort_equals_the_sorted_plan(cm, oracle, monkeypatch, nt, npix, tp, balance):
+    """The tile order is built as a stable multisplit (k_tile_rank: rank of a sample among the
+    earlier samples of its tile inside a chunk of 8192, per-chunk counts, one scan; k_tile_place)
+    instead of a radix sort + gather (CM2_TILE_BUILD=sort).  Both must give the same addresses:
+    the time -> tile-order map, the per-sample words and angles (seen through P and P^T on the tile
+    order, bit for bit), for ragged sizes, 10 % flagged samples, 1 .. 4096 tiles and re-cut
+    (balanced) tiles."""
+    from types import SimpleNamespace
+    from cosmomap2_amd import _hip, device as D
+    from cosmomap2_amd.interfaces import linearoperators as L
+    pol = 3
+    rng = np.random.default_rng(77)
+    pairs = rng.integers(0, npix, nt)
+    if balance == "1":
+        pairs[: nt // 2] = rng.integers(0, npix // 10, nt // 2)      # half of the samples on a tenth
+    pairs[rng.random(nt) < 0.1] = -1
+    phi = rng.uniform(0, np.pi, nt)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    x = rng.standard_normal(pol * npix)
+    v = rng.standard_normal(nt)
+    monkeypatch.setenv("CM2_TILE_BALANCE", balance)
+    got = []
+    for build in ("split", "sort"):
+        monkeypatch.setenv("CM2_TILE_BUILD", build)
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+        st = D.stream()
+        lab = cm.torch.empty(max(T.nvalid, 1), dtype=cm.torch.int32, device="cuda")
+        tix = cm.torch.arange(nt, dtype=cm.torch.int32, device="cuda")
+        _hip.call("cm2_i32_time_to_tiles", T.h, D.ptr(tix), D.ptr(lab), st)
+        d_tb, out = D.empty(T.nvalid), D.empty(pol * npix)
+        _hip.call("cm2_P_tiles_apply", T.h, D.ptr(D.f64(x)), D.ptr(d_tb), st)
+        v_tb = D.empty(T.nvalid)
+        vd = D.f64(v)
+        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(vd), D.ptr(v_tb), st)
+        _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+        got.append((T.ntiles, T.nvalid, lab.cpu().numpy()[: T.nvalid].copy(), d_tb.cpu().numpy().copy(),
+                    out.cpu().numpy().copy()))
+    a, b = got
+    assert a[0] == b[0] and a[1] == b[1] == int((pairs >= 0).sum())
+    for u, w in zip(a[2:], b[2:]):
+        np.testing.assert_array_equal(u, w)
+    # and the order is the stable one: inside a tile the time indices ascend
+    tmap = a[2]
+    assert np.array_equal(np.sort(tmap), np.flatnonzero(pairs >= 0))
+
+
 def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkeypatch):
     """Half of the samples on a tenth of the map: the tile plan re-cuts its pixel ranges to equal
     sample counts (the fixed-order P^T gives a tile to one workgroup), P^T N^-1 P does not change
