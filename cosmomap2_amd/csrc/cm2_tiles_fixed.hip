@@ -513,8 +513,9 @@ __global__ __launch_bounds__(64) void k_fx_pack(
 // runs from a flag scan, and a packing that needs no walk: runs are placed by CLASS with ranks from a
 // scan --
 //   runs of 5 .. 60 entries ("long") first, each in ceil(L / 4) consecutive groups with levels 0, 1, ..;
-//     rows of 64 groups (= one wave of the P^T kernel): run i with u_i = groups of the long runs before it
-//     goes to row u_i / 50 at offset u_i - (u of the row's first run) <= 49, so it ends inside the row;
+//     rows of 64 groups (= one wave of the P^T kernel): with R = 64 - (groups of the slice's longest run)
+//     + 1, run i with u_i = groups of the long runs before it goes to row u_i / R at offset u_i - (u of
+//     the row's first run) <= R - 1, so it ends inside the row;
 //   then the runs of 4, the runs of 3 (slot 3 takes a single), the runs of 2 in pairs (an odd one out
 //     takes two singles), the remaining singles four to a group.
 // What the P^T kernel needs holds as before: a run's entries are in time order, the pieces of a long
@@ -524,7 +525,6 @@ __global__ __launch_bounds__(64) void k_fx_pack(
 // Pass 1 (WRITE = false) sorts, stores the sorted keys in ent and counts; pass 2 reads ent and writes.
 constexpr int kFbT = 256, kFbMaxS = 4 * kFxT, kFbPer = kFbMaxS / kFbT;
 constexpr int kFbMaxGroups = 1280;       // 2048 entries: <= 0.4 groups an entry (runs of 5) x 64 / 50
-constexpr int kFbRow = 64 - (kFxMaxLevel + 1) + 1;
 
 __device__ __forceinline__ uint64_t fb_exscan(uint64_t v, uint64_t *tmp, uint64_t &total)
 {
@@ -640,15 +640,19 @@ __global__ __launch_bounds__(kFbT) void k_fx_build(
     const int n1 = (int)(totA & 0xFFF), n2 = (int)((totA >> 12) & 0xFFF), n3 = (int)((totA >> 24) & 0xFFF),
               n4 = (int)((totA >> 36) & 0xFFF);
     const int ntr = (int)((totB >> 12) & 0xFFF), nte = (int)(totB >> 24);
-    // rows of the long runs
+    // rows of the long runs: the row length leaves room for the slice's longest run
+#pragma unroll
+    for (int u = 0; u < kFbPer; ++u)
+        if (L[u] > 4 && L[u] <= 4 * (kFxMaxLevel + 1)) atomicMax(&misc[1], (uint32_t)((L[u] - 1) / 4));
+    __syncthreads();
+    const uint32_t row_len = 64u - misc[1];              // (longest run: misc[1] + 1 groups)
     {
         uint64_t b = exB;
 #pragma unroll
         for (int u = 0; u < kFbPer; ++u) {
             if (L[u] > 4 && L[u] <= 4 * (kFxMaxLevel + 1)) {
                 const uint32_t uu = (uint32_t)(b & 0xFFF);
-                atomicMin(&rowfirst[uu / kFbRow], uu);
-                atomicMax(&misc[1], (uint32_t)((L[u] - 1) / 4));
+                atomicMin(&rowfirst[uu / row_len], uu);
                 b += (uint64_t)((L[u] + 3) / 4);
             } else if (L[u] > 4 * (kFxMaxLevel + 1)) {
                 b += ((uint64_t)1 << 12) | ((uint64_t)L[u] << 24);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kFbT) void k_fx_build(
         for (int u = 0; u < kFbPer; ++u) {
             pos[u] = 0;
             if (L[u] > 4 && L[u] <= 4 * (kFxMaxLevel + 1)) {
-                const uint32_t uu = (uint32_t)(b & 0xFFF), row = uu / kFbRow;
+                const uint32_t uu = (uint32_t)(b & 0xFFF), row = uu / row_len;
                 pos[u] = (int)(64 * row + uu - rowfirst[row]);
                 atomicMax(&misc[0], (uint32_t)(pos[u] + (L[u] + 3) / 4));
                 b += (uint64_t)((L[u] + 3) / 4);
