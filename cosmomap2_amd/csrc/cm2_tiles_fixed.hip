@@ -550,7 +550,7 @@ __device__ __forceinline__ uint64_t fb_exscan(uint64_t v, uint64_t *tmp, uint64_
 
 template <bool WRITE, int NANG>
 __global__ __launch_bounds__(kFbT) void k_fx_build(
-    int64_t nslices, uint32_t qmask, const int64_t *__restrict__ slice_k0,
+    int64_t nslices, uint32_t qmask, const int64_t *__restrict__ slice_k0, int k0_stride,
     const uint16_t *__restrict__ pl, uint32_t *__restrict__ ent, const double *__restrict__ a_tb,
     const double *__restrict__ b_tb, uint32_t *__restrict__ counts, const uint2 *__restrict__ meta,
     const uint32_t *__restrict__ tent_off, uint32_t *__restrict__ gent, double *__restrict__ ga,
@@ -567,8 +567,9 @@ __global__ __launch_bounds__(kFbT) void k_fx_build(
     const int64_t s = blockIdx.x;
     if (s >= nslices) return;
     const int t = threadIdx.x;
-    const int64_t k0 = slice_k0[s];
-    const int len = (int)(slice_k0[s + 1] - k0);
+    // (k0_stride = 1: slice s = [slice_k0[s], slice_k0[s + 1]); 2: a list of (first, end) pairs)
+    const int64_t k0 = slice_k0[s * k0_stride];
+    const int len = (int)(slice_k0[s * k0_stride + 1] - k0);
     if (!WRITE) {
         int NS = 64;
         while (NS < len) NS <<= 1;
@@ -864,6 +865,55 @@ void fx_release(cm2_tiles *t)
     t->fx_ngroups = t->fx_nslices = 0;
 }
 
+static bool fx_serial()
+{
+    const char *e = getenv("CM2_FX_BUILD");
+    return e && strcmp(e, "serial") == 0;
+}
+
+// groups per full slice of S samples and the fraction of slices with more groups than threads,
+// from every 8th full slice (k_fx_build's counting pass on ~12 % of the samples): the slice length
+// is chosen from this before anything is allocated or written
+int fx_estimate(const cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *over)
+{
+    *mean_groups = 0.0;
+    *over = 0.0;
+    std::vector<int64_t> pairs;
+    int64_t seen = 0;
+    for (int64_t b = 0; b < t->ntiles; ++b)
+        for (int64_t k = t->tile_off[(size_t)b]; k + S <= t->tile_off[(size_t)b + 1]; k += S)
+            if (seen++ % 8 == 0) {
+                pairs.push_back(k);
+                pairs.push_back(k + S);
+            }
+    const int64_t np = (int64_t)pairs.size() / 2;
+    if (np == 0) return 0;
+    DevTemp<int64_t> d_pairs;
+    DevTemp<uint32_t> ent, d_counts;
+    DevTemp<unsigned int> d_overflow;
+    CM2_HIP(d_pairs.alloc(pairs.size()));
+    CM2_HIP(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(int64_t) * pairs.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(ent.alloc(t->nvalid));
+    CM2_HIP(d_counts.alloc(4 * np));
+    CM2_HIP(d_overflow.alloc(1));
+    k_fx_build<false, 0><<<(unsigned)np, kFbT, 0, st>>>(
+        np, t->half ? 0x7FFFu : 0xFFFFu, d_pairs, 2, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr,
+        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_overflow);
+    CM2_LAUNCH_OK();
+    std::vector<uint32_t> counts((size_t)(4 * np));
+    CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(), hipMemcpyDeviceToHost, st));
+    CM2_HIP(hipStreamSynchronize(st));
+    double gsum = 0.0;
+    int64_t nover = 0;
+    for (int64_t i = 0; i < np; ++i) {
+        gsum += counts[(size_t)(4 * i)];
+        if (counts[(size_t)(4 * i)] > (uint32_t)kFxT) ++nover;
+    }
+    *mean_groups = gsum / (double)np;
+    *over = (double)nover / (double)np;
+    return 0;
+}
+
 // builds the lists for slices of S samples; *mean_groups = average groups per full slice,
 // *over = fraction of slices with more groups than threads
 int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *over)
@@ -904,9 +954,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         const int pgrid = (int)((nslices + 63) / 64);
         // one workgroup per slice (k_fx_build) unless CM2_FX_BUILD=serial asks for the radix sort and
         // the one-thread-per-slice packer (k_fx_pack): other lists, the same sums
-        bool serial = false;
-        if (const char *e = getenv("CM2_FX_BUILD")) serial = strcmp(e, "serial") == 0;
-        if (S > kFbMaxS) serial = true;
+        const bool serial = fx_serial() || S > kFbMaxS;
         if (serial) {
             CM2_HIP(keys_in.alloc(nv));
             CM2_HIP(keys_out.alloc(nv));
@@ -927,7 +975,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
                                                    nullptr, nullptr, nullptr);
         } else {
             k_fx_build<false, 0><<<(unsigned)nslices, kFbT, 0, st>>>(
-                nslices, qmask, d_k0, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr, nullptr,
+                nslices, qmask, d_k0, 1, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr, nullptr,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_overflow);
         }
         CM2_LAUNCH_OK();
@@ -988,7 +1036,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
                 t->d_fx_tent, t->d_fx_ta, t->d_fx_tb);                                          \
         else                                                                                    \
             k_fx_build<true, NANG><<<(unsigned)nslices, kFbT, 0, st>>>(                           \
-                nslices, qmask, d_k0, t->d_pl, ent, t->half ? t->d_half : t->d_cos,              \
+                nslices, qmask, d_k0, 1, t->d_pl, ent, t->half ? t->d_half : t->d_cos,              \
                 t->half ? nullptr : t->d_sin, nullptr, t->d_fx_meta, d_tent_off,                \
                 reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, t->d_fx_gb, t->d_fx_trun, \
                 t->d_fx_tent, t->d_fx_ta, t->d_fx_tb, d_overflow);                              \
@@ -1098,12 +1146,20 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
             if (int rc = fx_build(t, forced < smax ? forced : smax, st, &mean, &over)) return rc;
         } else {
             int S = 1536 < smax ? 1536 : smax;
-            if (int rc = fx_build(t, S, st, &mean, &over)) return rc;
-            for (int iter = 0; iter < 3 && mean > 0.0; ++iter) {
-                int want = (int)(0.92 * kFxT * S / mean) / 64 * 64;
-                if (over > 0.10) want = want < S * 7 / 8 ? want : S * 7 / 8 / 64 * 64;
+            auto wanted = [&](int S_now) {
+                int want = (int)(0.92 * kFxT * S_now / mean) / 64 * 64;
+                if (over > 0.10) want = want < S_now * 7 / 8 ? want : S_now * 7 / 8 / 64 * 64;
                 if (want > smax) want = smax;
                 if (want < 256) want = 256;
+                return want;
+            };
+            if (!fx_serial() && S <= kFbMaxS) {           // first guess from a sample of the slices
+                if (int rc = fx_estimate(t, S, st, &mean, &over)) return rc;
+                if (mean > 0.0) S = wanted(S);
+            }
+            if (int rc = fx_build(t, S, st, &mean, &over)) return rc;
+            for (int iter = 0; iter < 3 && mean > 0.0; ++iter) {
+                const int want = wanted(S);
                 const bool close_enough = want >= S * 15 / 16 && want <= S * 17 / 16 && over <= 0.10;
                 if (close_enough || want == S) break;
                 S = want;

@@ -31,6 +31,7 @@ for rep in range(2):
     _hip.call = timed_call
     for mod in (L, sys.modules["cosmomap2_amd.utilities.process_ces"]):
         pass
+    gc.disable()                # (a generation-2 collection inside the timed region costs 10-20 ms)
     t0 = time.perf_counter()
     stmts = {}
     def lap(name, t=[t0]):
@@ -45,6 +46,7 @@ for rep in range(2):
     y = A * x[:pol * npc]; lap("first matvec")
     sync()
     total = time.perf_counter() - t0
+    gc.enable()
     _hip.call = orig
     inc = sum(acc.values())
     print(json.dumps({"rep": rep, "total_s": round(total, 4), "in_C_entry_points_s": round(inc, 4),
