@@ -105,6 +105,9 @@ hipError_t dev_free(void *p)
         c.live_bytes -= key.second;
         if (c.cap == 0) key.second = 0;                  // caching switched off
     }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != key.first) key.second = 0;   // another device is current: no
+                                                                                // cheap way to wait for the block's
     if (key.second == 0) return hipFree(p);
     // what hipFree guarantees: no work that may touch the block is still running
     hipError_t e = hipDeviceSynchronize();

@@ -553,11 +553,13 @@ def test_cm2_PtNP_tiles_apply_is_the_three_calls(cm, oracle):
 
 
 @pytest.mark.parametrize("angles", ["half", "full"])
-@pytest.mark.parametrize("nt,npix,tp,hot", [(300000, 5000, 2048, 0.0), (50000, 100, 64, 0.0),
-                                            (400000, 70000, 1024, 0.0), (40000, 20, 64, 0.0),
-                                            (300000, 40000, 1024, 0.05), (4097, 64, 64, 0.0)])
+@pytest.mark.parametrize("nt,npix,tp,hot,slice_len", [(300000, 5000, 2048, 0.0, 1280), (50000, 100, 64, 0.0, 1280),
+                                                      (400000, 70000, 1024, 0.0, 1280), (40000, 20, 64, 0.0, 1280),
+                                                      (300000, 40000, 1024, 0.05, 1280), (4097, 64, 64, 0.0, 1280),
+                                                      (50000, 100, 64, 0.0, 64), (300000, 5000, 2048, 0.0, 2048),
+                                                      (40000, 20, 64, 0.0, 2048), (120000, 9000, 1024, 0.05, 192)])
 def test_fixed_order_lists_built_per_slice_in_lds_give_the_serial_packers_sums(cm, oracle, monkeypatch, nt,
-                                                                             npix, tp, hot, angles):
+                                                                             npix, tp, hot, slice_len, angles):
     """The fixed-order P^T lists are built by one workgroup per slice (k_fx_build: bitonic sort in
     LDS, runs placed by class from scans) instead of a global radix sort and a one-thread-per-slice
     walk (CM2_FX_BUILD=serial).  The packing differs, the sums may not: P^T is bit-identical between
@@ -571,7 +573,7 @@ def test_fixed_order_lists_built_per_slice_in_lds_give_the_serial_packers_sums(c
     monkeypatch.setenv("CM2_TILE_ANGLES", angles)
     # (the slice length is tuned to the groups a slice packs into, which differ between the two
     #  packers; the chunk boundaries of a hot run follow the slice length: same length for both)
-    monkeypatch.setenv("CM2_PT_SLICE", "1280")
+    monkeypatch.setenv("CM2_PT_SLICE", str(slice_len))      # (64 and 2048: the shortest and longest slices)
     rng = np.random.default_rng(99)
     pairs = rng.integers(0, npix, nt)
     if hot:
