@@ -4,6 +4,10 @@
 //
 // All are HBM-bound; the per-pixel operators move 56-80 B in + 8*pol B out per pixel.
 #include "cm2_pixindex.h"
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
 #include "cm2_blocks.h"
 
 #include <hipcub/hipcub.hpp>
@@ -20,11 +24,18 @@ __global__ __launch_bounds__(256) void k_weights(
     int64_t npix, const int64_t *__restrict__ ptr, const uint32_t *__restrict__ sorted_t,
     const double *__restrict__ w, const double *__restrict__ c, const double *__restrict__ s,
     double *__restrict__ counts, double *__restrict__ cosine, double *__restrict__ sine,
-    double *__restrict__ cos2, double *__restrict__ sin2, double *__restrict__ sincos)
+    double *__restrict__ cos2, double *__restrict__ sin2, double *__restrict__ sincos,
+    int64_t hot_min, int32_t *__restrict__ hot_pix, unsigned int *__restrict__ hot_n,
+    unsigned long long *__restrict__ hot_longest)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
         const int64_t b = ptr[p], e = ptr[p + 1];
+        if (e - b >= hot_min) {                          // left to k_weights_hot (at most nt / hot_min pixels)
+            hot_pix[atomicAdd(hot_n, 1u)] = (int32_t)p;
+            atomicMax(hot_longest, (unsigned long long)(e - b));
+            continue;
+        }
         double n = 0.0, sc = 0.0, ss = 0.0, c2 = 0.0, s2 = 0.0, cs = 0.0;
         for (int64_t k = b; k < e; ++k) {
             const uint32_t t = sorted_t[k];
@@ -56,6 +67,88 @@ __global__ __launch_bounds__(256) void k_weights(
     }
 }
 
+// Hot pixels.  One thread walking a pixel's samples is a chain of dependent gathers: 0.37 us a
+// sample, 1.9 s for a pixel that holds 5 % of 1e8 samples (a stare at a source).  A pixel with at
+// least kWeightsHotMin samples is therefore summed like the hot tiles of the fixed-order P^T
+// (cm2_tiles_fixed.hip): its sample list is cut into ranges of kWeightsChunk entries, one workgroup per
+// range, thread t adding the terms at positions t, t + 256, ... in that order, the 256 thread sums
+// combined by a fixed halving tree; k_weights_hot_combine adds the range sums in time order.  Every
+// boundary and order follows from the pixel's sample count alone: reproducible bit for bit,
+// independent of the rest of the hit map; a regrouping of the serial sum (~1e-16 relative per level;
+// the hit count itself, a sum of ones, is exact).  CM2_WEIGHTS_ORDER=exact keeps the serial walk.
+constexpr int64_t kWeightsHotMin = 8192;
+constexpr int kWeightsChunk = 4096;
+
+template <int POL>
+__global__ __launch_bounds__(256) void k_weights_hot(
+    const int32_t *__restrict__ hot_pix, int64_t max_chunks, const int64_t *__restrict__ ptr,
+    const uint32_t *__restrict__ sorted_t, const double *__restrict__ w, const double *__restrict__ c,
+    const double *__restrict__ s, double *__restrict__ partial)
+{
+    __shared__ double red[6][256];
+    const int64_t h = blockIdx.y, ch = blockIdx.x;
+    const int64_t p = hot_pix[h];
+    const int64_t b = ptr[p] + ch * kWeightsChunk, end = ptr[p + 1];
+    if (b >= end) return;
+    const int64_t e = b + kWeightsChunk < end ? b + kWeightsChunk : end;
+    const int t = threadIdx.x;
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // n, sum c, sum s, c2, s2, cs
+    for (int64_t k = b + t; k < e; k += 256) {
+        const uint32_t ts = sorted_t[k];
+        const double wt = w ? w[ts] : 1.0;
+        if (POL == 1) {
+            a[0] += wt;
+        } else {
+            const double ct = c[ts], st = s[ts];
+            if (POL == 3) {
+                a[0] += wt;
+                a[1] += wt * ct;
+                a[2] += wt * st;
+            }
+            a[3] += wt * ct * ct;
+            a[4] += wt * st * st;
+            a[5] += wt * st * ct;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) red[q][t] = a[q];
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (t < half)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) red[q][t] += red[q][t + half];
+        __syncthreads();
+    }
+    if (t < 6) partial[(h * max_chunks + ch) * 6 + t] = red[t][0];
+}
+
+template <int POL>
+__global__ __launch_bounds__(64) void k_weights_hot_combine(
+    int64_t nhot, const int32_t *__restrict__ hot_pix, int64_t max_chunks,
+    const int64_t *__restrict__ ptr, const double *__restrict__ partial,
+    double *__restrict__ counts, double *__restrict__ cosine, double *__restrict__ sine,
+    double *__restrict__ cos2, double *__restrict__ sin2, double *__restrict__ sincos)
+{
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nhot) return;
+    const int64_t p = hot_pix[h];
+    const int64_t nch = (ptr[p + 1] - ptr[p] + kWeightsChunk - 1) / kWeightsChunk;
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t ch = 0; ch < nch; ++ch)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[q] += partial[(h * max_chunks + ch) * 6 + q];
+    if (POL != 2) counts[p] = a[0];
+    if (POL == 3) {
+        cosine[p] = a[1];
+        sine[p] = a[2];
+    }
+    if (POL >= 2) {
+        cos2[p] = a[3];
+        sin2[p] = a[4];
+        sincos[p] = a[5];
+    }
+}
+
 extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const int32_t *d_pix,
                                       const double *d_w, const double *d_cos,
                                       const double *d_sin, double *d_counts, double *d_cosine,
@@ -72,14 +165,52 @@ extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const i
     struct IxGuard { PixIndex *ix; ~IxGuard() { ix->release(); } } guard{&ix};
     if (int rc = build_pixindex(ix, d_pix, nt, npix, stream)) return rc;
     const int g = grid_for(npix);
+    // pixels with >= hot_min samples are listed by k_weights and summed by k_weights_hot
+    int64_t hot_min = kWeightsHotMin;
+    if (const char *e = getenv("CM2_WEIGHTS_ORDER"))
+        if (strcmp(e, "exact") == 0) hot_min = INT64_MAX;
+    DevTemp<int32_t> d_hot_pix;
+    DevTemp<unsigned int> d_hot_n;
+    DevTemp<unsigned long long> d_hot_longest;
+    CM2_HIP(d_hot_pix.alloc((size_t)(nt / kWeightsHotMin + 1)));
+    CM2_HIP(d_hot_n.alloc(1));
+    CM2_HIP(d_hot_longest.alloc(1));
+    CM2_HIP(hipMemsetAsync(d_hot_n.p, 0, sizeof(unsigned int), stream));
+    CM2_HIP(hipMemsetAsync(d_hot_longest.p, 0, sizeof(unsigned long long), stream));
 #define CM2_W(POL)                                                                          \
     k_weights<POL><<<g, kBlock, 0, stream>>>(npix, ix.d_ptr, ix.d_sorted_t, d_w, d_cos,     \
                                              d_sin, d_counts, d_cosine, d_sine, d_cos2,     \
-                                             d_sin2, d_sincos)
+                                             d_sin2, d_sincos, hot_min, d_hot_pix, d_hot_n, \
+                                             d_hot_longest)
     if (pol == 1) CM2_W(1); else if (pol == 2) CM2_W(2); else CM2_W(3);
 #undef CM2_W
     CM2_LAUNCH_OK();
+    unsigned int nhot = 0;
+    unsigned long long longest = 0;
+    CM2_HIP(hipMemcpyAsync(&nhot, d_hot_n.p, sizeof(nhot), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(hipMemcpyAsync(&longest, d_hot_longest.p, sizeof(longest), hipMemcpyDeviceToHost, stream));
     CM2_HIP(hipStreamSynchronize(stream));
+    if (nhot > 0) {
+        const int64_t max_chunks = ((int64_t)longest + kWeightsChunk - 1) / kWeightsChunk;
+        CM2_CHECK(max_chunks <= 0x7FFFFFFF, "cm2_weights_accumulate: a pixel with %llu samples", longest);
+        // (grid.y <= 65535: the hot pixels are taken in batches)
+        const unsigned int batch_max = 65535u;
+        DevTemp<double> d_partial;
+        CM2_HIP(d_partial.alloc((size_t)(nhot < batch_max ? nhot : batch_max) * (size_t)max_chunks * 6));
+#define CM2_WH(POL)                                                                              \
+    for (unsigned int h0 = 0; h0 < nhot; h0 += batch_max) {                                      \
+        const unsigned int nb = nhot - h0 < batch_max ? nhot - h0 : batch_max;                   \
+        k_weights_hot<POL><<<dim3((unsigned)max_chunks, nb), 256, 0, stream>>>(                  \
+            d_hot_pix.p + h0, max_chunks, ix.d_ptr, ix.d_sorted_t, d_w, d_cos, d_sin, d_partial); \
+        k_weights_hot_combine<POL><<<(nb + 63) / 64, 64, 0, stream>>>(                           \
+            nb, d_hot_pix.p + h0, max_chunks, ix.d_ptr, d_partial, d_counts, d_cosine, d_sine,   \
+            d_cos2, d_sin2, d_sincos);                                                           \
+    }
+        if (pol == 1) CM2_WH(1) else if (pol == 2) CM2_WH(2) else CM2_WH(3)
+#undef CM2_WH
+        CM2_LAUNCH_OK();
+        CM2_HIP(hipStreamSynchronize(stream));
+    }
     return 0;
 }
 

@@ -76,15 +76,34 @@ __global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ p
     if (b) atomicOr(bad, 1u);
 }
 
-// hits of every pixel (flagged / out-of-range samples skipped): input of the balanced tiling
+// hits of every pixel (flagged / out-of-range samples skipped): input of the balanced tiling.
+// A pixel that holds a large share of the samples (5e6 hits on one address: 50 ms of serialised
+// global atomics) is counted in LDS: every workgroup keeps a direct-mapped table of 1024 pixels,
+// first come first served; a sample whose slot belongs to its pixel is an LDS add, the others go to
+// memory as before, and the table is flushed with one global add per slot.  Counts are integers:
+// the result does not depend on which path a sample took.
 __global__ __launch_bounds__(256) void k_pix_hist(const int32_t *__restrict__ pix, int64_t nt,
                                                    int64_t npix, unsigned int *__restrict__ hits)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) {
-        const int32_t p = pix[i];
-        if (p >= 0 && p < npix) atomicAdd(&hits[p], 1u);
+    __shared__ unsigned int key[1024], cnt[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        key[i] = 0xFFFFFFFFu;
+        cnt[i] = 0;
     }
+    __syncthreads();
+    const int64_t span = (nt + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * span, i1 = i0 + span < nt ? i0 + span : nt;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int32_t p = pix[i];
+        if (p < 0 || p >= npix) continue;
+        const unsigned int slot = ((unsigned int)p * 2654435761u) >> 22;
+        const unsigned int old = atomicCAS(&key[slot], 0xFFFFFFFFu, (unsigned int)p);
+        if (old == 0xFFFFFFFFu || old == (unsigned int)p) atomicAdd(&cnt[slot], 1u);
+        else atomicAdd(&hits[p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        if (cnt[i]) atomicAdd(&hits[key[i]], cnt[i]);
 }
 
 __global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict__ keys, int64_t nt,

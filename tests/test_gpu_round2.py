@@ -603,6 +603,49 @@ def test_fixed_order_lists_built_per_slice_in_lds_give_the_serial_packers_sums(c
         np.testing.assert_array_equal(outs[1], oracle.sparse_rmult(pol, npix, pairs, c, s, v))
 
 
+@pytest.mark.parametrize("pol", [1, 2, 3])
+def test_weights_of_a_hot_pixel_are_summed_in_fixed_chunks(cm, oracle, monkeypatch, pol):
+    """ProcessTimeSamples' per-pixel sums (process_ces.py:480-539) are the reference's serial sums
+    bit for bit -- except for a pixel with 8192 samples or more, which one thread would walk for
+    seconds (1.9 s for 5 % of 1e8 samples): its sum is regrouped into fixed chunks of 4096 (thread
+    sums + halving tree + chunks in time order), reproducible and within 1e-13 of the serial sum;
+    CM2_WEIGHTS_ORDER=exact keeps the serial walk.  Two hot pixels here (105 k and 9 k samples)."""
+    nt, npix = 1 << 21, 5000
+    rng = np.random.default_rng(31)
+    pairs = rng.integers(0, npix, nt)
+    pairs[rng.random(nt) < 0.05] = 1234
+    pairs[rng.random(nt) < 0.004] = 77
+    pairs[rng.random(nt) < 0.02] = -1
+    pairs = pairs.astype(np.int32)
+    phi = rng.uniform(0, np.pi, nt)
+    w = rng.random(nt)
+    keys = {1: ("counts",), 2: ("cos2", "sin2", "sincos"),
+            3: ("counts", "cosine", "sine", "cos2", "sin2", "sincos")}[pol]
+    ro = oracle.process_time_samples(pairs.copy(), npix, pol=pol, phi=phi, w=w)
+    hot = np.isin(ro.obspix, [1234, 77])
+    assert hot.sum() == 2
+    runs = []
+    for _ in range(2):
+        rg = cm.U.ProcessTimeSamples(pairs.astype(np.int64), npix, pol=pol, phi=phi, w=w)
+        np.testing.assert_array_equal(rg.get_new_pixel[1], ro.obspix)
+        runs.append({k: np.asarray(getattr(rg, k)).copy() for k in keys})
+    for k in keys:
+        np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)           # reproducible
+        np.testing.assert_array_equal(runs[0][k][~hot], getattr(ro, k)[~hot], err_msg=k)
+        ref = getattr(ro, k)[hot]
+        assert np.all(np.abs(runs[0][k][hot] - ref) <= 1e-13 * np.abs(ref).max()), k
+    monkeypatch.setenv("CM2_WEIGHTS_ORDER", "exact")
+    rg = cm.U.ProcessTimeSamples(pairs.astype(np.int64), npix, pol=pol, phi=phi, w=w)
+    for k in keys:
+        np.testing.assert_array_equal(getattr(rg, k), getattr(ro, k), err_msg=k)
+    # unit weights: the hit counts are exact in either order
+    if pol != 2:
+        monkeypatch.delenv("CM2_WEIGHTS_ORDER")
+        r1 = cm.U.ProcessTimeSamples(pairs.astype(np.int64), npix, pol=pol, phi=phi)
+        np.testing.assert_array_equal(r1.counts, oracle.process_time_samples(pairs.copy(), npix, pol=pol,
+                                                                             phi=phi).counts)
+
+
 def test_library_device_memory_is_cached_and_released(cm):
     """Plans and their build temporaries come from the library's cache of released device blocks
     (cm2_core.hip): a second build of the same plan is served from the cache, live bytes return to
