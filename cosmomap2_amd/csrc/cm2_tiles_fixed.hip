@@ -865,6 +865,13 @@ void fx_release(cm2_tiles *t)
     t->fx_ngroups = t->fx_nslices = 0;
 }
 
+// a tile that k_Pt_hot takes over (hot_plan): its slices do not count when the slice length is tuned
+static bool fx_hot_tile(const cm2_tiles *t, int64_t b)
+{
+    return t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b] == 1 &&
+           t->tile_off[(size_t)b + 1] - t->tile_off[(size_t)b] >= kHotMin;
+}
+
 static bool fx_serial()
 {
     const char *e = getenv("CM2_FX_BUILD");
@@ -880,12 +887,14 @@ int fx_estimate(const cm2_tiles *t, int S, hipStream_t st, double *mean_groups, 
     *over = 0.0;
     std::vector<int64_t> pairs;
     int64_t seen = 0;
-    for (int64_t b = 0; b < t->ntiles; ++b)
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        if (fx_hot_tile(t, b)) continue;
         for (int64_t k = t->tile_off[(size_t)b]; k + S <= t->tile_off[(size_t)b + 1]; k += S)
             if (seen++ % 8 == 0) {
                 pairs.push_back(k);
                 pairs.push_back(k + S);
             }
+    }
     const int64_t np = (int64_t)pairs.size() / 2;
     if (np == 0) return 0;
     DevTemp<int64_t> d_pairs;
@@ -993,10 +1002,17 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             ngroups += counts[(size_t)(4 * s)];
             ntrun += counts[(size_t)(4 * s + 1)];
             ntent += counts[(size_t)(4 * s + 2)];
-            if (counts[(size_t)(4 * s)] > (uint32_t)kFxT) ++nover;
-            if (k0[(size_t)s + 1] - k0[(size_t)s] == S) {
-                ++nfull;
-                gsum += counts[(size_t)(4 * s)];
+        }
+        int64_t ncounted = 0;
+        for (int64_t b = 0; b < t->ntiles; ++b) {
+            if (fx_hot_tile(t, b)) continue;
+            for (int64_t s = slice0[(size_t)b]; s < slice0[(size_t)b + 1]; ++s) {
+                ++ncounted;
+                if (counts[(size_t)(4 * s)] > (uint32_t)kFxT) ++nover;
+                if (k0[(size_t)s + 1] - k0[(size_t)s] == S) {
+                    ++nfull;
+                    gsum += counts[(size_t)(4 * s)];
+                }
             }
         }
         meta[(size_t)nslices] = make_uint2((uint32_t)ngroups, (uint32_t)ntrun);
@@ -1004,7 +1020,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         CM2_CHECK(ngroups < ((int64_t)1 << 32) && ntent < ((int64_t)1 << 32) &&
                   ntrun < ((int64_t)1 << 28), "cm2_tiles: fixed-order lists exceed their offsets");
         *mean_groups = nfull ? gsum / (double)nfull : 0.0;
-        *over = (double)nover / (double)nslices;
+        *over = ncounted ? (double)nover / (double)ncounted : 0.0;
         // (+1 group: a slice without groups at the very end still loads "its" group 0)
         const int64_t ng1 = ngroups + 1, nt1 = ntent ? ntent : 1;
         CM2_HIP(cm2::dev_malloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
