@@ -35,7 +35,7 @@ int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
                    const std::vector<int64_t> &off, hipStream_t stream);
 int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream);
 int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                          int64_t ntiles, int64_t nvalid, bool want_rc, const double *d_v, double *d_out,
+                          int64_t ntiles, int64_t nvalid, int want_lists, const double *d_v, double *d_out,
                           hipStream_t stream);
 double real_os_tile_bytes_per_sample(const RealOS *f);
 int real_os_list_mode(const RealOS *f);

@@ -547,35 +547,39 @@ struct FusedOS {
     // the one-real-window kernel (cm2_fft_real.hip), built on first use when CM2_OS_KERNEL selects it
     RealOS *real = nullptr;
     int real_pt = 0;                     // 0: segment-pair kernel of this file
-    bool real_rc = true;                 // run-coded lists
+    int real_lists = 0;                  // 0 chosen by tile count, 1 plain, 2 run-coded, 3 inverse
     double *d_bands = nullptr;           // borrowed from the noise operator (lives as long as it does)
     int64_t lambda = 0;
     std::vector<int64_t> off;
 };
 
 // CM2_OS_KERNEL = pair | real16 | real32 selects the overlap-save kernel of the tile-order and
-// time-order applications; CM2_OS_LISTS = rc | plain the list format of the real-window kernel.
-static void os_choice(int *pt, bool *rc)
+// time-order applications; CM2_OS_LISTS = auto | rc | plain | inv the list format of the real-window
+// kernel (auto: inverse lists from 768 pixel tiles up, where a half window's address runs get short).
+static void os_choice(int *pt, int *lists)
 {
     *pt = 32;               // fastest on MI355X (profiles/r03_os_variants.md)
-    *rc = true;
+    *lists = 0;
     if (const char *e = getenv("CM2_OS_KERNEL")) {
         if (!strcmp(e, "pair")) *pt = 0;
         else if (!strcmp(e, "real32")) *pt = 32;
         else if (!strcmp(e, "real16")) *pt = 16;
     }
     if (const char *e = getenv("CM2_OS_LISTS"))
-        if (!strcmp(e, "plain")) *rc = false;
+    {
+        if (!strcmp(e, "plain")) *lists = 1;
+        else if (!strcmp(e, "inv")) *lists = 3;
+        else if (!strcmp(e, "rc")) *lists = 2;
+    }
 }
 
 static int ensure_pair_state(FusedOS *f, hipStream_t stream);
 
 static int ensure_real(FusedOS *f, hipStream_t stream)
 {
-    int pt;
-    bool rc;
-    os_choice(&pt, &rc);
-    f->real_rc = rc;
+    int pt, lists;
+    os_choice(&pt, &lists);
+    f->real_lists = lists;
     if (pt == f->real_pt && (pt == 0 || f->real)) return 0;
     if (f->real) real_os_destroy(f->real);
     f->real = nullptr;
@@ -693,7 +697,7 @@ int fused_os_apply_indexed(FusedOS *f, const uint32_t *d_idx, const int64_t *d_t
 {
     if (int rc = ensure_real(f, stream)) return rc;
     if (f->real)
-        return real_os_apply_indexed(f->real, d_idx, d_tile_off, plan_id, ntiles, nvalid, f->real_rc, d_v, d_out,
+        return real_os_apply_indexed(f->real, d_idx, d_tile_off, plan_id, ntiles, nvalid, f->real_lists, d_v, d_out,
                                      stream);
     if (int rc = ensure_pair_state(f, stream)) return rc;
     // the lists belong to ONE tile plan; keyed on its id (a device address may be handed out

@@ -338,6 +338,45 @@ __device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_
     }
 }
 
+// ---- inverse lists (MODE 3) ----------------------------------------------------------------------
+// The lists above are cut by TIME (two window halves, two result rounds), each sorted by address: a
+// tile's samples of one window are consecutive addresses, but a half window holds only half of them
+// (runs of 16 entries = 128 bytes at C4, 12 = 96 bytes on the result side), and every run ends in
+// partly used 64-byte sectors.  An inverse list keeps ONE address-sorted order per window (and one per
+// result window) and cuts it by ADDRESS: round j moves slots [j R, (j + 1) R) -- whole runs of 32
+// (24) entries -- linearly through the LDS buffer, and every thread picks (or places) its own points
+// by slot number: the list stored per POSITION is its slot (u16, 0xFFFF = no sample), read in
+// register order.  The slot -> address direction needs only the run table and one bit per slot (a
+// run starts here), kept transposed: bit u of word [round][thread] belongs to the thread's u-th slot
+// of that round.
+struct IListHdr {
+    uint32_t nvalid, nruns;
+    int32_t wbase[8];         // [round][wave]: run index in front of the wave's first slot of the round
+};
+
+// addresses of this thread's E slots of the round that starts at list slot `soff`
+template <int E>
+__device__ __forceinline__ void idecode(uint32_t fw, const uint32_t *__restrict__ tab_lds, int wbase,
+                                        uint32_t nvalid, uint32_t soff, int t, uint32_t (&kk)[E])
+{
+    int rb = wbase;
+    uint32_t s0 = soff + (uint32_t)slot_of<E>(t, 0);
+    asm volatile("" : "+v"(s0));
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const bool flag = ((fw >> u) & 1u) != 0u;
+        const uint64_t mask = __ballot(flag);
+        const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        int r = rb + below + (flag ? 1 : 0);
+        rb += __popcll(mask);
+        r = r < 0 ? 0 : r;
+        const uint32_t s = s0 + 64u * (uint32_t)u;
+        const uint32_t a = tab_lds[r] + s;
+        kk[u] = s < nvalid ? a : kInvalidSample;
+    }
+}
+
 // ---- the partner exchange and the spectrum product ------------------------------------------------
 // Z'[k] = alpha Z[k] + i beta conj(Z[N-k]):  re' = alpha re + beta pim,  im' = alpha im + beta pre.
 // Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3; its
@@ -430,7 +469,8 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const double2 *Wtw_inv, const double2 *__restrict__ AB, const uint32_t *__restrict__ lst_k,
     const uint16_t *__restrict__ lst_q, const ListHdr *__restrict__ hdrs,
     const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v,
-    double *__restrict__ out, uint32_t nbytes OS_STAMP_PARAM)
+    double *__restrict__ out, uint32_t nbytes, const IListHdr *__restrict__ ihdrs,
+    const uint32_t *__restrict__ iflags OS_STAMP_PARAM)
 {
     using G = Geo<PT>;
     constexpr int N = G::N, H = PT / 2;
@@ -493,6 +533,74 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
                 const double2 p = sp[256 * m];
                 zr[h * H + m] = p.x;
                 zi[h * H + m] = p.y;
+            }
+            __syncthreads();
+        }
+    } else if constexpr (MODE == 3) {
+        // inverse lists: two rounds of N slots of the window's address-sorted order.  Header, run
+        // table, flag words and this thread's slot numbers are requested together (the table is
+        // read up to its allocated length: no dependency on the run count).
+        const IListHdr *__restrict__ h0 = ihdrs + (int64_t)win * 2;
+        const uint32_t *__restrict__ pl = reinterpret_cast<const uint32_t *>(lst_q + (int64_t)win * G::PER);
+        uint32_t tv[TPT], fw[2], pp[PT];
+        {
+            const uint32_t *tg = tabs + ((int64_t)win * 2) * rmax;
+#pragma unroll
+            for (int i = 0; i < TPT; ++i) {
+                const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
+                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
+            }
+            fw[0] = iflags[((int64_t)win * 2) * 512 + t];
+            fw[1] = iflags[((int64_t)win * 2) * 512 + 256 + t];
+        }
+        const uint32_t nv = h0->nvalid;
+        const int wb0 = h0->wbase[wave], wb1 = h0->wbase[4 + wave];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) pp[m] = pl[t + kT * m];
+        tab_store<TPT>(tab_lds, t, rmax, tv);
+        __syncthreads();
+        // both rounds' gathers are issued before anything is staged: 2 PT loads in flight per thread
+        // while the transform's registers are not live yet
+        double va[PT], vb[PT];
+        {
+            uint32_t kk[PT];
+            idecode<PT>(fw[0], tab_lds, wb0, nv, 0u, t, kk);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) va[u] = keep(kk[u], gather(kk[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint32_t kk[PT];
+            idecode<PT>(fw[1], tab_lds, wb1, nv, (uint32_t)N, t, kk);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) vb[u] = keep(kk[u], gather(kk[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = j ? vb[u] : va[u];
+            if (j == 1) {
+                // the slot numbers again (L2): 32 registers not held across the first round's picks
+                const uint32_t *plj = pl;
+                asm volatile("" : "+v"(plj));
+#pragma unroll
+                for (int m = 0; m < PT; ++m) pp[m] = plj[t + kT * m];
+            }
+            __syncthreads();
+            // a point outside this round reads word 0 (one address for all such lanes: no bank conflict)
+#pragma unroll
+            for (int m = 0; m < PT; ++m) {
+                const uint32_t lo = (pp[m] & 0xFFFFu) - (uint32_t)(j * N), hi = (pp[m] >> 16) - (uint32_t)(j * N);
+                const bool inl = lo < (uint32_t)N, inh = hi < (uint32_t)N;
+                const double x = buf[inl ? lo : 0u], y = buf[inh ? hi : 0u];
+                if (j == 0) {
+                    zr[m] = inl ? x : 0.0;
+                    zi[m] = inh ? y : 0.0;
+                } else {
+                    zr[m] = inl ? x : zr[m];
+                    zi[m] = inh ? y : zi[m];
+                }
             }
             __syncthreads();
         }
@@ -685,6 +793,68 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     reg_exchange<PT, 3, 2, 0>(zi, buf, t);
     reg_inv<PT, 16, 0>(zr, zi, w_bi);
     if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
+    if constexpr (MODE == 3) {
+        // ---- inverse result list: rounds of RLEN slots of the result window's address-sorted order ----
+        constexpr int ER3 = G::RLEN / kT, NP = PT - 8;   // slots per thread and round; points with results
+        const IListHdr *h1 = ihdrs + (int64_t)win * 2 + 1;
+        const uint32_t *tg = tabs + ((int64_t)win * 2 + 1) * rmax;
+        const uint32_t *fg = iflags + ((int64_t)win * 2 + 1) * 512 + t;
+        asm volatile("" : "+v"(h1), "+v"(tg), "+v"(fg));
+        const uint32_t nv1 = h1->nvalid;
+        uint32_t tv[TPT], fr[G::RR], rp[NP];
+        const uint32_t *rl = reinterpret_cast<const uint32_t *>(lst_q + (int64_t)win * G::PER + 2 * N);
+        {
+#pragma unroll
+            for (int i = 0; i < TPT; ++i) {
+                const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
+                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < G::RR; ++j) fr[j] = fg[256 * j];
+            // the slot numbers of this thread's results, in registers by the end of the last pass
+            const uint32_t *rl0 = rl;
+            asm volatile("" : "+v"(rl0));
+#pragma unroll
+            for (int m = 0; m < NP; ++m) rp[m] = rl0[t + kT * m];
+        }
+        reg_exchange<PT, 2, 1, 16>(zr, buf, t);
+        tab_store<TPT>(tab_lds + rmax, t, rmax, tv);     // published by the barriers of the next exchange
+        reg_exchange<PT, 2, 1, 16>(zi, buf, t);
+        reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
+        OS_STAMP(4);
+#pragma unroll
+        for (int j = 0; j < G::RR; ++j) {
+            if (j > 0) {
+                __syncthreads();                         // the previous round's reads are done
+                const uint32_t *rlj = rl;                // (the slot numbers again, from L2)
+                asm volatile("" : "+v"(rlj));
+#pragma unroll
+                for (int m = 0; m < NP; ++m) rp[m] = rlj[t + kT * m];
+            }
+            // y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4): each value to its slot of this
+            // round, the others to a spare word behind the stage (no branch)
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const uint32_t lo = (rp[m] & 0xFFFFu) - (uint32_t)(j * G::RLEN), hi = (rp[m] >> 16) - (uint32_t)(j * G::RLEN);
+                buf[lo < (uint32_t)G::RLEN ? lo : (uint32_t)N] = zr[brev<PT>(m + 4)];
+                buf[hi < (uint32_t)G::RLEN ? hi : (uint32_t)N + 1u] = zi[brev<PT>(m + 4)];
+            }
+            __syncthreads();
+            uint32_t ks3[ER3];
+            idecode<ER3>(fr[j], tab_lds + rmax, h1->wbase[4 * j + wave], nv1, (uint32_t)(j * G::RLEN), t, ks3);
+            double rv[ER3];
+#pragma unroll
+            for (int u = 0; u < ER3; ++u) rv[u] = buf[slot_of<ER3>(t, u)];
+#pragma unroll
+            for (int u = 0; u < ER3; ++u) {
+                if constexpr (BUF) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, rv[u]), o_rs, ks3[u] * 8u, 0, 0);
+                } else {
+                    if (ks3[u] != kInvalidSample) st_result(out + ks3[u], rv[u]);
+                }
+            }
+        }
+    } else {
     // The result list of round 0 is requested here, behind the middle inverse pass: its run table
     // goes to LDS in front of the last exchange (whose barriers publish it), its 16-bit words are
     // in registers by the end of the last pass.  The pointers pass through an empty asm statement:
@@ -773,6 +943,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
                 }
             }
         }
+    }
     }
     OS_STAMP(5);
 }
@@ -1039,6 +1210,129 @@ __global__ __launch_bounds__(256) void k_real_lists(const WinDesc *__restrict__ 
     for (int i = t; i < len / 2; i += 256) dst[i] = src[i];
 }
 
+// ---- inverse lists (MODE 3 of k_os_real) ---------------------------------------------------------
+// One workgroup per list (l = 0: the 2N window positions, l = 1: the HOP result positions).  Same
+// arithmetic as k_real_lists over the whole (result) window: per-tile count and lowest address, scan,
+// slot = base[tile] + address - lowest[tile].  Written: the slot of every POSITION (u16, natural
+// order, 0xFFFF = no sample), the run table, one run-start bit per slot in the transposed layout the
+// kernel reads (bit u of word [round][thread]), the run index in front of every wave's slots of every
+// round.
+template <int PT>
+__global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__ wins, int64_t nlists,
+                                                      const uint32_t *__restrict__ idx,
+                                                      const int64_t *__restrict__ tile_off, int ntiles,
+                                                      uint16_t *__restrict__ plist, uint32_t *__restrict__ flags,
+                                                      IListHdr *__restrict__ hdrs, uint32_t *__restrict__ tabs,
+                                                      int rmax, uint32_t *__restrict__ max_runs)
+{
+    using G = Geo<PT>;
+    constexpr int EMAX = 2 * G::N / 256;
+    extern __shared__ uint32_t sm_i[];
+    uint32_t *toff = sm_i;                               // [ntiles + 1]
+    uint32_t *cnt = toff + ntiles + 1;                   // [ntiles] entries, then: base slot
+    uint32_t *mn = cnt + ntiles;                         // [ntiles] lowest address
+    uint32_t *misc = mn + ntiles;                        // [4] scan sums, [8] wbase counts
+    uint32_t *fl = misc + 12;                            // [512] run-start bits
+    const int64_t lid = blockIdx.x;
+    if (lid >= nlists) return;
+    const int l = (int)(lid & 1);
+    const int64_t win = lid >> 1;
+    const int64_t e0 = win * G::PER + (l ? 2 * G::N : 0);
+    const int len = l ? G::HOP : 2 * G::N;               // positions
+    const int RL = l ? G::RLEN : G::N;                   // slots a round
+    const int rounds = l ? G::RR : 2, rows = len / 256, E = RL / 256;
+    const WinDesc wd = wins[win];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int b = t; b <= ntiles; b += 256) toff[b] = (uint32_t)tile_off[b];
+    for (int b = t; b < ntiles; b += 256) {
+        cnt[b] = 0;
+        mn[b] = 0xFFFFFFFFu;
+    }
+    if (t < 12) misc[t] = 0;
+    for (int i = t; i < 512; i += 256) fl[i] = 0;
+    __syncthreads();
+    uint32_t a[EMAX];
+    uint16_t tl[EMAX];
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        a[i] = kInvalidSample;
+        tl[i] = 0;
+        if (i < rows) {
+            const int e = 256 * i + t;
+            if (l == 0) {
+                const int64_t ts = wd.start - kHalo + e;
+                if (ts >= wd.lo && ts < wd.hi) a[i] = idx[ts];
+            } else {
+                if (e < wd.len) a[i] = idx[wd.start + e];
+            }
+            if (a[i] != kInvalidSample) {
+                int lo = 0, hi = ntiles;                 // largest b with toff[b] <= a
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (toff[mid] <= a[i]) lo = mid; else hi = mid;
+                }
+                tl[i] = (uint16_t)lo;
+                atomicAdd(&cnt[lo], 1u);
+                atomicMin(&mn[lo], a[i]);
+            }
+        }
+    }
+    __syncthreads();
+    // scan over the tiles: base slot and run index (packed: runs << 16 | entries)
+    const int per = (ntiles + 255) / 256;
+    uint32_t mine = 0;
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) mine += cnt[b] | (cnt[b] ? 0x10000u : 0u);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) misc[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += misc[w];
+        total += misc[w];
+    }
+    const int nvalid = (int)(total & 0xFFFFu), nruns = (int)(total >> 16);
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) {
+        const uint32_t c = cnt[b];
+        const uint32_t base = before & 0xFFFFu, r = before >> 16;
+        cnt[b] = base;
+        if (c) {
+            if ((int)r < rmax) tabs[lid * rmax + r] = mn[b] - base;
+            // the run's first slot: round, then (wave, row, lane) of the kernel's slot order
+            const int j = (int)base / RL, sr = (int)base % RL;
+            const int wv = sr / (64 * E), rem = sr % (64 * E);
+            atomicOr(&fl[256 * j + 64 * wv + (rem & 63)], 1u << (rem >> 6));
+            for (int jj = 0; jj < rounds; ++jj)
+                for (int w = 0; w < 4; ++w)
+                    if ((int)base < jj * RL + w * (RL / 4)) atomicAdd(&misc[4 + 4 * jj + w], 1u);
+            before += c | 0x10000u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i)
+        if (i < rows) {
+            const int e = 256 * i + t;
+            uint16_t slot = 0xFFFFu;
+            if (a[i] != kInvalidSample) slot = (uint16_t)(cnt[tl[i]] + (a[i] - mn[tl[i]]));
+            plist[e0 + e] = slot;
+        }
+    for (int i = t; i < 512; i += 256) flags[lid * 512 + i] = fl[i];
+    if (t == 0) {
+        IListHdr h;
+        h.nvalid = (uint32_t)nvalid;
+        h.nruns = (uint32_t)nruns;
+        for (int k = 0; k < 8; ++k) h.wbase[k] = (int32_t)misc[4 + k] - 1;
+        hdrs[lid] = h;
+        atomicMax(max_runs, (uint32_t)nruns);
+    }
+}
+
 // W[t] = exp(-2 pi i t / N)
 __global__ void k_real_twiddles(int N, double2 *__restrict__ W)
 {
@@ -1131,25 +1425,29 @@ struct RealOS {
     double2 *d_W = nullptr;
     // lists of the tile-order path, built for one tile plan at a time
     uint64_t list_plan = 0;
-    int list_mode = 0;                   // 1 plain, 2 run-coded
+    int list_mode = 0;                   // 1 plain, 2 run-coded, 3 inverse (run-coded, rounds cut by address)
     uint32_t *d_lst_k = nullptr;
-    uint16_t *d_lst_q = nullptr;
+    uint16_t *d_lst_q = nullptr;         // modes 1, 2: position of every slot; mode 3: slot of every position
     ListHdr *d_hdrs = nullptr;
     uint32_t *d_tabs = nullptr;
+    IListHdr *d_ihdrs = nullptr;         // mode 3
+    uint32_t *d_iflags = nullptr;        // mode 3: run-start bits, [list][round][thread]
     int rmax = 0;
-    bool want_rc = true;                 // what the lists were asked to be when they were built
+    int want = 2;                        // what the lists were asked to be when they were built
     double list_bytes_per_window = 0.0;
 };
 
 static void real_free_lists(RealOS *f)
 {
-    void *ptrs[] = {f->d_lst_k, f->d_lst_q, f->d_hdrs, f->d_tabs};
+    void *ptrs[] = {f->d_lst_k, f->d_lst_q, f->d_hdrs, f->d_tabs, f->d_ihdrs, f->d_iflags};
     for (void *q : ptrs)
         if (q) (void)cm2::dev_free(q);
     f->d_lst_k = nullptr;
     f->d_lst_q = nullptr;
     f->d_hdrs = nullptr;
     f->d_tabs = nullptr;
+    f->d_ihdrs = nullptr;
+    f->d_iflags = nullptr;
     f->list_plan = 0;
     f->list_mode = 0;
     f->rmax = 0;
@@ -1238,14 +1536,14 @@ template <int PT, int MODE, int TPT, bool BUF>
 static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, uint32_t nbytes, hipStream_t stream)
 {
     using G = Geo<PT>;
-    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE == 2 ? sizeof(uint32_t) * 2 * (size_t)f->rmax : 0);
+    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)f->rmax : 0);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<PT, MODE, TPT, BUF>, lds, granted));
     if (f->nwin == 0) return 0;
     const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
     k_os_real<PT, MODE, TPT, BUF><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
                                                              f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out,
-                                                             nbytes OS_STAMP_ARG);
+                                                             nbytes, f->d_ihdrs, f->d_iflags OS_STAMP_ARG);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -1262,6 +1560,14 @@ static int real_launch(const RealOS *f, int mode, int64_t nvalid, const double *
         return buf ? real_launch_t<PT, 1, 1, true>(f, d_v, d_out, nbytes, stream)
                    : real_launch_t<PT, 1, 1, false>(f, d_v, d_out, 0, stream);
     const int tpt = (f->rmax + kT - 1) / kT;
+    if (mode == 3) {
+        if (tpt <= 2)
+            return buf ? real_launch_t<PT, 3, 2, true>(f, d_v, d_out, nbytes, stream)
+                       : real_launch_t<PT, 3, 2, false>(f, d_v, d_out, 0, stream);
+        if (tpt <= 8)
+            return buf ? real_launch_t<PT, 3, 8, true>(f, d_v, d_out, nbytes, stream)
+                       : real_launch_t<PT, 3, 8, false>(f, d_v, d_out, 0, stream);
+    }
     if (tpt <= 2)
         return buf ? real_launch_t<PT, 2, 2, true>(f, d_v, d_out, nbytes, stream)
                    : real_launch_t<PT, 2, 2, false>(f, d_v, d_out, 0, stream);
@@ -1338,13 +1644,50 @@ static int real_build_lists_direct(RealOS *f, const uint32_t *d_idx, const int64
     return 0;
 }
 
+// Inverse lists (k_real_ilists): needs the tile offsets and run tables that fit LDS (<= 2048 runs).
+template <int PT>
+static int real_build_ilists(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
+                             int64_t ntiles, hipStream_t stream)
+{
+    using G = Geo<PT>;
+    const int64_t total = f->nwin * G::PER;
+    const int64_t nlists = f->nwin * 2;
+    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
+    const int rmax = real_rmax<PT>(ntiles);
+    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&f->d_ihdrs, sizeof(IListHdr) * nlists));
+    CM2_HIP(cm2::dev_malloc(&f->d_iflags, sizeof(uint32_t) * nlists * 512));
+    CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+    DevTemp<uint32_t> d_max;
+    CM2_HIP(d_max.alloc(1));
+    CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
+    const size_t lds = sizeof(uint32_t) * (size_t)(3 * ntiles + 1 + 12 + 512);
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_real_ilists<PT>, lds, granted));
+    k_real_ilists<PT><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
+                                                             f->d_lst_q, f->d_iflags, f->d_ihdrs, f->d_tabs, rmax, d_max);
+    CM2_LAUNCH_OK();
+    uint32_t h_max = 0;
+    CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(hipStreamSynchronize(stream));
+    CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel tiles allow",
+              h_max, rmax);
+    f->rmax = rmax;
+    f->list_mode = 3;
+    f->list_bytes_per_window = 2.0 * G::PER + 2 * (sizeof(IListHdr) + 2048.0 + 4.0 * h_max);
+    guard.f = nullptr;
+    f->list_plan = plan_id;
+    return 0;
+}
+
 // d_tile_off: first address of every pixel tile ([ntiles + 1], NULL = unknown).  With it the lists
 // are written directly; without it (or CM2_OS_LIST_BUILD=sort, or more tiles than k_real_lists
 // keeps in LDS) they come from a segmented sort of (address, position) pairs.
 template <int PT>
 static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                            int64_t ntiles, bool want_rc, hipStream_t stream)
+                            int64_t ntiles, int want, hipStream_t stream)
 {
+    const bool want_rc = want >= 2;
     using G = Geo<PT>;
     real_free_lists(f);
     if (f->nwin == 0) {
@@ -1355,8 +1698,11 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
     {
         const char *e = getenv("CM2_OS_LIST_BUILD");         // direct (default) | sort
         const bool sort = e && strcmp(e, "sort") == 0;
-        if (!sort && d_tile_off && ntiles > 0 && ntiles <= 4096)
+        if (!sort && d_tile_off && ntiles > 0 && ntiles <= 4096) {
+            if (want == 3 && real_rmax<PT>(ntiles) <= 8 * kT && f->nwin * 2 < ((int64_t)1 << 31))
+                return real_build_ilists<PT>(f, d_idx, d_tile_off, plan_id, ntiles, stream);
             return real_build_lists_direct<PT>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream);
+        }
     }
     const int64_t total = f->nwin * G::PER;
     struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
@@ -1427,14 +1773,20 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
 }
 
 int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                          int64_t ntiles, int64_t nvalid, bool want_rc, const double *d_v, double *d_out,
+                          int64_t ntiles, int64_t nvalid, int want, const double *d_v, double *d_out,
                           hipStream_t stream)
 {
-    if (f->list_plan != plan_id || f->list_mode == 0 || f->want_rc != want_rc) {
-        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream)
-                                  : real_build_lists<32>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream)))
+    // want = 0: by tile count.  Lists cut by time (mode 2) keep the pick / place side cheap and win
+    // while a half window's address runs are long (512 tiles at C4: 16 entries); from ~768 tiles up
+    // the longer runs and whole sectors of the lists cut by address (mode 3) win: C5's 1536 tiles
+    // 1.24 -> 1.05 ms, the balanced tiling of an uneven hit map (1015 tiles) 0.92 -> 0.87 ms, 512 tiles
+    // 0.76 -> 0.79 ms (profiles/r03_inverse_lists.md).
+    if (want == 0) want = ntiles >= 768 ? 3 : 2;
+    if (f->list_plan != plan_id || f->list_mode == 0 || f->want != want) {
+        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)
+                                  : real_build_lists<32>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)))
             return rc;
-        f->want_rc = want_rc;          // (a plan whose run tables do not fit stays on plain lists)
+        f->want = want;                // (a plan whose run tables do not fit stays on plain lists)
     }
     return f->pt == 16 ? real_launch<16>(f, f->list_mode, nvalid, d_v, d_out, stream)
                        : real_launch<32>(f, f->list_mode, nvalid, d_v, d_out, stream);

@@ -1268,7 +1268,8 @@ def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
 
 
 @pytest.mark.parametrize("kernel,lists", [("pair", "plain"), ("real16", "rc"), ("real16", "plain"),
-                                          ("real32", "plain"), ("real32", "rc")])
+                                          ("real32", "plain"), ("real32", "rc"), ("real32", "inv"),
+                                          ("real16", "inv")])
 @pytest.mark.parametrize("tp,lam,npix", [(1024, 300, 70000), (2048, 2049, 70000), (64, 40, 200000)])
 def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp, lam, npix):
     """Every overlap-save kernel behind the switches (CM2_OS_KERNEL = pair | real16 | real32,
@@ -1300,7 +1301,7 @@ def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp
     assert info["os_kernel"] == kernel
     many_tiles = npix // tp > 2048
     assert info["os_lists"] == ("plain" if lists == "plain" or kernel == "pair" or many_tiles
-                                else "run-coded")
+                                else ("inverse run-coded" if lists == "inv" else "run-coded"))
 
 
 def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
