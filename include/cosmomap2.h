@@ -203,7 +203,9 @@ int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
  * kernel), h_info[1] = list format (1 plain, 2 run-coded, 0 = lists not built yet), h_info[2] =
  * window length in samples; *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to
  * move (lists + gathered windows + results).  Environment switches read at every application:
- * CM2_OS_KERNEL = real32 (default) | real16 | pair, CM2_OS_LISTS = rc (default) | plain. */
+ * CM2_OS_KERNEL = real32 (default) | real16 | pair, CM2_OS_LISTS = auto (default: rc below 768
+ * pixel tiles, inv from there up) | rc | inv | plain.  h_info[1]: 1 plain, 2 run-coded lists cut by
+ * time, 3 run-coded lists cut by address ("inverse"). */
 int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample);
 
 /* ------------------------------------------------------------------------- *
