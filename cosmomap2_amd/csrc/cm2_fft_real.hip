@@ -294,7 +294,8 @@ struct ListArgs {
     const uint32_t *tab;      // RC: run table of this list in global memory
 };
 
-// RC: request the run table of a list (at most TPT words per thread)
+// RC: request the run table of a list (at most TPT words per thread).  Callers pass the allocated
+// length of the table, not the list's run count: the request then does not wait for the header.
 template <int TPT>
 __device__ __forceinline__ void tab_request(const ListArgs &la, int t, uint32_t nruns, uint32_t (&tv)[TPT])
 {
@@ -621,8 +622,8 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             nvb = l1.hdr->nvalid;
             wba = l0.hdr->wbase[wave];
             wbb = l1.hdr->wbase[wave];
-            tab_request<TPT>(l0, t, l0.hdr->nruns, ta);
-            tab_request<TPT>(l1, t, l1.hdr->nruns, tb);
+            tab_request<TPT>(l0, t, (uint32_t)rmax, ta);
+            tab_request<TPT>(l1, t, (uint32_t)rmax, tb);
         }
 #pragma unroll
         for (int u = 0; u < PT; ++u) qa[u] = ld_list(l0.q + slot_of<PT>(t, u));
@@ -704,8 +705,8 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             nvb = l1.hdr->nvalid;
             wba = l0.hdr->wbase[wave];
             wbb = l1.hdr->wbase[wave];
-            tab_request<TPT>(l0, t, l0.hdr->nruns, ta);
-            tab_request<TPT>(l1, t, l1.hdr->nruns, tb);
+            tab_request<TPT>(l0, t, (uint32_t)rmax, ta);
+            tab_request<TPT>(l1, t, (uint32_t)rmax, tb);
         }
 #pragma unroll
         for (int u = 0; u < PT; ++u) {
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             if constexpr (MODE == 2) {
                 nv = ls.hdr->nvalid;
                 wb = ls.hdr->wbase[wave];
-                tab_request<TPT>(ls, t, ls.hdr->nruns, tq);
+                tab_request<TPT>(ls, t, (uint32_t)rmax, tq);
             }
 #pragma unroll
             for (int u = 0; u < ER; ++u) {
