@@ -219,6 +219,108 @@ __global__ __launch_bounds__(256) void k_tile_place(
     }
 }
 
+// k_tile_place with the chunk's samples staged in LDS by address: one workgroup per chunk of
+// kSplitChunk samples.  The chunk's samples of tile b occupy the addresses base[b][chunk] ..; in LDS
+// they get the slots lbase[b] .. (lbase = scan of the chunk's per-tile counts), so that consecutive
+// slots are consecutive addresses inside a run and the 2-byte words and half angles leave in pieces
+// of 16 entries per tile instead of one scattered store per sample (4.9 -> 2 ms at C4).  Used for the
+// one-array forms (pol = 1, half angles): 8192 doubles + 2 x 8192 words + two tables per tile.
+template <int POL>
+__global__ __launch_bounds__(256) void k_tile_place_staged(
+    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t nchunks, int ntiles,
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ base,
+    const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
+    uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb)
+{
+    extern __shared__ double sm_p[];
+    double *hs = sm_p;                                              // [kSplitChunk] half angles by slot
+    uint32_t *gbase = reinterpret_cast<uint32_t *>(hs + (POL > 1 ? kSplitChunk : 0));   // [ntiles]
+    uint32_t *lbase = gbase + ntiles;                               // [ntiles + 1]
+    uint16_t *ws = reinterpret_cast<uint16_t *>(lbase + ntiles + 1);   // [kSplitChunk] pl words by slot
+    uint16_t *ts = ws + kSplitChunk;                                // [kSplitChunk] tile of the slot
+    __shared__ uint32_t wsum[4];
+    const int64_t ch = blockIdx.x;
+    const int64_t i0 = ch * kSplitChunk, i1 = i0 + kSplitChunk < nt ? i0 + kSplitChunk : nt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // per-tile counts of the chunk (next word of the tile-major scan minus this one), scanned
+    const int per = (ntiles + 255) / 256;
+    uint32_t mine = 0;
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) {
+        const uint32_t g0 = base[(int64_t)b * nchunks + ch], g1 = base[(int64_t)b * nchunks + ch + 1];
+        gbase[b] = g0;
+        lbase[b] = g1 - g0;
+        mine += g1 - g0;
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
+    }
+    for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) {
+        const uint32_t cnt = lbase[b];
+        lbase[b] = before;
+        before += cnt;
+    }
+    if (t == 0) lbase[ntiles] = total;
+    __syncthreads();
+    // (one workgroup per CU: four samples per thread in flight at a time)
+    for (int64_t ib = i0 + t; ib < i1; ib += 4 * 256) {
+        uint32_t pk[4];
+        int32_t px[4];
+        double cv[4], sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = ib + 256 * u;
+            const bool in = i < i1;
+            pk[u] = in ? packed[i] : 0xFFFFFFFFu;
+            px[u] = in ? pix[i] : 0;
+            if (POL > 1) {
+                cv[u] = in ? c[i] : 1.0;
+                sv[u] = in ? s[i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = ib + 256 * u;
+            if (i >= i1) continue;
+            if (pk[u] == 0xFFFFFFFFu) {
+                tb_dst[i] = kInvalidSample;
+                continue;
+            }
+            const uint32_t tile = pk[u] >> 16, r = pk[u] & 0xFFFFu;
+            tb_dst[i] = gbase[tile] + r;
+            const uint32_t slot = lbase[tile] + r;
+            uint16_t w = p0 ? (uint16_t)(px[u] - p0[tile]) : (uint16_t)(px[u] - (int32_t)tile * tp);
+            if (POL > 1) {
+                if (cv[u] < 0.0) {
+                    w |= 0x8000;
+                    hs[slot] = sv[u] / (1.0 - cv[u]);
+                } else {
+                    hs[slot] = sv[u] / (1.0 + cv[u]);
+                }
+            }
+            ws[slot] = w;
+            ts[slot] = (uint16_t)tile;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < total; j += 256) {
+        const uint32_t tile = ts[j];
+        const uint32_t k = gbase[tile] + (j - lbase[tile]);
+        pl[k] = ws[j];
+        if (POL > 1) ctb[k] = hs[j];
+    }
+}
+
 // 1 if some (cos, sin) pair is not on the unit circle to rounding: then the half-angle form
 // would change the operator and the full arrays are kept
 __global__ __launch_bounds__(256) void k_unit_circle(int64_t nt, const double *__restrict__ c,
@@ -745,7 +847,16 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
                 nt, t->nvalid, tile_pixels, balance ? t->d_tile_p0 : nullptr,                  \
                 (uint32_t)t->ntiles, tb_src, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl,        \
                 HALF ? t->d_half : t->d_cos, t->d_sin);                                        \
-        else                                                                                   \
+        else if ((HALF || POL == 1) && t->ntiles <= 4096) {                                    \
+            const size_t lds = (POL > 1 ? sizeof(double) * kSplitChunk : 0) +                  \
+                               sizeof(uint32_t) * (2 * (size_t)t->ntiles + 1) +                \
+                               sizeof(uint16_t) * 2 * kSplitChunk;                             \
+            static size_t granted[64] = {0};                                                   \
+            CM2_HIP(ensure_dynamic_lds((const void *)k_tile_place_staged<POL>, lds, granted));  \
+            k_tile_place_staged<POL><<<(unsigned)nchunks, 256, lds, stream>>>(                 \
+                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, nchunks, (int)t->ntiles,    \
+                packed, cnt_t, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl, t->d_half);          \
+        } else                                                                                 \
             k_tile_place<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                      \
                 nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, nchunks, packed, cnt_t,     \
                 d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl, HALF ? t->d_half : t->d_cos,        \
