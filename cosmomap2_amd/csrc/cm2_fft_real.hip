@@ -71,6 +71,12 @@ __host__ __device__ constexpr int brev(int m)
 #ifndef CM2_OS_RES_BOTH
 #define CM2_OS_RES_BOTH 0
 #endif
+//   CM2_OS_INV_OVERLAP : inverse lists: the second round's gathers are issued behind the first
+//                       round's staging and fly while the first round is picked (instead of both
+//                       rounds' gathers up front)
+#ifndef CM2_OS_INV_OVERLAP
+#define CM2_OS_INV_OVERLAP 0
+#endif
 //   CM2_OS_NT_STORE / CM2_OS_NT_LIST / CM2_OS_NT_GATHER : non-temporal result stores / list loads /
 //                       sample gathers
 #ifndef CM2_OS_NT_STORE
@@ -560,6 +566,52 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         for (int m = 0; m < PT; ++m) pp[m] = pl[t + kT * m];
         tab_store<TPT>(tab_lds, t, rmax, tv);
         __syncthreads();
+#if CM2_OS_INV_OVERLAP
+        // round 1's gathers are in flight while round 0 is picked
+        double va[PT], vb[PT];
+        {
+            uint32_t kk[PT];
+            idecode<PT>(fw[0], tab_lds, wb0, nv, 0u, t, kk);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) va[u] = keep(kk[u], gather(kk[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = va[u];
+        {
+            uint32_t kk[PT];
+            idecode<PT>(fw[1], tab_lds, wb1, nv, (uint32_t)N, t, kk);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) vb[u] = keep(kk[u], gather(kk[u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1) {
+#pragma unroll
+                for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = vb[u];
+                const uint32_t *plj = pl;
+                asm volatile("" : "+v"(plj));
+#pragma unroll
+                for (int m = 0; m < PT; ++m) pp[m] = plj[t + kT * m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < PT; ++m) {
+                const uint32_t lo = (pp[m] & 0xFFFFu) - (uint32_t)(j * N), hi = (pp[m] >> 16) - (uint32_t)(j * N);
+                const bool inl = lo < (uint32_t)N, inh = hi < (uint32_t)N;
+                const double x = buf[inl ? lo : 0u], y = buf[inh ? hi : 0u];
+                if (j == 0) {
+                    zr[m] = inl ? x : 0.0;
+                    zi[m] = inh ? y : 0.0;
+                } else {
+                    zr[m] = inl ? x : zr[m];
+                    zi[m] = inh ? y : zi[m];
+                }
+            }
+            __syncthreads();
+        }
+#else
         // both rounds' gathers are issued before anything is staged: 2 PT loads in flight per thread
         // while the transform's registers are not live yet
         double va[PT], vb[PT];
@@ -605,6 +657,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             }
             __syncthreads();
         }
+#endif
     } else {
 #if CM2_OS_LOAD2
         // Both halves' lists are requested together and both halves' gathers are in flight
