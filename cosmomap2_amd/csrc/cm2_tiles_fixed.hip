@@ -1149,6 +1149,14 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
     struct FailMark { cm2_tiles *t; bool ok; ~FailMark() { if (!ok) { t->fx_failed = 1; t->fx_S = 0; } } } mark{t, false};
     if (t->fx_S == 0) {
         int smax = 4 * kFxT;                             // 4 staged values per thread at most
+        // Two workgroups per CU need <= 79 KB each: a 2048-pixel IQU tile (48 KB) with four staged
+        // values per thread in two buffers (32 KB) would leave ONE workgroup per CU (C5: P^T 0.53 ->
+        // 0.64 ms); the slice is kept short enough for two whenever some slice length allows it.
+        {
+            int s2 = smax;
+            while (s2 > 2 * kFxT && fx_lds_bytes(t, s2) > 79 * 1024) s2 -= kFxT;
+            if (fx_lds_bytes(t, s2) <= 79 * 1024) smax = s2;
+        }
         while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
         if (fx_lds_bytes(t, smax) > 159 * 1024) {        // the tile alone fills LDS: atomics
             t->pt_fixed = 0;
