@@ -306,6 +306,14 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             y = A * x
+        # The end of the queue is polled before the closing barrier + synchronize: a blocking wait of
+        # the runtime sometimes wakes 1-30 ms late on these boxes (seen as single calls of 12-35 ms in
+        # profiles/r03_setup_calls.jsonl and as +0.05 .. 0.1 ms per step over 20 steps here), which
+        # is host latency, not GPU time; after the poll the synchronize returns at once.
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
+            pass
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
