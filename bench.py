@@ -369,8 +369,30 @@ def main():
         ts = sorted(a.elapsed_time(b) for a, b in evs)
         return float(np.mean(ts)), float(ts[len(ts) // 2])
 
+    def seq_time(fns, reps):
+        """The callables launched one after the other, `reps` times back to back, an event between
+        every two launches: each kernel's duration with the caches in the state the step leaves them
+        in (a kernel relaunched on its own inputs finds part of its data in the 256 MB Infinity Cache
+        and measures 3-12 % faster than inside a step; profiles/r03_step_gaps.json)."""
+        for fn in fns:
+            fn()
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)] for _ in range(reps)]
+        for row in evs:
+            row[0].record()
+            for i, fn in enumerate(fns):
+                fn()
+                row[i + 1].record()
+        torch.cuda.synchronize()
+        out = []
+        for i in range(len(fns)):
+            ts = sorted(row[i].elapsed_time(row[i + 1]) for row in evs)
+            out.append((float(np.mean(ts)), float(ts[len(ts) // 2])))
+        return out
+
     reps = max(5, min(args.steps, 20))
     stages = {}          # name -> ((mean ms, median ms), bytes_survey, bytes_designed)
+    stage_timing = "each kernel alone, relaunched on its own inputs"
     map_bytes = 48.0 * npix_c
     tile_info = None
     if lam:
@@ -388,13 +410,21 @@ def main():
                          "half_angle_storage": T.half_angle,
                          "pt_order": {0: "atomic", 1: "fixed (time order per pixel, hot runs in fixed chunks, "
                                       "no atomics)", 2: "exact (time order per pixel)"}[T.pt_mode]}
-            stages["P tiles (k_P_tiles)"] = (ev_time(lambda: call(
-                "cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()), reps),
-                28.0 * nt + map_bytes / 2, (2.0 + ang + 8.0) * nv + map_bytes / 2)
+            pt_name = "P^T tiles (k_Pt_tiles_fixed)" if T.pt_fixed else "P^T tiles (k_Pt_tiles)"
+            pt_designed = ((8.0 + 4.0 + ang) if T.pt_fixed else (8.0 + 2.0 + ang)) * nv + map_bytes / 2
             if args.toeplitz == "fused":
+                # the three kernels of a step in sequence, events between them
                 v_tb = D.empty(T.nvalid)
-                os_ms = ev_time(lambda: call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb),
-                                             D.ptr(v_tb), st()), reps)
+                p_ms, os_ms, pt_ms = seq_time([
+                    lambda: call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()),
+                    lambda: call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(d_tb), D.ptr(v_tb), st()),
+                    lambda: call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st())], reps)
+                stage_timing = "P, N^-1, P^T launched in sequence, events between the kernels"
+            else:
+                p_ms = ev_time(lambda: call("cm2_P_tiles_apply", T.h, D.ptr(x), D.ptr(d_tb), st()), reps)
+            stages["P tiles (k_P_tiles)"] = (p_ms, 28.0 * nt + map_bytes / 2,
+                                             (2.0 + ang + 8.0) * nv + map_bytes / 2)
+            if args.toeplitz == "fused":
                 kinfo = N.tile_kernel_info()               # which kernel ran, its list format
                 tile_info["overlap_save"] = kinfo
                 os_name = ("k_overlap_save_reg, segment pairs" if kinfo["os_kernel"] == "pair" else
@@ -412,11 +442,9 @@ def main():
                 stages["time->tiles (k_time_to_tiles)"] = (ev_time(lambda: call(
                     "cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st()), reps),
                     16.0 * nt, 22.0 * nt)
-            pt_name = "P^T tiles (k_Pt_tiles_fixed)" if T.pt_fixed else "P^T tiles (k_Pt_tiles)"
-            pt_designed = ((8.0 + 4.0 + ang) if T.pt_fixed else (8.0 + 2.0 + ang)) * nv + map_bytes / 2
-            stages[pt_name] = (ev_time(lambda: call(
-                "cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st()), reps),
-                28.0 * nt + map_bytes / 2, pt_designed)
+            if args.toeplitz != "fused":
+                pt_ms = ev_time(lambda: call("cm2_Pt_tiles_apply", T.h, D.ptr(d_tb), D.ptr(out), st()), reps)
+            stages[pt_name] = (pt_ms, 28.0 * nt + map_bytes / 2, pt_designed)
             del d_tb, out
         else:
             stages["P (k_P_time)"] = (ev_time(lambda: P * x, reps), 28.0 * nt + map_bytes / 2,
@@ -831,7 +859,7 @@ def main():
             "roofline": roofline,
             "step_algorithmic_GBps": round(step_gbs, 1),
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
-            "stages": stage_report,
+            "stages": stage_report, "stage_timing": stage_timing,
             "distributed": dist_info,
             "other_scaling_point": other,
             "pcg": pcg,
