@@ -646,6 +646,58 @@ def test_weights_of_a_hot_pixel_are_summed_in_fixed_chunks(cm, oracle, monkeypat
                                                                              phi=phi).counts)
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_problems_every_plan_builder_and_list_format_give_the_same_bits(cm, monkeypatch, seed):
+    """Random shapes (3 000 .. 600 000 samples, 50 .. 120 000 pixels, tiles of 64 .. 2048 pixels, 1 .. 6
+    ragged noise blocks, lambda 2 .. 2049, up to 30 % flagged, sometimes a hot pixel or a tenth of the
+    map holding half of the samples): P^T N^-1 P on the tile order is bit-identical between the
+    sort-free plan builders and the sorted / serial ones, between run-coded lists cut by time and
+    inverse lists cut by address, and between uniform and balanced tiles (pure time order, so that a
+    hot run's chunk boundaries do not enter)."""
+    from types import SimpleNamespace
+    from cosmomap2_amd.interfaces import linearoperators as L
+    rng = np.random.default_rng(seed)
+    monkeypatch.setenv("CM2_PT_ORDER", "exact")
+    builds = (("new", {}), ("old", {"CM2_TILE_BUILD": "sort", "CM2_OS_LIST_BUILD": "sort",
+                                    "CM2_FX_BUILD": "serial", "CM2_OS_LISTS": "rc"}),
+              ("inv", {"CM2_OS_LISTS": "inv"}), ("bal", {"CM2_TILE_BALANCE": "1"}))
+    for case in range(6):
+        pol = int(rng.choice([1, 2, 3]))
+        nt = int(rng.integers(3000, 600000))
+        npix = int(rng.integers(50, 120000))
+        tp = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+        nblk = int(rng.integers(1, 7))
+        cuts = np.sort(rng.choice(np.arange(1, nt), nblk - 1, replace=False)) if nblk > 1 else np.array([], int)
+        sizes = np.diff(np.concatenate([[0], cuts, [nt]])).tolist()
+        lam = int(rng.choice([2, 17, 300, 2049]))
+        pairs = rng.integers(0, npix, nt)
+        if rng.random() < 0.4:
+            pairs[rng.random(nt) < rng.uniform(0.01, 0.2)] = int(rng.integers(0, npix))
+        if rng.random() < 0.3:
+            h = rng.random(nt) < 0.5
+            pairs[h] = pairs[h] % max(npix // 10, 1)
+        pairs[rng.random(nt) < rng.uniform(0, 0.3)] = -1
+        phi = rng.uniform(0, np.pi, nt)
+        ang = SimpleNamespace(cos=np.cos(2 * phi), sin=np.sin(2 * phi))
+        kk = np.arange(lam)
+        bands = [(1.0 + 0.1 * b) * np.exp(-kk / max(lam / 4.0, 1.0)) for b in range(nblk)]
+        x = rng.standard_normal(pol * npix)
+        outs = {}
+        for name, env in builds:
+            for k in ("CM2_TILE_BUILD", "CM2_OS_LIST_BUILD", "CM2_FX_BUILD", "CM2_OS_LISTS", "CM2_TILE_BALANCE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=ang)
+            L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+            N = cm.I.BlockLO(sizes, bands, offdiag=True, method=3)
+            outs[name] = np.asarray(L._TiledNormalLO(P, N) * x)
+        for name in ("old", "inv", "bal"):
+            np.testing.assert_array_equal(outs["new"], outs[name],
+                                          err_msg="%s: %r" % (name, dict(pol=pol, nt=nt, npix=npix, tp=tp,
+                                                                         sizes=sizes, lam=lam)))
+
+
 def test_library_device_memory_is_cached_and_released(cm):
     """Plans and their build temporaries come from the library's cache of released device blocks
     (cm2_core.hip): a second build of the same plan is served from the cache, live bytes return to
