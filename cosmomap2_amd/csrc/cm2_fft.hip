@@ -564,6 +564,7 @@ static void os_choice(int *pt, int *lists)
         if (!strcmp(e, "pair")) *pt = 0;
         else if (!strcmp(e, "real32")) *pt = 32;
         else if (!strcmp(e, "real16")) *pt = 16;
+        else if (!strcmp(e, "wide32")) *pt = 64;         // 32-point windows on 512 threads x 16 points
     }
     if (const char *e = getenv("CM2_OS_LISTS"))
     {

@@ -358,7 +358,8 @@ __device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_
 // of that round.
 struct IListHdr {
     uint32_t nvalid, nruns;
-    int32_t wbase[8];         // [round][wave]: run index in front of the wave's first slot of the round
+    int32_t wbase[16];        // [round][wave] (4 or 8 waves a workgroup): run index in front of the wave's
+                              // first slot of the round
 };
 
 // addresses of this thread's E slots of the round that starts at list slot `soff`
@@ -1002,6 +1003,291 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     OS_STAMP(5);
 }
 
+// ---- the same window on 512 threads (k_os_wide) ---------------------------------------------------
+// k_os_real<32> keeps 32 complex points a thread in registers: 256 VGPRs, one wave per SIMD and
+// workgroup, two in all -- every phase follows its own latency.  Here the 16384-sample window (the
+// same N = 8192 complex points, the same windows, lists and bytes) is held by 512 threads x 16 points
+// (<= 128 VGPRs: four waves per SIMD with two workgroups per CU) as a radix-2 decimation in time on
+// top of the 16-point kernel's passes: threads 0..255 ("group 0") transform the even complex points
+// z[2b], threads 256..511 the odd ones z[2b + 1], each with the 4096-point register FFT (radix
+// 16 x 16 x 16, its own half of the LDS buffer); then  Z[k'] = E[k'] + W^k' O[k'],  Z[k' + 4096] =
+// E[k'] - W^k' O[k'],  W = exp(-2 pi i / 8192): one more exchange per plane, group 0 ends with the
+// bins below 4096, group 1 with those above, both at the slot of k'.  The partner of bin k, N - k, is
+// the slot of 4096 - k' in the OTHER group (k' = 0: the bin itself), i.e. the 16-point kernel's partner
+// map read from the other half of the buffer.  The inverse mirrors it:  E' = Z'[k'] + Z'[k' + 4096],
+// O' = (Z'[k'] - Z'[k' + 4096]) conj(W^k').  Inverse lists only (mode 3); point a = 2 (t + 256 m) + g.
+constexpr int kTW = 512;
+#ifndef CM2_OS_WIDE_WAVES
+#define CM2_OS_WIDE_WAVES 2             // waves per SIMD the register allocation aims at (2: 180 VGPRs, one workgroup per CU; 4: 128 + 57 spilled)
+#endif
+
+template <int TPT, bool BUF>
+__global__ __launch_bounds__(kTW, CM2_OS_WIDE_WAVES) void k_os_wide(
+    const WinDesc *__restrict__ wins, int nwin, const double2 *__restrict__ W8, const double2 *W8_inv,
+    const double2 *__restrict__ ABw, const uint16_t *__restrict__ plist,
+    const IListHdr *__restrict__ ihdrs, const uint32_t *__restrict__ iflags,
+    const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v, double *__restrict__ out,
+    uint32_t nbytes)
+{
+    using G = Geo<32>;                                   // windows, lists: those of the 32-point kernel
+    constexpr int N = G::N, N4 = N / 2, PT = 16, L16 = Geo<16>::LDSD;
+    __amdgpu_buffer_rsrc_t v_rs, o_rs;
+    if constexpr (BUF) {
+        v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(v), 0, (int)nbytes, 0x00020000);
+        o_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)nbytes, 0x00020000);
+    }
+    auto gather = [&](uint32_t k) -> double {
+        if constexpr (BUF) {
+            const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(v_rs, k * 8u, 0, 0);
+            return __builtin_bit_cast(double, r);
+        } else {
+            const double x = ld_gather(v + (k != kInvalidSample ? k : 0u));
+            return k != kInvalidSample ? x : 0.0;
+        }
+    };
+    extern __shared__ double buf[];                      // two halves of L16 doubles, then the run tables
+    uint32_t *__restrict__ tab_lds = reinterpret_cast<uint32_t *>(buf + 2 * L16);
+    const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, wave = tid >> 6;
+    double *__restrict__ bufg = buf + g * L16;
+    const double *__restrict__ bufo = buf + (1 - g) * L16;
+    const int per_xcd = (nwin + 7) / 8;
+    const int win = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (win >= nwin) return;
+    const WinDesc wd = wins[win];
+
+    double zr[PT], zi[PT];
+    // ---- load: two rounds of N slots of the window's address-sorted order ----
+    {
+        const IListHdr *__restrict__ h0 = ihdrs + (int64_t)win * 2;
+        const uint32_t *__restrict__ pl = reinterpret_cast<const uint32_t *>(plist + (int64_t)win * G::PER) + g;
+        uint32_t tv[TPT], fw[2], pp[PT];
+        {
+            const uint32_t *tg = tabs + ((int64_t)win * 2) * rmax;
+#pragma unroll
+            for (int i = 0; i < TPT; ++i) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)i * kTW;
+                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
+            }
+            fw[0] = iflags[((int64_t)win * 2) * (2 * kTW) + tid];
+            fw[1] = iflags[((int64_t)win * 2) * (2 * kTW) + kTW + tid];
+        }
+        const uint32_t nv = h0->nvalid;
+        const int wb0 = h0->wbase[wave], wb1 = h0->wbase[8 + wave];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) pp[m] = pl[2 * (t + 256 * m)];
+#pragma unroll
+        for (int i = 0; i < TPT; ++i)
+            if (tid + i * kTW < rmax) tab_lds[tid + i * kTW] = tv[i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            {
+                uint32_t kk[PT];
+                idecode<PT>(fw[j], tab_lds, j ? wb1 : wb0, nv, (uint32_t)(j * N), tid, kk);
+                double vv[PT];
+#pragma unroll
+                for (int u = 0; u < PT; ++u) vv[u] = gather(kk[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PT; ++u) buf[slot_of<PT>(tid, u)] = vv[u];
+            }
+            if (j == 1) {
+                const uint32_t *plj = pl;
+                asm volatile("" : "+v"(plj));
+#pragma unroll
+                for (int m = 0; m < PT; ++m) pp[m] = plj[2 * (t + 256 * m)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < PT; ++m) {
+                const uint32_t lo = (pp[m] & 0xFFFFu) - (uint32_t)(j * N), hi = (pp[m] >> 16) - (uint32_t)(j * N);
+                const bool inl = lo < (uint32_t)N, inh = hi < (uint32_t)N;
+                const double x = buf[inl ? lo : 0u], y = buf[inh ? hi : 0u];
+                if (j == 0) {
+                    zr[m] = inl ? x : 0.0;
+                    zi[m] = inh ? y : 0.0;
+                } else {
+                    zr[m] = inl ? x : zr[m];
+                    zi[m] = inh ? y : zi[m];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- forward: each group's 4096-point transform (radix 16, 16, 16) ----
+    const double2 w_a = W8[2 * t];                       // exp(-2 pi i t / 4096)
+    const double2 w_b = W8[32 * (t & 15)];               // exp(-2 pi i (t & 15) / 256)
+    reg_fwd<PT, 16, 0>(zr, zi, w_a);
+    reg_exchange<PT, 1, 2, 16>(zr, bufg, t);
+    reg_exchange<PT, 1, 2, 16>(zi, bufg, t);
+    reg_fwd<PT, 16, 0>(zr, zi, w_b);
+    reg_exchange<PT, 2, 3, 16>(zr, bufg, t);
+    reg_exchange<PT, 2, 3, 16>(zi, bufg, t);
+    dft_sub<PT, 16, 0>(zr, zi);
+    // register s = brev16(d3) of thread t now holds bin k' = (t >> 4) + 16 (t & 15) + 256 d3 of the group
+    const int kbase = (t >> 4) + 16 * (t & 15);
+    double *__restrict__ wq = bufg + reg_base<PT, 3>(t);
+    const double *__restrict__ rq = bufo + reg_base<PT, 3>(t);
+    // ---- combine: group 1 multiplies by W^k', then Z = E + W O (group 0), E - W O (group 1) ----
+    if (g == 1) {
+#pragma unroll
+        for (int d3 = 0; d3 < PT; ++d3) {
+            const int sl = brev<16>(d3);
+            const double2 w = W8[kbase + 256 * d3];
+            const double tr = zr[sl] * w.x - zi[sl] * w.y;
+            zi[sl] = zr[sl] * w.y + zi[sl] * w.x;
+            zr[sl] = tr;
+        }
+    }
+    {
+        double p[PT];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zr[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) p[m] = rq[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) zr[m] = g ? p[m] - zr[m] : zr[m] + p[m];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zi[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) p[m] = rq[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) zi[m] = g ? p[m] - zi[m] : zi[m] + p[m];
+    }
+    // ---- pairing with bin N - k (the other group's slot of 4096 - k') and the spectrum product ----
+    {
+        const int tp = t >= 16 ? 271 - t : 16 - t;
+        const int A0 = t == 0 ? 16 : 16 * tp + (tp >> 1) + 15;
+        const double *__restrict__ r0 = bufo + A0;
+        const bool self0 = (t == 0);
+        const double2 *ab = ABw + (int64_t)wd.blk * N + g * N4 + t;
+        double pr[PT];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zr[reg_slot<16>(m)];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) pr[m] = (m == 0 && self0) ? bufg[0] : r0[-m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zi[reg_slot<16>(m)];
+        __syncthreads();
+#pragma unroll
+        for (int m0 = 0; m0 < PT; m0 += 4) {
+            double2 c[4];
+            const double2 *abp = ab + m0 * 256;
+            asm volatile("" : "+v"(abp));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = abp[i * 256];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i, sl = reg_slot<16>(m);
+                const double pim = (m == 0 && self0) ? bufg[0] : r0[-m];
+                const double nr = c[i].x * zr[sl] + c[i].y * pim;
+                const double ni = c[i].x * zi[sl] + c[i].y * pr[m];
+                zr[sl] = nr;
+                zi[sl] = ni;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // ---- inverse combine: E' = Z'[k'] + Z'[k' + 4096] (group 0), O' = (Z'[k'] - Z'[k' + 4096]) conj(W^k') ----
+    {
+        double p[PT];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zr[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) p[m] = rq[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) zr[m] = g ? p[m] - zr[m] : zr[m] + p[m];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) wq[m] = zi[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) p[m] = rq[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PT; ++m) zi[m] = g ? p[m] - zi[m] : zi[m] + p[m];
+    }
+    if (g == 1) {
+#pragma unroll
+        for (int d3 = 0; d3 < PT; ++d3) {
+            const int sl = brev<16>(d3);
+            const double2 w = W8_inv[kbase + 256 * d3];
+            const double tr = zr[sl] * w.x + zi[sl] * w.y;
+            zi[sl] = zi[sl] * w.x - zr[sl] * w.y;
+            zr[sl] = tr;
+        }
+    }
+    // ---- inverse: each group's 4096-point transform ----
+    dit_sub<PT, 16, 0>(zi, zr);
+    const double2 w_bi = W8_inv[32 * (t & 15)], w_ai = W8_inv[2 * t];
+    reg_exchange<PT, 3, 2, 0>(zr, bufg, t);
+    reg_exchange<PT, 3, 2, 0>(zi, bufg, t);
+    reg_inv<PT, 16, 0>(zr, zi, w_bi);
+    // ---- results: the result window's slots in two rounds of RLEN ----
+    constexpr int ER = G::RLEN / kTW, NP = PT - 4;       // slots per thread and round; points with results
+    const IListHdr *h1 = ihdrs + (int64_t)win * 2 + 1;
+    const uint32_t *tg = tabs + ((int64_t)win * 2 + 1) * rmax;
+    const uint32_t *fg = iflags + ((int64_t)win * 2 + 1) * (2 * kTW) + tid;
+    asm volatile("" : "+v"(h1), "+v"(tg), "+v"(fg));
+    const uint32_t nv1 = h1->nvalid;
+    uint32_t tv[TPT], fr[2];
+    const uint32_t *rl = reinterpret_cast<const uint32_t *>(plist + (int64_t)win * G::PER + 2 * N) + g;
+    {
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+            const uint32_t r = (uint32_t)tid + (uint32_t)i * kTW;
+            tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
+        }
+        fr[0] = fg[0];
+        fr[1] = fg[kTW];
+    }
+    reg_exchange<PT, 2, 1, 16>(zr, bufg, t);
+#pragma unroll
+    for (int i = 0; i < TPT; ++i)
+        if (tid + i * kTW < rmax) tab_lds[rmax + tid + i * kTW] = tv[i];   // published by the next barriers
+    reg_exchange<PT, 2, 1, 16>(zi, bufg, t);
+    reg_inv<PT, PT, 0>(zr, zi, w_ai);                    // point b = t + 256 m at index brev<16>(m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j > 0) __syncthreads();
+        const uint32_t *rlj = rl;
+        asm volatile("" : "+v"(rlj));
+        uint32_t rp[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) rp[m] = rlj[2 * (t + 256 * m)];
+        // point a = 2 (t + 256 m) + g holds window samples 2a, 2a + 1; results are the points with
+        // m in [2, 14): result position 2 (a - 1024) + {0, 1}
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const uint32_t lo = (rp[m] & 0xFFFFu) - (uint32_t)(j * G::RLEN), hi = (rp[m] >> 16) - (uint32_t)(j * G::RLEN);
+            buf[lo < (uint32_t)G::RLEN ? lo : (uint32_t)N] = zr[brev<16>(m + 2)];
+            buf[hi < (uint32_t)G::RLEN ? hi : (uint32_t)N + 1u] = zi[brev<16>(m + 2)];
+        }
+        __syncthreads();
+        uint32_t ks[ER];
+        idecode<ER>(fr[j], tab_lds + rmax, h1->wbase[8 * j + wave], nv1, (uint32_t)(j * G::RLEN), tid, ks);
+        double rv[ER];
+#pragma unroll
+        for (int u = 0; u < ER; ++u) rv[u] = buf[slot_of<ER>(tid, u)];
+#pragma unroll
+        for (int u = 0; u < ER; ++u) {
+            if constexpr (BUF) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, rv[u]), o_rs, ks[u] * 8u, 0, 0);
+            } else {
+                if (ks[u] != kInvalidSample) st_result(out + ks[u], rv[u]);
+            }
+        }
+    }
+}
+
 // ---- plan-time kernels ----------------------------------------------------------------------------
 // entries of the lists of windows [w0, w0 + nw), PER per window, in the order they are stored:
 //   list 0 / 1: window positions [0, N) / [N, 2N)        -> value = position within the half
@@ -1277,16 +1563,18 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
                                                       const int64_t *__restrict__ tile_off, int ntiles,
                                                       uint16_t *__restrict__ plist, uint32_t *__restrict__ flags,
                                                       IListHdr *__restrict__ hdrs, uint32_t *__restrict__ tabs,
-                                                      int rmax, uint32_t *__restrict__ max_runs)
+                                                      int rmax, uint32_t *__restrict__ max_runs, int threads)
 {
+    // threads: workgroup size of the kernel that will read the lists (256: k_os_real, 512: k_os_wide);
+    // it fixes the slot order of a round (slot = 64 (E wave + u) + lane, E = round / threads)
     using G = Geo<PT>;
     constexpr int EMAX = 2 * G::N / 256;
     extern __shared__ uint32_t sm_i[];
     uint32_t *toff = sm_i;                               // [ntiles + 1]
     uint32_t *cnt = toff + ntiles + 1;                   // [ntiles] entries, then: base slot
     uint32_t *mn = cnt + ntiles;                         // [ntiles] lowest address
-    uint32_t *misc = mn + ntiles;                        // [4] scan sums, [8] wbase counts
-    uint32_t *fl = misc + 12;                            // [512] run-start bits
+    uint32_t *misc = mn + ntiles;                        // [4] scan sums, [16] wbase counts
+    uint32_t *fl = misc + 20;                            // [2 threads] run-start bits
     const int64_t lid = blockIdx.x;
     if (lid >= nlists) return;
     const int l = (int)(lid & 1);
@@ -1294,7 +1582,7 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
     const int64_t e0 = win * G::PER + (l ? 2 * G::N : 0);
     const int len = l ? G::HOP : 2 * G::N;               // positions
     const int RL = l ? G::RLEN : G::N;                   // slots a round
-    const int rounds = l ? G::RR : 2, rows = len / 256, E = RL / 256;
+    const int rounds = l ? G::RR : 2, rows = len / 256, E = RL / threads, nw = threads / 64;
     const WinDesc wd = wins[win];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int b = t; b <= ntiles; b += 256) toff[b] = (uint32_t)tile_off[b];
@@ -1302,8 +1590,8 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
         cnt[b] = 0;
         mn[b] = 0xFFFFFFFFu;
     }
-    if (t < 12) misc[t] = 0;
-    for (int i = t; i < 512; i += 256) fl[i] = 0;
+    if (t < 20) misc[t] = 0;
+    for (int i = t; i < 2 * threads; i += 256) fl[i] = 0;
     __syncthreads();
     uint32_t a[EMAX];
     uint16_t tl[EMAX];
@@ -1360,10 +1648,10 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
             // the run's first slot: round, then (wave, row, lane) of the kernel's slot order
             const int j = (int)base / RL, sr = (int)base % RL;
             const int wv = sr / (64 * E), rem = sr % (64 * E);
-            atomicOr(&fl[256 * j + 64 * wv + (rem & 63)], 1u << (rem >> 6));
+            atomicOr(&fl[threads * j + 64 * wv + (rem & 63)], 1u << (rem >> 6));
             for (int jj = 0; jj < rounds; ++jj)
-                for (int w = 0; w < 4; ++w)
-                    if ((int)base < jj * RL + w * (RL / 4)) atomicAdd(&misc[4 + 4 * jj + w], 1u);
+                for (int w = 0; w < nw; ++w)
+                    if ((int)base < jj * RL + w * (RL / nw)) atomicAdd(&misc[4 + nw * jj + w], 1u);
             before += c | 0x10000u;
         }
     }
@@ -1376,12 +1664,12 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
             if (a[i] != kInvalidSample) slot = (uint16_t)(cnt[tl[i]] + (a[i] - mn[tl[i]]));
             plist[e0 + e] = slot;
         }
-    for (int i = t; i < 512; i += 256) flags[lid * 512 + i] = fl[i];
+    for (int i = t; i < 2 * threads; i += 256) flags[lid * 2 * threads + i] = fl[i];
     if (t == 0) {
         IListHdr h;
         h.nvalid = (uint32_t)nvalid;
         h.nruns = (uint32_t)nruns;
-        for (int k = 0; k < 8; ++k) h.wbase[k] = (int32_t)misc[4 + k] - 1;
+        for (int k = 0; k < 16; ++k) h.wbase[k] = (int32_t)misc[4 + k] - 1;
         hdrs[lid] = h;
         atomicMax(max_runs, (uint32_t)nruns);
     }
@@ -1466,6 +1754,28 @@ __global__ __launch_bounds__(256) void k_real_alpha_beta(int nb, const double *_
     }
 }
 
+
+// the same tables for k_os_wide: N = 8192 bins, bin k = k' + 4096 g with k' = (t >> 4) + 16 (t & 15) +
+// 256 m at [block][g][m][t]
+__global__ __launch_bounds__(256) void k_real_alpha_beta_wide(int nb, const double *__restrict__ Hs,
+                                                               double2 *__restrict__ AB)
+{
+    constexpr int N = Geo<32>::N;
+    const int64_t total = (int64_t)nb * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N;
+        const int a = (int)(e - b * N);
+        const int g = a / 4096, m = (a / 256) % 16, t = a % 256;
+        const int k = (t >> 4) + 16 * (t & 15) + 256 * m + 4096 * g;
+        const double *h = Hs + b * (N + 1);
+        const double hk = h[k], hp = h[N - k];
+        const double S = 0.5 * (hk + hp), Dd = 0.5 * (hk - hp);
+        const double th = (double)k / (double)N;
+        AB[e] = make_double2((S - Dd * sinpi(th)) / (double)N, (Dd * cospi(th)) / (double)N);
+    }
+}
+
 }  // namespace
 
 namespace cm2 {
@@ -1488,6 +1798,8 @@ struct RealOS {
     uint32_t *d_iflags = nullptr;        // mode 3: run-start bits, [list][round][thread]
     int rmax = 0;
     int want = 2;                        // what the lists were asked to be when they were built
+    bool wide = false;                   // tile order through k_os_wide (512 threads x 16 points, inverse lists)
+    double2 *d_ABw = nullptr;            // its (alpha, beta) tables: [block][group][slot][thread]
     double list_bytes_per_window = 0.0;
 };
 
@@ -1511,7 +1823,7 @@ void real_os_destroy(RealOS *f)
 {
     if (!f) return;
     real_free_lists(f);
-    void *ptrs[] = {f->d_wins, f->d_AB, f->d_W};
+    void *ptrs[] = {f->d_wins, f->d_AB, f->d_W, f->d_ABw};
     for (void *q : ptrs)
         if (q) (void)cm2::dev_free(q);
     delete f;
@@ -1558,6 +1870,11 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
         CM2_LAUNCH_OK();
         k_real_alpha_beta<PT><<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_AB);
         CM2_LAUNCH_OK();
+        if (f->wide && PT == 32) {
+            CM2_HIP(cm2::dev_malloc(&f->d_ABw, sizeof(double2) * nb * G::N));
+            k_real_alpha_beta_wide<<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_ABw);
+            CM2_LAUNCH_OK();
+        }
         CM2_HIP(hipStreamSynchronize(stream));
     }
     CM2_HIP(cm2::dev_malloc(&f->d_W, sizeof(double2) * G::N));
@@ -1572,11 +1889,16 @@ int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
 {
     CM2_CHECK(out != nullptr, "real_os_create: out is NULL");
     *out = nullptr;
+    // pt = 64: the 32-point kernel's windows and lists, applied on the tile order by k_os_wide
+    // (512 threads x 16 points); the time order keeps the 32-point kernel
+    const bool wide = pt == 64;
+    if (wide) pt = 32;
     CM2_CHECK(pt == 16 || pt == 32, "real_os_create: points per thread must be 16 or 32, got %d", pt);
     CM2_CHECK(lambda >= 1 && lambda - 1 <= kHalo, "fused overlap-save supports lambda <= 2049, got %lld",
               (long long)lambda);
     RealOS *f = new RealOS();
     f->pt = pt;
+    f->wide = wide;
     struct Guard { RealOS *f; ~Guard() { if (f) real_os_destroy(f); } } guard{f};
     if (int rc = (pt == 16 ? real_create<16>(f, d_bands, lambda, off, stream)
                            : real_create<32>(f, d_bands, lambda, off, stream)))
@@ -1628,6 +1950,33 @@ static int real_launch(const RealOS *f, int mode, int64_t nvalid, const double *
     if (tpt <= 8)
         return buf ? real_launch_t<PT, 2, 8, true>(f, d_v, d_out, nbytes, stream)
                    : real_launch_t<PT, 2, 8, false>(f, d_v, d_out, 0, stream);
+    set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
+    return 2;
+}
+
+template <int TPT, bool BUF>
+static int wide_launch_t(const RealOS *f, const double *d_v, double *d_out, uint32_t nbytes, hipStream_t stream)
+{
+    const size_t lds = sizeof(double) * 2 * (size_t)Geo<16>::LDSD + sizeof(uint32_t) * 2 * (size_t)f->rmax;
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_os_wide<TPT, BUF>, lds, granted));
+    if (f->nwin == 0) return 0;
+    const int grid = (int)(((f->nwin + 7) / 8) * 8);
+    k_os_wide<TPT, BUF><<<grid, kTW, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_ABw, f->d_lst_q,
+                                                   f->d_ihdrs, f->d_iflags, f->d_tabs, f->rmax, d_v, d_out, nbytes);
+    CM2_LAUNCH_OK();
+    return 0;
+}
+
+static int wide_launch(const RealOS *f, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream)
+{
+    const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !getenv("CM2_OS_FLAT");
+    const uint32_t nbytes = buf ? (uint32_t)(nvalid * 8) : 0u;
+    const int tpt = (f->rmax + kTW - 1) / kTW;
+    if (tpt <= 1)
+        return buf ? wide_launch_t<1, true>(f, d_v, d_out, nbytes, stream) : wide_launch_t<1, false>(f, d_v, d_out, 0, stream);
+    if (tpt <= 4)
+        return buf ? wide_launch_t<4, true>(f, d_v, d_out, nbytes, stream) : wide_launch_t<4, false>(f, d_v, d_out, 0, stream);
     set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
     return 2;
 }
@@ -1704,22 +2053,24 @@ static int real_build_ilists(RealOS *f, const uint32_t *d_idx, const int64_t *d_
                              int64_t ntiles, hipStream_t stream)
 {
     using G = Geo<PT>;
+    const int threads = f->wide ? 512 : 256;             // workgroup size of the kernel that reads them
     const int64_t total = f->nwin * G::PER;
     const int64_t nlists = f->nwin * 2;
     struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
     const int rmax = real_rmax<PT>(ntiles);
     CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
     CM2_HIP(cm2::dev_malloc(&f->d_ihdrs, sizeof(IListHdr) * nlists));
-    CM2_HIP(cm2::dev_malloc(&f->d_iflags, sizeof(uint32_t) * nlists * 512));
+    CM2_HIP(cm2::dev_malloc(&f->d_iflags, sizeof(uint32_t) * nlists * 2 * threads));
     CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
     DevTemp<uint32_t> d_max;
     CM2_HIP(d_max.alloc(1));
     CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
-    const size_t lds = sizeof(uint32_t) * (size_t)(3 * ntiles + 1 + 12 + 512);
+    const size_t lds = sizeof(uint32_t) * (size_t)(3 * ntiles + 1 + 20 + 2 * threads);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_real_ilists<PT>, lds, granted));
     k_real_ilists<PT><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
-                                                             f->d_lst_q, f->d_iflags, f->d_ihdrs, f->d_tabs, rmax, d_max);
+                                                             f->d_lst_q, f->d_iflags, f->d_ihdrs, f->d_tabs, rmax, d_max,
+                                                             threads);
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
     CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1836,12 +2187,14 @@ int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_til
     // 1.24 -> 1.05 ms, the balanced tiling of an uneven hit map (1015 tiles) 0.92 -> 0.87 ms, 512 tiles
     // 0.76 -> 0.79 ms (profiles/r03_inverse_lists.md).
     if (want == 0) want = ntiles >= 768 ? 3 : 2;
+    if (f->wide) want = 3;                               // k_os_wide reads inverse lists only
     if (f->list_plan != plan_id || f->list_mode == 0 || f->want != want) {
         if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)
                                   : real_build_lists<32>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)))
             return rc;
         f->want = want;                // (a plan whose run tables do not fit stays on plain lists)
     }
+    if (f->wide && f->list_mode == 3) return wide_launch(f, nvalid, d_v, d_out, stream);
     return f->pt == 16 ? real_launch<16>(f, f->list_mode, nvalid, d_v, d_out, stream)
                        : real_launch<32>(f, f->list_mode, nvalid, d_v, d_out, stream);
 }

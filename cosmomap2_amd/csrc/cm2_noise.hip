@@ -409,7 +409,7 @@ extern "C" int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, d
     *h_bytes_per_sample = cm2::fused_os_tile_info(n->fused, kernel);
     h_info[0] = kernel[0];
     h_info[1] = kernel[1];
-    h_info[2] = kernel[0] ? 512 * (int64_t)kernel[0] : 12288;
+    h_info[2] = kernel[0] == 64 ? 16384 : (kernel[0] ? 512 * (int64_t)kernel[0] : 12288);   // (64: k_os_wide)
     return 0;
 }
 

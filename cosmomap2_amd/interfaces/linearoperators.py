@@ -583,7 +583,7 @@ class BlockLO(blk.BlockDiagonalLinearOperator):
         info = (ctypes.c_int64 * 3)()
         bps = ctypes.c_double(0.0)
         _hip.call("cm2_noise_tile_kernel_info", self._noise.h, info, ctypes.byref(bps))
-        return dict(os_kernel=("pair" if info[0] == 0 else "real%d" % info[0]),
+        return dict(os_kernel={0: "pair", 64: "wide32"}.get(int(info[0]), "real%d" % info[0]),
                     os_lists={0: "not built", 1: "plain", 2: "run-coded", 3: "inverse run-coded"}[int(info[1])],
                     os_window=int(info[2]), tile_bytes_per_sample=round(float(bps.value), 2))
 

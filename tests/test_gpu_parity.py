@@ -1269,7 +1269,7 @@ def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
 
 @pytest.mark.parametrize("kernel,lists", [("pair", "plain"), ("real16", "rc"), ("real16", "plain"),
                                           ("real32", "plain"), ("real32", "rc"), ("real32", "inv"),
-                                          ("real16", "inv")])
+                                          ("real16", "inv"), ("wide32", "inv")])
 @pytest.mark.parametrize("tp,lam,npix", [(1024, 300, 70000), (2048, 2049, 70000), (64, 40, 200000)])
 def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp, lam, npix):
     """Every overlap-save kernel behind the switches (CM2_OS_KERNEL = pair | real16 | real32,
