@@ -77,6 +77,13 @@ __host__ __device__ constexpr int brev(int m)
 #ifndef CM2_OS_INV_OVERLAP
 #define CM2_OS_INV_OVERLAP 0
 #endif
+//   CM2_OS_SETPRIO     : wave priority (s_setprio 1..3) during the transform phases, 0 in the load and
+//                       result phases: the workgroup that computes wins the SIMD's issue slots over
+//                       the one that waits for memory; negative: the other way round (time-cut lists
+//                       only).  Measured: +5 % slower with 1 or 3 (profiles/r03_os_knob_builds.jsonl)
+#ifndef CM2_OS_SETPRIO
+#define CM2_OS_SETPRIO 0
+#endif
 //   CM2_OS_NT_STORE / CM2_OS_NT_LIST / CM2_OS_NT_GATHER : non-temporal result stores / list loads /
 //                       sample gathers
 #ifndef CM2_OS_NT_STORE
@@ -510,6 +517,9 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const int64_t w0 = wd.start - kHalo;            // time of window position 0
     const int wave = t >> 6;
     OS_STAMP(0);
+#if CM2_OS_SETPRIO < 0
+    __builtin_amdgcn_s_setprio(-(CM2_OS_SETPRIO));   // (negative: the load and result phases are the favoured ones)
+#endif
 
     auto list_args = [&](int l) {
         ListArgs la;
@@ -817,6 +827,11 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
 
 #endif
     OS_STAMP(1);
+#if CM2_OS_SETPRIO > 0
+    __builtin_amdgcn_s_setprio(CM2_OS_SETPRIO);      // transform phases win the issue slots of the SIMD
+#elif CM2_OS_SETPRIO < 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const double2 w_a = Wtw[t];                      // n = N:   exp(-2 pi i t / N)
     const double2 w_b = Wtw[PT * (t & 15)];          // n = 256: exp(-2 pi i (t & 15) / 256)
 
@@ -948,6 +963,11 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
     // ---- store: y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4), RSLOTS slots a round --
     OS_STAMP(4);
+#if CM2_OS_SETPRIO > 0
+    __builtin_amdgcn_s_setprio(0);
+#elif CM2_OS_SETPRIO < 0
+    __builtin_amdgcn_s_setprio(-(CM2_OS_SETPRIO));
+#endif
 #pragma unroll
     for (int j = 0; j < G::RR; ++j) {
         const uint32_t *tabj = tab_lds;
