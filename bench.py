@@ -427,8 +427,7 @@ def main():
             if args.toeplitz == "fused":
                 kinfo = N.tile_kernel_info()               # which kernel ran, its list format
                 tile_info["overlap_save"] = kinfo
-                os_name = ("k_overlap_save_reg, segment pairs" if kinfo["os_kernel"] == "pair" else
-                           "k_os_real<%s>, one real window of %d samples per workgroup, %s lists"
+                os_name = ("k_os_real<%s>, one real window of %d samples per workgroup, %s lists"
                            % (kinfo["os_kernel"][4:], kinfo["os_window"], kinfo["os_lists"]))
                 stages["N^-1 on tile order (%s)" % os_name] = (
                     os_ms, 16.0 * nt, float(kinfo["tile_bytes_per_sample"]) * nv)

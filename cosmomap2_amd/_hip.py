@@ -52,6 +52,7 @@ PROTOTYPES = {
     "cm2_noise_destroy": [_vp],
     "cm2_noise_apply": [_vp, _vp, _vp, _vp],
     "cm2_noise_apply_tiles": [_vp, _vp, _vp, _vp, _vp],
+    "cm2_noise_prepare_tiles": [_vp, _vp, _vp],
     "cm2_noise_expand_diag": [_vp, _vp, _vp],
     "cm2_noise_info": [_vp, ctypes.POINTER(_i64)],
     "cm2_noise_tile_kernel_info": [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)],

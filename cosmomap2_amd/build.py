@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=
 
 
 # translation units whose results are not compared bit for bit (FFT butterflies): FMA allowed
-FMA_OK = {"cm2_fft.hip", "cm2_fft_real.hip"}
+FMA_OK = {"cm2_overlap_save.hip"}
 
 
 def _newer(target, deps):
@@ -36,7 +36,19 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def compile_command(src, obj):
+    """hipcc line of one translation unit (with the per-kernel resource remarks switched on)."""
+    flags = list(FLAGS) + os.environ.get("CM2_EXTRA_HIPCC_FLAGS", "").split()
+    if os.path.basename(src) in FMA_OK:
+        flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
+    return [HIPCC] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+
+
+def build(force=False, verbose=True, allow_spills=None):
+    """Compile what is out of date, link, write the per-kernel register table of the shipped objects
+    to profiles/kernel_resources.md and raise when a default-path kernel spills registers
+    (kernel_resources.NO_SPILL; CM2_ALLOW_SPILLS=1 turns the failure into a warning for experiments)."""
+    from cosmomap2_amd import kernel_resources as KR
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + \
@@ -46,23 +58,56 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            flags = list(FLAGS) + os.environ.get("CM2_EXTRA_HIPCC_FLAGS", "").split()
-            if os.path.basename(s) in FMA_OK:
-                flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
-            jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
+        res = os.path.join(OBJ, os.path.basename(s)[:-4] + ".resources.json")
+        if force or _newer(o, [s] + hdrs) or not os.path.exists(res):
+            jobs.append((s, compile_command(s, o)))
+    # objects of translation units that no longer exist must not be linked
+    for f in os.listdir(OBJ):
+        stem = f.split(".")[0]
+        if (f.endswith(".o") or f.endswith(".resources.json")) and \
+                not os.path.exists(os.path.join(CSRC, stem + ".hip")):
+            os.remove(os.path.join(OBJ, f))
 
-    def run(cmd):
+    def run(job):
+        src, cmd = job
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        rest = [ln for ln in p.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+        if rest and (verbose or p.returncode):
+            print("\n".join(rest), file=sys.stderr, flush=True)
+        if p.returncode:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        KR.store(os.path.basename(src), p.stderr)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs +
-            ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + \
+            ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    rows = KR.load_all()
+    if jobs:
+        prof = os.path.join(HERE, "..", "profiles")
+        if os.path.isdir(prof):
+            with open(os.path.join(prof, "kernel_resources.md"), "w") as fh:
+                fh.write("# Register / scratch / LDS use of every kernel in libcosmomap2_hip.so\n\n"
+                         "Written by `cosmomap2_amd/build.py` from hipcc's `-Rpass-analysis=kernel-resource-usage` "
+                         "remarks of the compile that produced the shipped objects (gfx950). The build fails "
+                         "when a kernel matching `kernel_resources.NO_SPILL` spills.\n\n")
+                fh.write(KR.table(KR.own_kernels(rows)) + "\n")
+    bad = KR.offenders(rows)
+    if bad:
+        msg = "default-path kernels spill registers: " + ", ".join(
+            "%s (%d VGPRs spilled, %d B/lane scratch)" % (r["kernel"], r.get("vgpr_spill", 0),
+                                                         r.get("scratch_bytes_per_lane", 0)) for r in bad)
+        if allow_spills if allow_spills is not None else os.environ.get("CM2_ALLOW_SPILLS"):
+            print("WARNING: " + msg, file=sys.stderr)
+        else:
+            raise RuntimeError(msg)
     return LIB
 
 

@@ -19,11 +19,12 @@
 //             and is evaluated in closed form H_k = (a0 + 2 sum_j a_j cos(2 pi j k/L))/L.
 // Algorithmic traffic 16 B/sample (read v, write y); the rocFFT route moves
 // ~7x that through HBM (pack, 2 FFTs, spectrum multiply, unpack) -- see DESIGN.md.
-#include "cm2_fft.h"
+#include "cm2_overlap_save.h"
 
 #include <rocfft/rocfft.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 using namespace cm2;
@@ -58,6 +59,7 @@ struct cm2_noise {
     int64_t ndirtiles = 0;
     bool auto_method = false;        // the caller left the choice to the library
     std::vector<int64_t> h_off;      // block offsets (host)
+    std::mutex mu;                   // lazy creation of `fused`
 };
 
 #define CM2_FFT(call)                                                                  \
@@ -409,7 +411,7 @@ extern "C" int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, d
     *h_bytes_per_sample = cm2::fused_os_tile_info(n->fused, kernel);
     h_info[0] = kernel[0];
     h_info[1] = kernel[1];
-    h_info[2] = kernel[0] == 64 ? 16384 : (kernel[0] ? 512 * (int64_t)kernel[0] : 12288);   // (64: k_os_wide)
+    h_info[2] = 512 * (int64_t)kernel[0];                 // window samples
     return 0;
 }
 
@@ -511,25 +513,48 @@ extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t);
 extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t);
 
+static int noise_tiles_ready(cm2_noise *n, const cm2_tiles *tiles, const char *who, void *stream_)
+{
+    if (!n->fused && n->auto_method && n->lambda > 0 && cm2::fused_os_supported(n->lambda)) {
+        // the method was left to the library and resolved to the direct sum (short band) for
+        // the time order; on a tile order the fused overlap-save kernel is the fast one
+        std::lock_guard<std::mutex> lock(n->mu);
+        if (!n->fused)
+            if (int rc = cm2::fused_os_create(&n->fused, n->d_t, n->lambda, n->h_off, as_stream(stream_)))
+                return rc;
+    }
+    CM2_CHECK(n->fused && (n->method == CM2_TOEPLITZ_FUSED || n->auto_method),
+              "%s needs a Toeplitz operator built with CM2_TOEPLITZ_FUSED or CM2_TOEPLITZ_AUTO", who);
+    CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
+              (long long)n->nt, (long long)cm2_tiles_nt(tiles));
+    return 0;
+}
+
+static cm2::OsPlanView plan_view(const cm2_tiles *tiles)
+{
+    cm2::OsPlanView pv;
+    pv.d_idx = cm2_tiles_index(tiles);
+    pv.d_tile_off = cm2_tiles_offsets(tiles);
+    pv.plan_id = cm2_tiles_plan_id(tiles);
+    pv.ntiles = cm2_tiles_ntiles(tiles);
+    pv.nvalid = cm2_tiles_nvalid(tiles);
+    return pv;
+}
+
+extern "C" int cm2_noise_prepare_tiles(cm2_noise *n, const cm2_tiles *tiles, void *stream_)
+{
+    CM2_CHECK(n && tiles, "cm2_noise_prepare_tiles: NULL argument");
+    if (int rc = noise_tiles_ready(n, tiles, "cm2_noise_prepare_tiles", stream_)) return rc;
+    return cm2::fused_os_prepare_indexed(n->fused, plan_view(tiles), as_stream(stream_));
+}
+
 extern "C" int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
                                      double *d_out_tb, void *stream_)
 {
     CM2_CHECK(n && tiles && d_in_tb && d_out_tb, "cm2_noise_apply_tiles: NULL argument");
     CM2_CHECK(d_in_tb != d_out_tb, "cm2_noise_apply_tiles: in-place application is not supported");
-    if (!n->fused && n->auto_method && n->lambda > 0 && cm2::fused_os_supported(n->lambda)) {
-        // the method was left to the library and resolved to the direct sum (short band) for
-        // the time order; on a tile order the fused overlap-save kernel is the fast one
-        if (int rc = cm2::fused_os_create(&n->fused, n->d_t, n->lambda, n->h_off, as_stream(stream_)))
-            return rc;
-    }
-    CM2_CHECK(n->fused && (n->method == CM2_TOEPLITZ_FUSED || n->auto_method),
-              "cm2_noise_apply_tiles needs a Toeplitz operator built with CM2_TOEPLITZ_FUSED "
-              "or CM2_TOEPLITZ_AUTO");
-    CM2_CHECK(cm2_tiles_nt(tiles) == n->nt, "noise operator has %lld samples, tile plan %lld",
-              (long long)n->nt, (long long)cm2_tiles_nt(tiles));
-    return cm2::fused_os_apply_indexed(n->fused, cm2_tiles_index(tiles), cm2_tiles_offsets(tiles),
-                                       cm2_tiles_plan_id(tiles), cm2_tiles_ntiles(tiles), cm2_tiles_nvalid(tiles),
-                                       d_in_tb, d_out_tb, as_stream(stream_));
+    if (int rc = noise_tiles_ready(n, tiles, "cm2_noise_apply_tiles", stream_)) return rc;
+    return cm2::fused_os_apply_indexed(n->fused, plan_view(tiles), d_in_tb, d_out_tb, as_stream(stream_));
 }
 
 // One call for the whole tile-order chain y = P^T N^-1 P x (SURVEY 8b's fused cm2_PtNP_apply):

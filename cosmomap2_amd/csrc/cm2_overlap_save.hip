@@ -1,40 +1,43 @@
-// cm2_fft_real.hip -- banded-Toeplitz N^-1 by overlap-save, ONE REAL WINDOW per workgroup.
+// cm2_overlap_save.hip -- banded-Toeplitz N^-1 by overlap-save, ONE REAL WINDOW per workgroup.
 //
 // Reference semantics: ToeplitzLO.mult, interfaces/linearoperators.py:582-595 (symmetric band,
 // ZERO boundary at both ends of every block), dispatched per block as interfaces/blkop.py:195-206.
 //
-// Where cm2_fft.hip packs two segments of a block as one complex signal A + iB of 8192 points
-// (224 VGPRs, 66 KB of LDS: two workgroups of one wave per SIMD each per CU, which behave as two
-// sequential machines -- DESIGN.md section 3), this kernel transforms one real window of
-// 2N samples as a complex signal of N points
+// One workgroup (256 threads x 32 complex points in registers, LDS only as the exchange buffer between
+// the radix-32 / 16 / 16 passes: 66 KB, two workgroups per CU) transforms one real window of 2N =
+// 16384 samples as a complex signal of N = 8192 points
 //
 //     z[a] = x[2a] + i x[2a+1],   Z = FFT_N(z),
 //     Z'[k] = alpha_k Z[k] + i beta_k conj(Z[N-k]),   z' = IFFT_N(Z') = y[2a] + i y[2a+1]
 //
 // with two real tables per noise block, alpha = (S - D sin(pi k/N)) / N, beta = D cos(pi k/N) / N,
 // S, D = (H[k] +- H[k+N]) / 2 and H the band's real, even spectrum on 2N points: no untangling pass;
-// the partner bin N-k lives in ONE other thread (k' = N-k is (263 - t, 31 - m) resp. (271 - t,
-// 15 - m) in the digit-reversed register layout), so the pairing costs one more plane exchange.
+// the partner bin N-k lives in ONE other thread (k' = N-k is (263 - t, 31 - m) in the digit-reversed
+// register layout), so the pairing costs one more plane exchange.  12288 outputs per window (halo
+// 2048 >= lambda - 1 on both sides: overlap 1.33).
 //
-//   PT = 16: N = 4096, window 8192 samples, 4096 outputs; 16 complex points per thread,
-//            <= 128 VGPRs and <= 40 KB of LDS -> FOUR workgroups (16 waves) per CU;
-//   PT = 32: N = 8192, window 16384 samples, 12288 outputs (overlap 1.33 instead of 1.5); the
-//            register budget of the pair kernel, two workgroups per CU.
-//
-// On the tile-bucketed order the window is reached through address-sorted lists (two half-window
-// lists, one or two result lists), in one of two formats:
-//   plain : a 4-byte address and a 2-byte position per entry;
+// On the tile-bucketed order the window is reached through address-sorted lists, in one of three
+// formats:
+//   plain : a 4-byte address and a 2-byte position per entry (plans with more than 2048 tiles);
 //   RC    : run-coded -- a window's samples in one pixel tile are consecutive addresses, so a list is
 //           a few hundred runs: per entry 2 bytes (position, bit 15 = "a run starts here"), per run
 //           one 4-byte word delta = address - slot, staged in LDS; entry s of run r has address
 //           delta[r] + s, r from a ballot and a population count.  2.0 + 4 / run length bytes per
-//           entry instead of 6.
+//           entry instead of 6.  Two window halves and two result rounds, each sorted by address;
+//   inverse : one address-sorted order per window (and per result window), cut by ADDRESS into rounds.
+// History (profiles/r03_*): the segment-pair kernel of rounds 1-2 (cm2_fft.hip,
+// A + iB packing: 0.89-0.95 ms at C4), a 16-point / four-workgroups-per-CU variant of this kernel
+// (1.00-1.06 ms) and a 512-thread x 16-point variant of the same window (1.28 ms) all lost to this one
+// (0.75-0.80 ms) and were removed in round 4.  The templates keep the points per thread as a parameter;
+// only PT = 32 is instantiated.
 // This translation unit is compiled with FMA contraction ON (results are compared with the direct
 // sum at 1e-12, not bit for bit).
-#include "cm2_fft.h"
+#include "cm2_overlap_save.h"
 
 #include <hipcub/hipcub.hpp>
 #include <cstring>
+#include <memory>
+#include <mutex>
 
 using namespace cm2;
 
@@ -53,51 +56,15 @@ __host__ __device__ constexpr int brev(int m)
     return out;
 }
 
-// Experiment switches (compile time; the defaults are what measured fastest, profiles/r03_os_*):
-//   CM2_OS_AB_BATCH32 : (alpha, beta) bins per batch of the 32-point variant; the first batch is
-//                       requested in front of the last forward pass when CM2_OS_AB_EARLY
-//   CM2_OS_LOAD2      : both window halves' gathers in flight together (two dependent round trips
-//                       instead of three, 2 x PT more live values)
-//   CM2_OS_RES_BOTH   : both result rounds' lists requested in front of the last exchange
-#ifndef CM2_OS_AB_BATCH32
-#define CM2_OS_AB_BATCH32 4
-#endif
-#ifndef CM2_OS_AB_EARLY
-#define CM2_OS_AB_EARLY 0
-#endif
-#ifndef CM2_OS_LOAD2
-#define CM2_OS_LOAD2 0
-#endif
-#ifndef CM2_OS_RES_BOTH
-#define CM2_OS_RES_BOTH 0
-#endif
-//   CM2_OS_INV_OVERLAP : inverse lists: the second round's gathers are issued behind the first
-//                       round's staging and fly while the first round is picked (instead of both
-//                       rounds' gathers up front)
-#ifndef CM2_OS_INV_OVERLAP
-#define CM2_OS_INV_OVERLAP 0
-#endif
-//   CM2_OS_SETPRIO     : wave priority (s_setprio 1..3) during the transform phases, 0 in the load and
-//                       result phases: the workgroup that computes wins the SIMD's issue slots over
-//                       the one that waits for memory; negative: the other way round (time-cut lists
-//                       only).  Measured: +5 % slower with 1 or 3 (profiles/r03_os_knob_builds.jsonl)
-#ifndef CM2_OS_SETPRIO
-#define CM2_OS_SETPRIO 0
-#endif
-//   CM2_OS_NT_STORE / CM2_OS_NT_LIST / CM2_OS_NT_GATHER : non-temporal result stores / list loads /
-//                       sample gathers
-#ifndef CM2_OS_NT_STORE
-#define CM2_OS_NT_STORE 0
-#endif
-#ifndef CM2_OS_NT_LIST
-#define CM2_OS_NT_LIST 1
-#endif
-#ifndef CM2_OS_NT_GATHER
-#define CM2_OS_NT_GATHER 0
-#endif
-template <class T> __device__ __forceinline__ T ld_list(const T *p) { return CM2_OS_NT_LIST ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ double ld_gather(const double *p) { return CM2_OS_NT_GATHER ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void st_result(double *p, double x) { if (CM2_OS_NT_STORE) __builtin_nontemporal_store(x, p); else *p = x; }
+// What was measured and dropped (each was a compile-time switch of this source until round 4; the
+// numbers are in profiles/r03_os_knob_builds.jsonl and DESIGN.md section 3.1): (alpha, beta) in
+// batches of 8 bins requested in front of the last forward pass, both window halves' gathers in
+// flight together, both result rounds' lists requested up front, the second inverse-list round's
+// gathers behind the first round's staging, wave priorities, non-temporal gathers and result stores.
+// Kept: non-temporal LIST loads (a list is read once).
+template <class T> __device__ __forceinline__ T ld_list(const T *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double ld_gather(const double *p) { return *p; }
+__device__ __forceinline__ void st_result(double *p, double x) { *p = x; }
 
 constexpr int kT = 256;           // threads per workgroup
 constexpr int kHalo = 2048;       // window halo on both sides (>= lambda - 1)
@@ -300,6 +267,32 @@ __device__ __forceinline__ void reg_inv(double (&xr)[PT], double (&xi)[PT], doub
 template <int E>
 __device__ __forceinline__ int slot_of(int t, int u) { return 64 * (E * (t >> 6) + u) + (t & 63); }
 
+// Where the 16-bit word of slot s of a list with E entries per thread is STORED: the words of a
+// thread's entries 4i .. 4i+3 share one 8-byte word, word (E/4 wave + i) 64 + lane of the list, so a
+// thread fetches its E words with E/4 coalesced 8-byte loads into E/2 registers (one 2-byte load and
+// one register per entry before round 4: the 24-32 list words held across the last transform pass
+// were what pushed the kernel over 256 VGPRs).  The plan-time kernels write through this map.
+__host__ __device__ inline int q_index(int s, int E)
+{
+    const int row = s >> 6, lane = s & 63, w = row / E, u = row % E;
+    return (((E / 4) * w + (u >> 2)) * 64 + lane) * 4 + (u & 3);
+}
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+// this thread's E list words, two per register
+template <int E>
+__device__ __forceinline__ void q_request(const uint16_t *q, int t, uint32_t (&qq)[E / 2])
+{
+    const v2u_t *p = reinterpret_cast<const v2u_t *>(q) + (E / 4) * 64 * (t >> 6) + (t & 63);
+#pragma unroll
+    for (int i = 0; i < E / 4; ++i) {
+        const v2u_t v = __builtin_nontemporal_load(p + 64 * i);
+        qq[2 * i] = v.x;
+        qq[2 * i + 1] = v.y;
+    }
+}
+template <int E2>
+__device__ __forceinline__ uint32_t q_word(const uint32_t (&qq)[E2], int u) { return (qq[u >> 1] >> (16 * (u & 1))) & 0xFFFFu; }
+
 struct ListArgs {
     const uint32_t *k;        // plain: addresses of this list
     const uint16_t *q;        // plain / RC: positions of this list
@@ -307,29 +300,30 @@ struct ListArgs {
     const uint32_t *tab;      // RC: run table of this list in global memory
 };
 
-// RC: request the run table of a list (at most TPT words per thread).  Callers pass the allocated
-// length of the table, not the list's run count: the request then does not wait for the header.
-template <int TPT>
-__device__ __forceinline__ void tab_request(const ListArgs &la, int t, uint32_t nruns, uint32_t (&tv)[TPT])
+// RC: the run table of a list (rmax words, a multiple of 64; the table is read up to its ALLOCATED
+// length, so the request does not wait for the list header) goes from global memory straight into
+// LDS (global_load_lds_dword: lane l of a wave writes word l behind the wave-uniform LDS base in M0):
+// no VGPR holds a table word.  The data is in LDS once the issuing wave's vmcnt has drained; the
+// __syncthreads() that publishes it to the other waves waits for that (the compiler puts
+// s_waitcnt vmcnt(0) in front of the barrier).
+// At most kTabRows requests per wave (rmax <= 256 kTabRows), unrolled behind wave-uniform tests: with a
+// loop of unknown length the compiler cannot count the requests in flight and every later wait for
+// an OLDER load becomes s_waitcnt vmcnt(0), i.e. a wait for the table and the list words as well.
+constexpr int kTabRows = 8;
+__device__ __forceinline__ void tab_dma(const uint32_t *gtab, uint32_t *tab_lds, int rmax, int wave, int t)
 {
+    const uint32_t *g = gtab + 64 * wave + (t & 63);
 #pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-        const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
-        tv[i] = la.tab[r < nruns ? r : 0u];
-    }
-}
-template <int TPT>
-__device__ __forceinline__ void tab_store(uint32_t *__restrict__ tab_lds, int t, int rmax,
-                                          const uint32_t (&tv)[TPT])
-{
-#pragma unroll
-    for (int i = 0; i < TPT; ++i)
-        if (t + i * kT < rmax) tab_lds[t + i * kT] = tv[i];
+    for (int i = 0; i < kTabRows; ++i)
+        if (64 * wave + kT * i < rmax)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + kT * i),
+                                             (__attribute__((address_space(3))) void *)(tab_lds + 64 * wave + kT * i),
+                                             4, 0, 0);
 }
 
 // RC: addresses of E entries from their 16-bit words (bit 15 = run start) and the run table in LDS
 template <int E>
-__device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_t *__restrict__ tab_lds,
+__device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E / 2], const uint32_t *__restrict__ tab_lds,
                                           int wbase, uint32_t nvalid, int t, uint32_t (&kk)[E])
 {
     int rb = wbase;
@@ -339,7 +333,7 @@ __device__ __forceinline__ void rc_decode(const uint32_t (&qq)[E], const uint32_
     asm volatile("" : "+v"(s0));
 #pragma unroll
     for (int u = 0; u < E; ++u) {
-        const bool flag = (qq[u] & 0x8000u) != 0u;
+        const bool flag = (qq[u >> 1] & (0x8000u << (16 * (u & 1)))) != 0u;
         const uint64_t mask = __ballot(flag);
         const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -397,19 +391,20 @@ __device__ __forceinline__ void idecode(uint32_t fw, const uint32_t *__restrict_
 // Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3; its
 // partner is published at P3 index A_e(t) - m of the padded plane (see the header comment).
 // (alpha, beta) reach the registers in batches of BA bins, one batch after the other (the table
-// loads are L2 hits that take a microsecond on a chip busy with gathers); with CM2_OS_AB_EARLY the
-// first batch is requested by the caller in front of the last forward pass.
-template <int PT> struct PairBatch { static constexpr int BA = PT == 32 ? CM2_OS_AB_BATCH32 : 4; };
+// loads are L2 hits that take a microsecond on a chip busy with gathers).
+template <int PT> struct PairBatch { static constexpr int BA = 4; };
 
 template <int PT, int BA>
 __device__ __forceinline__ void ab_request(const double2 *ab, int m0, double2 (&c)[BA])
 {
-    // the pointer passes through an empty asm statement: the loads have no other dependency and
-    // would otherwise all be hoisted to one place (4 VGPRs per bin)
-    const double2 *abp = ab + m0 * kT;
-    asm volatile("" : "+v"(abp));
+    // the OFFSET passes through an empty asm statement: the loads have no other dependency and
+    // would otherwise all be hoisted to one place (4 VGPRs per bin).  The pointer itself must keep its
+    // provenance: a laundered pointer is loaded from with FLAT instructions, and one pending flat load
+    // turns every later wait into s_waitcnt vmcnt(0) lgkmcnt(0) (flat loads may return out of order)
+    int o = m0 * kT;
+    asm volatile("" : "+v"(o));
 #pragma unroll
-    for (int i = 0; i < BA; ++i) c[i] = abp[i * kT];
+    for (int i = 0; i < BA; ++i) c[i] = ab[o + i * kT];
 }
 
 template <int PT, int BA>
@@ -445,7 +440,7 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
     __syncthreads();
 #pragma unroll
     for (int m0 = 0; m0 < PT; m0 += BA) {
-        if (m0 > 0 || !CM2_OS_AB_EARLY) ab_request<PT, BA>(ab, m0, c);
+        ab_request<PT, BA>(ab, m0, c);
 #pragma unroll
         for (int i0 = 0; i0 < BA; i0 += 4) {
             double pim[4];
@@ -470,15 +465,14 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
     __syncthreads();
 }
 
-// MODE 0: time order; 1: plain lists; 2: run-coded lists.  TPT: run-table words per thread (RC).
+// MODE 0: time order; 1: plain lists; 2: run-coded lists; 3: inverse lists.
 // BUF: the TOD buffers are addressed through buffer descriptors of `nbytes` bytes -- an entry
 // without a sample carries the address 0xFFFFFFFF, whose byte offset lies outside the descriptor:
 // such a load returns 0 and such a store is dropped by the hardware, so the gathers need no
 // address clamp and no zeroing select and the result stores no branch (48 exec-masked blocks in
 // the flat form).  Flat addressing is kept for buffers of 4 GB and more.
-typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 
-template <int PT, int MODE, int TPT, bool BUF>
+template <int PT, int MODE, bool BUF>
 __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const WinDesc *__restrict__ wins, int nwin, const double2 *__restrict__ Wtw,
     const double2 *Wtw_inv, const double2 *__restrict__ AB, const uint32_t *__restrict__ lst_k,
@@ -515,11 +509,8 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     if (win >= nwin) return;
     const WinDesc wd = wins[win];
     const int64_t w0 = wd.start - kHalo;            // time of window position 0
-    const int wave = t >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: an SGPR, the header words become scalar loads
     OS_STAMP(0);
-#if CM2_OS_SETPRIO < 0
-    __builtin_amdgcn_s_setprio(-(CM2_OS_SETPRIO));   // (negative: the load and result phases are the favoured ones)
-#endif
 
     auto list_args = [&](int l) {
         ListArgs la;
@@ -560,14 +551,9 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         // read up to its allocated length: no dependency on the run count).
         const IListHdr *__restrict__ h0 = ihdrs + (int64_t)win * 2;
         const uint32_t *__restrict__ pl = reinterpret_cast<const uint32_t *>(lst_q + (int64_t)win * G::PER);
-        uint32_t tv[TPT], fw[2], pp[PT];
+        uint32_t fw[2], pp[PT];
         {
-            const uint32_t *tg = tabs + ((int64_t)win * 2) * rmax;
-#pragma unroll
-            for (int i = 0; i < TPT; ++i) {
-                const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
-                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
-            }
+            tab_dma(tabs + ((int64_t)win * 2) * rmax, tab_lds, rmax, wave, t);
             fw[0] = iflags[((int64_t)win * 2) * 512 + t];
             fw[1] = iflags[((int64_t)win * 2) * 512 + 256 + t];
         }
@@ -575,54 +561,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         const int wb0 = h0->wbase[wave], wb1 = h0->wbase[4 + wave];
 #pragma unroll
         for (int m = 0; m < PT; ++m) pp[m] = pl[t + kT * m];
-        tab_store<TPT>(tab_lds, t, rmax, tv);
         __syncthreads();
-#if CM2_OS_INV_OVERLAP
-        // round 1's gathers are in flight while round 0 is picked
-        double va[PT], vb[PT];
-        {
-            uint32_t kk[PT];
-            idecode<PT>(fw[0], tab_lds, wb0, nv, 0u, t, kk);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) va[u] = keep(kk[u], gather(kk[u]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = va[u];
-        {
-            uint32_t kk[PT];
-            idecode<PT>(fw[1], tab_lds, wb1, nv, (uint32_t)N, t, kk);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) vb[u] = keep(kk[u], gather(kk[u]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1) {
-#pragma unroll
-                for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = vb[u];
-                const uint32_t *plj = pl;
-                asm volatile("" : "+v"(plj));
-#pragma unroll
-                for (int m = 0; m < PT; ++m) pp[m] = plj[t + kT * m];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < PT; ++m) {
-                const uint32_t lo = (pp[m] & 0xFFFFu) - (uint32_t)(j * N), hi = (pp[m] >> 16) - (uint32_t)(j * N);
-                const bool inl = lo < (uint32_t)N, inh = hi < (uint32_t)N;
-                const double x = buf[inl ? lo : 0u], y = buf[inh ? hi : 0u];
-                if (j == 0) {
-                    zr[m] = inl ? x : 0.0;
-                    zi[m] = inh ? y : 0.0;
-                } else {
-                    zr[m] = inl ? x : zr[m];
-                    zi[m] = inh ? y : zi[m];
-                }
-            }
-            __syncthreads();
-        }
-#else
         // both rounds' gathers are issued before anything is staged: 2 PT loads in flight per thread
         // while the transform's registers are not live yet
         double va[PT], vb[PT];
@@ -646,10 +585,10 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             for (int u = 0; u < PT; ++u) buf[slot_of<PT>(t, u)] = j ? vb[u] : va[u];
             if (j == 1) {
                 // the slot numbers again (L2): 32 registers not held across the first round's picks
-                const uint32_t *plj = pl;
-                asm volatile("" : "+v"(plj));
+                int tj = t;
+                asm volatile("" : "+v"(tj));
 #pragma unroll
-                for (int m = 0; m < PT; ++m) pp[m] = plj[t + kT * m];
+                for (int m = 0; m < PT; ++m) pp[m] = pl[tj + kT * m];
             }
             __syncthreads();
             // a point outside this round reads word 0 (one address for all such lanes: no bank conflict)
@@ -668,17 +607,9 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             }
             __syncthreads();
         }
-#endif
     } else {
-#if CM2_OS_LOAD2
-        // Both halves' lists are requested together and both halves' gathers are in flight
-        // together: two dependent round trips (lists, samples), not three.  After its gather is
-        // issued an address is dead; whether an entry has a sample is kept in bit 15 of its word
-        // (plain lists: set by the list builder; run-coded: slot >= number of valid entries).
         const ListArgs l0 = list_args(0), l1 = list_args(1);
-        uint32_t qa[PT], qb[PT];
-        double va[PT], vb[PT];
-        uint32_t ta[TPT], tb[TPT];
+        uint32_t qa[PT / 2], qb[PT / 2], ka[PT], kb[PT];
         uint32_t nva = 0, nvb = 0;
         int wba = -1, wbb = -1;
         if constexpr (MODE == 2) {
@@ -686,105 +617,20 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             nvb = l1.hdr->nvalid;
             wba = l0.hdr->wbase[wave];
             wbb = l1.hdr->wbase[wave];
-            tab_request<TPT>(l0, t, (uint32_t)rmax, ta);
-            tab_request<TPT>(l1, t, (uint32_t)rmax, tb);
+            tab_dma(l0.tab, tab_lds, rmax, wave, t);
+            tab_dma(l1.tab, tab_lds + rmax, rmax, wave, t);
         }
+        q_request<PT>(l0.q, t, qa);
+        if constexpr (MODE == 1) {
 #pragma unroll
-        for (int u = 0; u < PT; ++u) qa[u] = ld_list(l0.q + slot_of<PT>(t, u));
-#pragma unroll
-        for (int u = 0; u < PT; ++u) qb[u] = ld_list(l1.q + slot_of<PT>(t, u));
-        if constexpr (MODE == 2) {
-            tab_store<TPT>(tab_lds, t, rmax, ta);
-            tab_store<TPT>(tab_lds + rmax, t, rmax, tb);
-            __syncthreads();
+            for (int u = 0; u < PT; ++u) ka[u] = ld_list(l0.k + slot_of<PT>(t, u));
         }
-        {
-            uint32_t ka[PT];
-            if constexpr (MODE == 1) {
+        q_request<PT>(l1.q, t, qb);
+        if constexpr (MODE == 1) {
 #pragma unroll
-                for (int u = 0; u < PT; ++u) ka[u] = ld_list(l0.k + slot_of<PT>(t, u));
-            } else {
-                rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
-#pragma unroll
-                for (int u = 0; u < PT; ++u)
-                    qa[u] = (qa[u] & 0x7FFFu) | (ka[u] == kInvalidSample ? 0x8000u : 0u);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) va[u] = gather((qa[u] & 0x8000u) ? kInvalidSample : ka[u]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            uint32_t kb[PT];
-            if constexpr (MODE == 1) {
-#pragma unroll
-                for (int u = 0; u < PT; ++u) kb[u] = ld_list(l1.k + slot_of<PT>(t, u));
-            } else {
-                rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
-#pragma unroll
-                for (int u = 0; u < PT; ++u)
-                    qb[u] = (qb[u] & 0x7FFFu) | (kb[u] == kInvalidSample ? 0x8000u : 0u);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) vb[u] = gather((qb[u] & 0x8000u) ? kInvalidSample : kb[u]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = (qa[u] & 0x8000u) ? 0.0 : va[u];
-        __syncthreads();
-        {
-            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
-#pragma unroll
-            for (int m = 0; m < H; ++m) {
-                const double2 p = sp[256 * m];
-                zr[m] = p.x;
-                zi[m] = p.y;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = (qb[u] & 0x8000u) ? 0.0 : vb[u];
-        __syncthreads();
-        {
-            const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
-#pragma unroll
-            for (int m = 0; m < H; ++m) {
-                const double2 p = sp[256 * m];
-                zr[H + m] = p.x;
-                zi[H + m] = p.y;
-            }
-        }
-        __syncthreads();
-    }
-
-#else
-        const ListArgs l0 = list_args(0), l1 = list_args(1);
-        uint32_t qa[PT], qb[PT], ka[PT], kb[PT];
-        uint32_t ta[TPT], tb[TPT];
-        uint32_t nva = 0, nvb = 0;
-        int wba = -1, wbb = -1;
-        if constexpr (MODE == 2) {
-            nva = l0.hdr->nvalid;
-            nvb = l1.hdr->nvalid;
-            wba = l0.hdr->wbase[wave];
-            wbb = l1.hdr->wbase[wave];
-            tab_request<TPT>(l0, t, (uint32_t)rmax, ta);
-            tab_request<TPT>(l1, t, (uint32_t)rmax, tb);
-        }
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            qa[u] = ld_list(l0.q + slot_of<PT>(t, u));
-            if constexpr (MODE == 1) ka[u] = ld_list(l0.k + slot_of<PT>(t, u));
-        }
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            qb[u] = ld_list(l1.q + slot_of<PT>(t, u));
-            if constexpr (MODE == 1) kb[u] = ld_list(l1.k + slot_of<PT>(t, u));
+            for (int u = 0; u < PT; ++u) kb[u] = ld_list(l1.k + slot_of<PT>(t, u));
         }
         if constexpr (MODE == 2) {
-            tab_store<TPT>(tab_lds, t, rmax, ta);
-            tab_store<TPT>(tab_lds + rmax, t, rmax, tb);
             __syncthreads();
             rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
         }
@@ -794,7 +640,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         for (int u = 0; u < PT; ++u) vv[u] = gather(ka[u]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qa[u] & 0x7FFFu] = keep(ka[u], vv[u]);
+        for (int u = 0; u < PT; ++u) buf[q_word(qa, u) & 0x7FFFu] = keep(ka[u], vv[u]);
         if constexpr (MODE == 2) rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -811,7 +657,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < PT; ++u) buf[qb[u] & 0x7FFFu] = keep(kb[u], vv[u]);
+        for (int u = 0; u < PT; ++u) buf[q_word(qb, u) & 0x7FFFu] = keep(kb[u], vv[u]);
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
@@ -825,13 +671,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         __syncthreads();
     }
 
-#endif
     OS_STAMP(1);
-#if CM2_OS_SETPRIO > 0
-    __builtin_amdgcn_s_setprio(CM2_OS_SETPRIO);      // transform phases win the issue slots of the SIMD
-#elif CM2_OS_SETPRIO < 0
-    __builtin_amdgcn_s_setprio(0);
-#endif
     const double2 w_a = Wtw[t];                      // n = N:   exp(-2 pi i t / N)
     const double2 w_b = Wtw[PT * (t & 15)];          // n = 256: exp(-2 pi i (t & 15) / 256)
 
@@ -846,7 +686,6 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     constexpr int BA = PairBatch<PT>::BA;
     const double2 *ab = AB + (int64_t)wd.blk * N + t;
     double2 cab[BA];
-    if (CM2_OS_AB_EARLY) ab_request<PT, BA>(ab, 0, cab);
     dft_sub<PT, 16, 0>(zr, zi);
     if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi);
     OS_STAMP(2);
@@ -861,34 +700,43 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const double2 w_bi = Wtw_inv[PT * (t & 15)], w_ai = Wtw_inv[t];
     reg_exchange<PT, 3, 2, 0>(zr, buf, t);
     reg_exchange<PT, 3, 2, 0>(zi, buf, t);
-    reg_inv<PT, 16, 0>(zr, zi, w_bi);
-    if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
+    // The result lists of round 0 are requested HERE, in front of the middle inverse pass: a run table
+    // travels by LDS-DMA, and while one is in flight every workgroup barrier waits for it (s_waitcnt
+    // vmcnt(0) in front of s_barrier) -- so the request is issued right behind a barrier, with the
+    // longest barrier-free stretch of arithmetic (the two radix-16 blocks) to hide behind; the 16-bit
+    // words are in registers by the end of the last pass.  Both twiddles are made to arrive first
+    // (requested two exchanges ago): a wait for a load OLDER than the table requests would be emitted as
+    // s_waitcnt vmcnt(0) too -- the compiler does not count LDS-DMA requests behind wave-uniform
+    // branches -- and would wait for the lists as well.
+    asm volatile("" : : "v"(w_bi.x), "v"(w_bi.y), "v"(w_ai.x), "v"(w_ai.y));
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (MODE == 3) {
         // ---- inverse result list: rounds of RLEN slots of the result window's address-sorted order ----
         constexpr int ER3 = G::RLEN / kT, NP = PT - 8;   // slots per thread and round; points with results
-        const IListHdr *h1 = ihdrs + (int64_t)win * 2 + 1;
-        const uint32_t *tg = tabs + ((int64_t)win * 2 + 1) * rmax;
-        const uint32_t *fg = iflags + ((int64_t)win * 2 + 1) * 512 + t;
-        asm volatile("" : "+v"(h1), "+v"(tg), "+v"(fg));
+        // (the list number passes through an empty asm statement -- an offset, not a pointer, see
+        // ab_request: the requests below have no other dependency and would be hoisted to the top)
+        int l1 = 1;
+        asm volatile("" : "+s"(l1));
+        const IListHdr *h1 = ihdrs + (int64_t)win * 2 + l1;
+        const uint32_t *tg = tabs + ((int64_t)win * 2 + l1) * rmax;
+        const uint32_t *fg = iflags + ((int64_t)win * 2 + l1) * 512 + t;
         const uint32_t nv1 = h1->nvalid;
-        uint32_t tv[TPT], fr[G::RR], rp[NP];
+        uint32_t fr[G::RR], rp[NP];
         const uint32_t *rl = reinterpret_cast<const uint32_t *>(lst_q + (int64_t)win * G::PER + 2 * N);
         {
-#pragma unroll
-            for (int i = 0; i < TPT; ++i) {
-                const uint32_t r = (uint32_t)t + (uint32_t)i * kT;
-                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
-            }
+            tab_dma(tg, tab_lds + rmax, rmax, wave, t);        // published by the barriers of the next exchange
 #pragma unroll
             for (int j = 0; j < G::RR; ++j) fr[j] = fg[256 * j];
             // the slot numbers of this thread's results, in registers by the end of the last pass
-            const uint32_t *rl0 = rl;
-            asm volatile("" : "+v"(rl0));
+            int t0 = t;
+            asm volatile("" : "+v"(t0));
 #pragma unroll
-            for (int m = 0; m < NP; ++m) rp[m] = rl0[t + kT * m];
+            for (int m = 0; m < NP; ++m) rp[m] = rl[t0 + kT * m];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        reg_inv<PT, 16, 0>(zr, zi, w_bi);
+        if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
         reg_exchange<PT, 2, 1, 16>(zr, buf, t);
-        tab_store<TPT>(tab_lds + rmax, t, rmax, tv);     // published by the barriers of the next exchange
         reg_exchange<PT, 2, 1, 16>(zi, buf, t);
         reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
         OS_STAMP(4);
@@ -896,10 +744,10 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         for (int j = 0; j < G::RR; ++j) {
             if (j > 0) {
                 __syncthreads();                         // the previous round's reads are done
-                const uint32_t *rlj = rl;                // (the slot numbers again, from L2)
-                asm volatile("" : "+v"(rlj));
+                int tj = t;                              // (the slot numbers again, from L2)
+                asm volatile("" : "+v"(tj));
 #pragma unroll
-                for (int m = 0; m < NP; ++m) rp[m] = rlj[t + kT * m];
+                for (int m = 0; m < NP; ++m) rp[m] = rl[tj + kT * m];
             }
             // y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4): each value to its slot of this
             // round, the others to a spare word behind the stage (no branch)
@@ -925,70 +773,42 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             }
         }
     } else {
-    // The result list of round 0 is requested here, behind the middle inverse pass: its run table
-    // goes to LDS in front of the last exchange (whose barriers publish it), its 16-bit words are
-    // in registers by the end of the last pass.  The pointers pass through an empty asm statement:
-    // the loads have no other dependency and would otherwise be hoisted to the top of the kernel
-    // and spilled.
     constexpr int ER = G::RLEN / kT;                 // result entries per thread and round
-    constexpr bool kBoth = CM2_OS_RES_BOTH && G::RR == 2 && MODE != 0;   // round 1 requested with round 0
-    uint32_t qs[ER], ks[ER], qs1[kBoth ? ER : 1], ks1[kBoth ? ER : 1];
-    uint32_t ts_[TPT], ts1[TPT];
-    uint32_t nvs = 0, nvs1 = 0;
-    int wbs = -1, wbs1 = -1;
-    auto request_results = [&](int j, auto &qq, auto &kq, uint32_t (&tq)[TPT], uint32_t &nv, int &wb) {
+    uint32_t qs[ER / 2], ks[ER];
+    uint32_t nvs = 0;
+    int wbs = -1;
+    auto request_results = [&](int j, auto &qq, auto &kq, uint32_t &nv, int &wb) {
         if constexpr (MODE != 0) {
-            ListArgs ls = list_args(2 + j);
-            asm volatile("" : "+v"(ls.q), "+v"(ls.k), "+v"(ls.hdr), "+v"(ls.tab));
+            // (the list number passes through an empty asm statement: an offset, not a pointer, see
+            // ab_request; the list's addresses stay wave-uniform and its header words scalar loads)
+            int lj = 2 + j;
+            asm volatile("" : "+s"(lj));
+            const ListArgs ls = list_args(lj);
             if constexpr (MODE == 2) {
                 nv = ls.hdr->nvalid;
                 wb = ls.hdr->wbase[wave];
-                tab_request<TPT>(ls, t, (uint32_t)rmax, tq);
+                tab_dma(ls.tab, tab_lds, rmax, wave, t);
             }
-#pragma unroll
-            for (int u = 0; u < ER; ++u) {
-                qq[u] = ld_list(ls.q + slot_of<ER>(t, u));
-                if constexpr (MODE == 1) kq[u] = ld_list(ls.k + slot_of<ER>(t, u));
-            }
+            q_request<ER>(ls.q, t, qq);
+            (void)kq;         // (plain lists: the addresses are fetched behind the last pass, see below)
         }
     };
-    request_results(0, qs, ks, ts_, nvs, wbs);
-    if constexpr (kBoth) request_results(1, qs1, ks1, ts1, nvs1, wbs1);
+    request_results(0, qs, ks, nvs, wbs);          // (its run table: published by the barriers of the next exchange)
+    __builtin_amdgcn_sched_barrier(0);
+    reg_inv<PT, 16, 0>(zr, zi, w_bi);
+    if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
     reg_exchange<PT, 2, 1, 16>(zr, buf, t);
-    if constexpr (MODE == 2) {
-        tab_store<TPT>(tab_lds, t, rmax, ts_);
-        if constexpr (kBoth) tab_store<TPT>(tab_lds + rmax, t, rmax, ts1);
-    }
     reg_exchange<PT, 2, 1, 16>(zi, buf, t);
     reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
     // ---- store: y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4), RSLOTS slots a round --
     OS_STAMP(4);
-#if CM2_OS_SETPRIO > 0
-    __builtin_amdgcn_s_setprio(0);
-#elif CM2_OS_SETPRIO < 0
-    __builtin_amdgcn_s_setprio(-(CM2_OS_SETPRIO));
-#endif
 #pragma unroll
     for (int j = 0; j < G::RR; ++j) {
         const uint32_t *tabj = tab_lds;
         if (j > 0) {
             __syncthreads();                         // the previous round's reads are done
-            if constexpr (kBoth) {
-#pragma unroll
-                for (int u = 0; u < ER; ++u) {
-                    qs[u] = qs1[u];
-                    if constexpr (MODE == 1) ks[u] = ks1[u];
-                }
-                nvs = nvs1;
-                wbs = wbs1;
-                tabj = tab_lds + rmax;
-            } else {
-                request_results(j, qs, ks, ts_, nvs, wbs);
-                if constexpr (MODE == 2) {
-                    tab_store<TPT>(tab_lds, t, rmax, ts_);
-                    __syncthreads();
-                }
-            }
+            request_results(j, qs, ks, nvs, wbs);
+            if constexpr (MODE == 2) __syncthreads();
         }
         if constexpr (MODE == 2) rc_decode<ER>(qs, tabj, wbs, nvs, t, ks);
         double2 *__restrict__ sp = reinterpret_cast<double2 *>(buf) + t;
@@ -996,6 +816,13 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         for (int mm = 0; mm < G::RSLOTS; ++mm) {
             const int m = 4 + j * G::RSLOTS + mm;
             sp[256 * mm] = make_double2(zr[brev<PT>(m)], zi[brev<PT>(m)]);
+        }
+        if constexpr (MODE == 1) {
+            // plain lists: 24 address words held across the radix-32 pass do not fit beside its 128 data
+            // registers (20 spilled VGPRs in the flat form); they are requested here instead
+            const ListArgs ls = list_args(2 + j);
+#pragma unroll
+            for (int u = 0; u < ER; ++u) ks[u] = ld_list(ls.k + slot_of<ER>(t, u));
         }
         __syncthreads();
         if constexpr (MODE == 0) {
@@ -1008,7 +835,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         } else {
             double rv[ER];
 #pragma unroll
-            for (int u = 0; u < ER; ++u) rv[u] = buf[qs[u] & 0x7FFFu];
+            for (int u = 0; u < ER; ++u) rv[u] = buf[q_word(qs, u) & 0x7FFFu];
 #pragma unroll
             for (int u = 0; u < ER; ++u) {
                 if constexpr (BUF) {
@@ -1021,291 +848,6 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     }
     }
     OS_STAMP(5);
-}
-
-// ---- the same window on 512 threads (k_os_wide) ---------------------------------------------------
-// k_os_real<32> keeps 32 complex points a thread in registers: 256 VGPRs, one wave per SIMD and
-// workgroup, two in all -- every phase follows its own latency.  Here the 16384-sample window (the
-// same N = 8192 complex points, the same windows, lists and bytes) is held by 512 threads x 16 points
-// (<= 128 VGPRs: four waves per SIMD with two workgroups per CU) as a radix-2 decimation in time on
-// top of the 16-point kernel's passes: threads 0..255 ("group 0") transform the even complex points
-// z[2b], threads 256..511 the odd ones z[2b + 1], each with the 4096-point register FFT (radix
-// 16 x 16 x 16, its own half of the LDS buffer); then  Z[k'] = E[k'] + W^k' O[k'],  Z[k' + 4096] =
-// E[k'] - W^k' O[k'],  W = exp(-2 pi i / 8192): one more exchange per plane, group 0 ends with the
-// bins below 4096, group 1 with those above, both at the slot of k'.  The partner of bin k, N - k, is
-// the slot of 4096 - k' in the OTHER group (k' = 0: the bin itself), i.e. the 16-point kernel's partner
-// map read from the other half of the buffer.  The inverse mirrors it:  E' = Z'[k'] + Z'[k' + 4096],
-// O' = (Z'[k'] - Z'[k' + 4096]) conj(W^k').  Inverse lists only (mode 3); point a = 2 (t + 256 m) + g.
-constexpr int kTW = 512;
-#ifndef CM2_OS_WIDE_WAVES
-#define CM2_OS_WIDE_WAVES 2             // waves per SIMD the register allocation aims at (2: 180 VGPRs, one workgroup per CU; 4: 128 + 57 spilled)
-#endif
-
-template <int TPT, bool BUF>
-__global__ __launch_bounds__(kTW, CM2_OS_WIDE_WAVES) void k_os_wide(
-    const WinDesc *__restrict__ wins, int nwin, const double2 *__restrict__ W8, const double2 *W8_inv,
-    const double2 *__restrict__ ABw, const uint16_t *__restrict__ plist,
-    const IListHdr *__restrict__ ihdrs, const uint32_t *__restrict__ iflags,
-    const uint32_t *__restrict__ tabs, int rmax, const double *__restrict__ v, double *__restrict__ out,
-    uint32_t nbytes)
-{
-    using G = Geo<32>;                                   // windows, lists: those of the 32-point kernel
-    constexpr int N = G::N, N4 = N / 2, PT = 16, L16 = Geo<16>::LDSD;
-    __amdgpu_buffer_rsrc_t v_rs, o_rs;
-    if constexpr (BUF) {
-        v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(v), 0, (int)nbytes, 0x00020000);
-        o_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)nbytes, 0x00020000);
-    }
-    auto gather = [&](uint32_t k) -> double {
-        if constexpr (BUF) {
-            const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(v_rs, k * 8u, 0, 0);
-            return __builtin_bit_cast(double, r);
-        } else {
-            const double x = ld_gather(v + (k != kInvalidSample ? k : 0u));
-            return k != kInvalidSample ? x : 0.0;
-        }
-    };
-    extern __shared__ double buf[];                      // two halves of L16 doubles, then the run tables
-    uint32_t *__restrict__ tab_lds = reinterpret_cast<uint32_t *>(buf + 2 * L16);
-    const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, wave = tid >> 6;
-    double *__restrict__ bufg = buf + g * L16;
-    const double *__restrict__ bufo = buf + (1 - g) * L16;
-    const int per_xcd = (nwin + 7) / 8;
-    const int win = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (win >= nwin) return;
-    const WinDesc wd = wins[win];
-
-    double zr[PT], zi[PT];
-    // ---- load: two rounds of N slots of the window's address-sorted order ----
-    {
-        const IListHdr *__restrict__ h0 = ihdrs + (int64_t)win * 2;
-        const uint32_t *__restrict__ pl = reinterpret_cast<const uint32_t *>(plist + (int64_t)win * G::PER) + g;
-        uint32_t tv[TPT], fw[2], pp[PT];
-        {
-            const uint32_t *tg = tabs + ((int64_t)win * 2) * rmax;
-#pragma unroll
-            for (int i = 0; i < TPT; ++i) {
-                const uint32_t r = (uint32_t)tid + (uint32_t)i * kTW;
-                tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
-            }
-            fw[0] = iflags[((int64_t)win * 2) * (2 * kTW) + tid];
-            fw[1] = iflags[((int64_t)win * 2) * (2 * kTW) + kTW + tid];
-        }
-        const uint32_t nv = h0->nvalid;
-        const int wb0 = h0->wbase[wave], wb1 = h0->wbase[8 + wave];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) pp[m] = pl[2 * (t + 256 * m)];
-#pragma unroll
-        for (int i = 0; i < TPT; ++i)
-            if (tid + i * kTW < rmax) tab_lds[tid + i * kTW] = tv[i];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            {
-                uint32_t kk[PT];
-                idecode<PT>(fw[j], tab_lds, j ? wb1 : wb0, nv, (uint32_t)(j * N), tid, kk);
-                double vv[PT];
-#pragma unroll
-                for (int u = 0; u < PT; ++u) vv[u] = gather(kk[u]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < PT; ++u) buf[slot_of<PT>(tid, u)] = vv[u];
-            }
-            if (j == 1) {
-                const uint32_t *plj = pl;
-                asm volatile("" : "+v"(plj));
-#pragma unroll
-                for (int m = 0; m < PT; ++m) pp[m] = plj[2 * (t + 256 * m)];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < PT; ++m) {
-                const uint32_t lo = (pp[m] & 0xFFFFu) - (uint32_t)(j * N), hi = (pp[m] >> 16) - (uint32_t)(j * N);
-                const bool inl = lo < (uint32_t)N, inh = hi < (uint32_t)N;
-                const double x = buf[inl ? lo : 0u], y = buf[inh ? hi : 0u];
-                if (j == 0) {
-                    zr[m] = inl ? x : 0.0;
-                    zi[m] = inh ? y : 0.0;
-                } else {
-                    zr[m] = inl ? x : zr[m];
-                    zi[m] = inh ? y : zi[m];
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // ---- forward: each group's 4096-point transform (radix 16, 16, 16) ----
-    const double2 w_a = W8[2 * t];                       // exp(-2 pi i t / 4096)
-    const double2 w_b = W8[32 * (t & 15)];               // exp(-2 pi i (t & 15) / 256)
-    reg_fwd<PT, 16, 0>(zr, zi, w_a);
-    reg_exchange<PT, 1, 2, 16>(zr, bufg, t);
-    reg_exchange<PT, 1, 2, 16>(zi, bufg, t);
-    reg_fwd<PT, 16, 0>(zr, zi, w_b);
-    reg_exchange<PT, 2, 3, 16>(zr, bufg, t);
-    reg_exchange<PT, 2, 3, 16>(zi, bufg, t);
-    dft_sub<PT, 16, 0>(zr, zi);
-    // register s = brev16(d3) of thread t now holds bin k' = (t >> 4) + 16 (t & 15) + 256 d3 of the group
-    const int kbase = (t >> 4) + 16 * (t & 15);
-    double *__restrict__ wq = bufg + reg_base<PT, 3>(t);
-    const double *__restrict__ rq = bufo + reg_base<PT, 3>(t);
-    // ---- combine: group 1 multiplies by W^k', then Z = E + W O (group 0), E - W O (group 1) ----
-    if (g == 1) {
-#pragma unroll
-        for (int d3 = 0; d3 < PT; ++d3) {
-            const int sl = brev<16>(d3);
-            const double2 w = W8[kbase + 256 * d3];
-            const double tr = zr[sl] * w.x - zi[sl] * w.y;
-            zi[sl] = zr[sl] * w.y + zi[sl] * w.x;
-            zr[sl] = tr;
-        }
-    }
-    {
-        double p[PT];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zr[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) p[m] = rq[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) zr[m] = g ? p[m] - zr[m] : zr[m] + p[m];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zi[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) p[m] = rq[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) zi[m] = g ? p[m] - zi[m] : zi[m] + p[m];
-    }
-    // ---- pairing with bin N - k (the other group's slot of 4096 - k') and the spectrum product ----
-    {
-        const int tp = t >= 16 ? 271 - t : 16 - t;
-        const int A0 = t == 0 ? 16 : 16 * tp + (tp >> 1) + 15;
-        const double *__restrict__ r0 = bufo + A0;
-        const bool self0 = (t == 0);
-        const double2 *ab = ABw + (int64_t)wd.blk * N + g * N4 + t;
-        double pr[PT];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zr[reg_slot<16>(m)];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) pr[m] = (m == 0 && self0) ? bufg[0] : r0[-m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zi[reg_slot<16>(m)];
-        __syncthreads();
-#pragma unroll
-        for (int m0 = 0; m0 < PT; m0 += 4) {
-            double2 c[4];
-            const double2 *abp = ab + m0 * 256;
-            asm volatile("" : "+v"(abp));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c[i] = abp[i * 256];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i, sl = reg_slot<16>(m);
-                const double pim = (m == 0 && self0) ? bufg[0] : r0[-m];
-                const double nr = c[i].x * zr[sl] + c[i].y * pim;
-                const double ni = c[i].x * zi[sl] + c[i].y * pr[m];
-                zr[sl] = nr;
-                zi[sl] = ni;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-    // ---- inverse combine: E' = Z'[k'] + Z'[k' + 4096] (group 0), O' = (Z'[k'] - Z'[k' + 4096]) conj(W^k') ----
-    {
-        double p[PT];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zr[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) p[m] = rq[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) zr[m] = g ? p[m] - zr[m] : zr[m] + p[m];
-#pragma unroll
-        for (int m = 0; m < PT; ++m) wq[m] = zi[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) p[m] = rq[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < PT; ++m) zi[m] = g ? p[m] - zi[m] : zi[m] + p[m];
-    }
-    if (g == 1) {
-#pragma unroll
-        for (int d3 = 0; d3 < PT; ++d3) {
-            const int sl = brev<16>(d3);
-            const double2 w = W8_inv[kbase + 256 * d3];
-            const double tr = zr[sl] * w.x + zi[sl] * w.y;
-            zi[sl] = zi[sl] * w.x - zr[sl] * w.y;
-            zr[sl] = tr;
-        }
-    }
-    // ---- inverse: each group's 4096-point transform ----
-    dit_sub<PT, 16, 0>(zi, zr);
-    const double2 w_bi = W8_inv[32 * (t & 15)], w_ai = W8_inv[2 * t];
-    reg_exchange<PT, 3, 2, 0>(zr, bufg, t);
-    reg_exchange<PT, 3, 2, 0>(zi, bufg, t);
-    reg_inv<PT, 16, 0>(zr, zi, w_bi);
-    // ---- results: the result window's slots in two rounds of RLEN ----
-    constexpr int ER = G::RLEN / kTW, NP = PT - 4;       // slots per thread and round; points with results
-    const IListHdr *h1 = ihdrs + (int64_t)win * 2 + 1;
-    const uint32_t *tg = tabs + ((int64_t)win * 2 + 1) * rmax;
-    const uint32_t *fg = iflags + ((int64_t)win * 2 + 1) * (2 * kTW) + tid;
-    asm volatile("" : "+v"(h1), "+v"(tg), "+v"(fg));
-    const uint32_t nv1 = h1->nvalid;
-    uint32_t tv[TPT], fr[2];
-    const uint32_t *rl = reinterpret_cast<const uint32_t *>(plist + (int64_t)win * G::PER + 2 * N) + g;
-    {
-#pragma unroll
-        for (int i = 0; i < TPT; ++i) {
-            const uint32_t r = (uint32_t)tid + (uint32_t)i * kTW;
-            tv[i] = tg[r < (uint32_t)rmax ? r : 0u];
-        }
-        fr[0] = fg[0];
-        fr[1] = fg[kTW];
-    }
-    reg_exchange<PT, 2, 1, 16>(zr, bufg, t);
-#pragma unroll
-    for (int i = 0; i < TPT; ++i)
-        if (tid + i * kTW < rmax) tab_lds[rmax + tid + i * kTW] = tv[i];   // published by the next barriers
-    reg_exchange<PT, 2, 1, 16>(zi, bufg, t);
-    reg_inv<PT, PT, 0>(zr, zi, w_ai);                    // point b = t + 256 m at index brev<16>(m)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j > 0) __syncthreads();
-        const uint32_t *rlj = rl;
-        asm volatile("" : "+v"(rlj));
-        uint32_t rp[NP];
-#pragma unroll
-        for (int m = 0; m < NP; ++m) rp[m] = rlj[2 * (t + 256 * m)];
-        // point a = 2 (t + 256 m) + g holds window samples 2a, 2a + 1; results are the points with
-        // m in [2, 14): result position 2 (a - 1024) + {0, 1}
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-            const uint32_t lo = (rp[m] & 0xFFFFu) - (uint32_t)(j * G::RLEN), hi = (rp[m] >> 16) - (uint32_t)(j * G::RLEN);
-            buf[lo < (uint32_t)G::RLEN ? lo : (uint32_t)N] = zr[brev<16>(m + 2)];
-            buf[hi < (uint32_t)G::RLEN ? hi : (uint32_t)N + 1u] = zi[brev<16>(m + 2)];
-        }
-        __syncthreads();
-        uint32_t ks[ER];
-        idecode<ER>(fr[j], tab_lds + rmax, h1->wbase[8 * j + wave], nv1, (uint32_t)(j * G::RLEN), tid, ks);
-        double rv[ER];
-#pragma unroll
-        for (int u = 0; u < ER; ++u) rv[u] = buf[slot_of<ER>(tid, u)];
-#pragma unroll
-        for (int u = 0; u < ER; ++u) {
-            if constexpr (BUF) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, rv[u]), o_rs, ks[u] * 8u, 0, 0);
-            } else {
-                if (ks[u] != kInvalidSample) st_result(out + ks[u], rv[u]);
-            }
-        }
-    }
 }
 
 // ---- plan-time kernels ----------------------------------------------------------------------------
@@ -1410,6 +952,25 @@ __global__ __launch_bounds__(256) void k_real_rc(int64_t nlists, const uint32_t 
         hdrs[lid].nruns = (uint32_t)runs;
         atomicMax(max_runs, (uint32_t)runs);
     }
+}
+
+// the 16-bit words of every list from slot order (what the segmented sort and k_real_rc leave) to
+// the stored order q_index: one workgroup per list, through LDS
+template <int PT>
+__global__ __launch_bounds__(256) void k_real_qperm(int64_t nlists, uint16_t *__restrict__ lq)
+{
+    using G = Geo<PT>;
+    __shared__ uint16_t stage[G::N];
+    const int64_t lid = blockIdx.x;
+    if (lid >= nlists) return;
+    const int l = (int)(lid % G::NLIST);
+    const int64_t e0 = (lid / G::NLIST) * G::PER + G::list_off(l);
+    const int len = G::list_len(l), E = len / 256;
+    for (int s = threadIdx.x; s < len; s += 256) stage[q_index(s, E)] = lq[e0 + s];
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lq + e0);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(stage);
+    for (int i = threadIdx.x; i < len / 2; i += 256) dst[i] = src[i];
 }
 
 // ---- the lists without a sort ------------------------------------------------------------------
@@ -1551,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_real_lists(const WinDesc *__restrict__ 
                 slot = inv_before + (int)((inv_rank[i / 2] >> (16 * (i & 1))) & 0xFFFFu);
                 if (!RC) word |= 0x8000u;
             }
-            stage[slot] = word;
+            stage[q_index(slot, len / 256)] = word;
             if (!RC) lk[e0 + slot] = a[i];
         }
     }
@@ -1775,87 +1336,83 @@ __global__ __launch_bounds__(256) void k_real_alpha_beta(int nb, const double *_
 }
 
 
-// the same tables for k_os_wide: N = 8192 bins, bin k = k' + 4096 g with k' = (t >> 4) + 16 (t & 15) +
-// 256 m at [block][g][m][t]
-__global__ __launch_bounds__(256) void k_real_alpha_beta_wide(int nb, const double *__restrict__ Hs,
-                                                               double2 *__restrict__ AB)
-{
-    constexpr int N = Geo<32>::N;
-    const int64_t total = (int64_t)nb * N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t b = e / N;
-        const int a = (int)(e - b * N);
-        const int g = a / 4096, m = (a / 256) % 16, t = a % 256;
-        const int k = (t >> 4) + 16 * (t & 15) + 256 * m + 4096 * g;
-        const double *h = Hs + b * (N + 1);
-        const double hk = h[k], hp = h[N - k];
-        const double S = 0.5 * (hk + hp), Dd = 0.5 * (hk - hp);
-        const double th = (double)k / (double)N;
-        AB[e] = make_double2((S - Dd * sinpi(th)) / (double)N, (Dd * cospi(th)) / (double)N);
-    }
-}
-
 }  // namespace
 
 namespace cm2 {
 
-struct RealOS {
-    int pt = 16;
+constexpr int kPT = 32;                  // complex points per thread of the kernel that ships
+using G32 = Geo<kPT>;
+constexpr size_t kListCache = 3;         // tile plans whose lists one operator keeps (most recent first)
+
+// Address lists of one (noise operator, tile plan) pair.  Owned by a shared_ptr: an application
+// holds a reference while it launches, so a concurrent eviction cannot free lists that a launch is
+// about to use (dev_free waits for the device before a block can be handed out again).
+struct OsLists {
+    uint64_t plan_id = 0;
+    int mode = 0;                        // 1 plain, 2 run-coded (cut by time), 3 inverse (cut by address)
+    uint32_t *d_lst_k = nullptr;         // mode 1: addresses
+    uint16_t *d_lst_q = nullptr;         // modes 1, 2: position of every slot; mode 3: slot of every position
+    ListHdr *d_hdrs = nullptr;           // mode 2
+    uint32_t *d_tabs = nullptr;          // modes 2, 3: run tables
+    IListHdr *d_ihdrs = nullptr;         // mode 3
+    uint32_t *d_iflags = nullptr;        // mode 3: run-start bits, [list][round][thread]
+    int rmax = 0;
+    double bytes_per_window = 0.0;
+    ~OsLists()
+    {
+        void *ptrs[] = {d_lst_k, d_lst_q, d_hdrs, d_tabs, d_ihdrs, d_iflags};
+        for (void *q : ptrs)
+            if (q) (void)cm2::dev_free(q);
+    }
+};
+
+struct FusedOS {
     int64_t nwin = 0;
     int64_t nb = 0;
     WinDesc *d_wins = nullptr;
     double2 *d_AB = nullptr;
     double2 *d_W = nullptr;
-    // lists of the tile-order path, built for one tile plan at a time
-    uint64_t list_plan = 0;
-    int list_mode = 0;                   // 1 plain, 2 run-coded, 3 inverse (run-coded, rounds cut by address)
-    uint32_t *d_lst_k = nullptr;
-    uint16_t *d_lst_q = nullptr;         // modes 1, 2: position of every slot; mode 3: slot of every position
-    ListHdr *d_hdrs = nullptr;
-    uint32_t *d_tabs = nullptr;
-    IListHdr *d_ihdrs = nullptr;         // mode 3
-    uint32_t *d_iflags = nullptr;        // mode 3: run-start bits, [list][round][thread]
-    int rmax = 0;
-    int want = 2;                        // what the lists were asked to be when they were built
-    bool wide = false;                   // tile order through k_os_wide (512 threads x 16 points, inverse lists)
-    double2 *d_ABw = nullptr;            // its (alpha, beta) tables: [block][group][slot][thread]
-    double list_bytes_per_window = 0.0;
+    // switches, read ONCE when the operator is created (never on the application path):
+    int want_lists = 0;                  // CM2_OS_LISTS = auto (0) | plain (1) | rc (2) | inv (3)
+    bool build_sort = false;             // CM2_OS_LIST_BUILD = sort: lists from a segmented sort
+    bool flat = false;                   // CM2_OS_FLAT: flat addressing although the buffers are < 4 GB
+    int64_t sort_chunk_windows = 0;      // CM2_OS_LIST_CHUNK_PAIRS (test hook: sort in several chunks)
+    std::mutex mu;                       // guards `cache`; list builds run under it
+    std::vector<std::shared_ptr<OsLists>> cache;
 };
 
-static void real_free_lists(RealOS *f)
-{
-    void *ptrs[] = {f->d_lst_k, f->d_lst_q, f->d_hdrs, f->d_tabs, f->d_ihdrs, f->d_iflags};
-    for (void *q : ptrs)
-        if (q) (void)cm2::dev_free(q);
-    f->d_lst_k = nullptr;
-    f->d_lst_q = nullptr;
-    f->d_hdrs = nullptr;
-    f->d_tabs = nullptr;
-    f->d_ihdrs = nullptr;
-    f->d_iflags = nullptr;
-    f->list_plan = 0;
-    f->list_mode = 0;
-    f->rmax = 0;
-}
-
-void real_os_destroy(RealOS *f)
+void fused_os_destroy(FusedOS *f)
 {
     if (!f) return;
-    real_free_lists(f);
-    void *ptrs[] = {f->d_wins, f->d_AB, f->d_W, f->d_ABw};
+    f->cache.clear();
+    void *ptrs[] = {f->d_wins, f->d_AB, f->d_W};
     for (void *q : ptrs)
         if (q) (void)cm2::dev_free(q);
     delete f;
 }
 
-int64_t real_os_window(const RealOS *f) { return f ? 512 * (int64_t)f->pt : 0; }
+bool fused_os_supported(int64_t lambda) { return lambda >= 1 && lambda - 1 <= kHalo; }
 
-template <int PT>
-static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const std::vector<int64_t> &off,
-                       hipStream_t stream)
+int64_t fused_os_length(const FusedOS *f) { return f ? G32::N : 0; }
+
+int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda, const std::vector<int64_t> &off,
+                    hipStream_t stream)
 {
-    using G = Geo<PT>;
+    using G = G32;
+    CM2_CHECK(out != nullptr, "fused_os_create: out is NULL");
+    *out = nullptr;
+    CM2_CHECK(fused_os_supported(lambda), "fused overlap-save supports lambda <= 2049, got %lld",
+              (long long)lambda);
+    FusedOS *f = new FusedOS();
+    struct Guard { FusedOS *f; ~Guard() { if (f) fused_os_destroy(f); } } guard{f};
+    if (const char *e = getenv("CM2_OS_LISTS")) {
+        if (!strcmp(e, "plain")) f->want_lists = 1;
+        else if (!strcmp(e, "rc")) f->want_lists = 2;
+        else if (!strcmp(e, "inv")) f->want_lists = 3;
+    }
+    if (const char *e = getenv("CM2_OS_LIST_BUILD")) f->build_sort = strcmp(e, "sort") == 0;
+    f->flat = getenv("CM2_OS_FLAT") != nullptr;
+    if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS")) f->sort_chunk_windows = atoll(e);
     const int64_t nb = (int64_t)off.size() - 1;
     f->nb = nb;
     std::vector<WinDesc> wins;
@@ -1871,6 +1428,7 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
             wins.push_back(wd);
         }
     f->nwin = (int64_t)wins.size();
+    CM2_CHECK(f->nwin * 4 < ((int64_t)1 << 31), "fused overlap-save: too many windows (%lld)", (long long)f->nwin);
     CM2_HIP(cm2::dev_malloc(&f->d_wins, sizeof(WinDesc) * (wins.size() ? wins.size() : 1)));
     if (!wins.empty())
         CM2_HIP(hipMemcpy(f->d_wins, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice));
@@ -1888,129 +1446,68 @@ static int real_create(RealOS *f, const double *d_bands, int64_t lambda, const s
         const int chunks = (G::N + 1 + kSpecK - 1) / kSpecK;
         k_real_spectrum<<<(int)nb * chunks, 256, ct_lds, stream>>>((int)nb, lambda, G::N, d_bands, ct, Hs);
         CM2_LAUNCH_OK();
-        k_real_alpha_beta<PT><<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_AB);
+        k_real_alpha_beta<kPT><<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_AB);
         CM2_LAUNCH_OK();
-        if (f->wide && PT == 32) {
-            CM2_HIP(cm2::dev_malloc(&f->d_ABw, sizeof(double2) * nb * G::N));
-            k_real_alpha_beta_wide<<<grid_for(nb * G::N), kBlock, 0, stream>>>((int)nb, Hs, f->d_ABw);
-            CM2_LAUNCH_OK();
-        }
         CM2_HIP(hipStreamSynchronize(stream));
     }
     CM2_HIP(cm2::dev_malloc(&f->d_W, sizeof(double2) * G::N));
     k_real_twiddles<<<(G::N + 255) / 256, 256, 0, stream>>>(G::N, f->d_W);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
-    return 0;
-}
-
-int real_os_create(RealOS **out, int pt, const double *d_bands, int64_t lambda,
-                   const std::vector<int64_t> &off, hipStream_t stream)
-{
-    CM2_CHECK(out != nullptr, "real_os_create: out is NULL");
-    *out = nullptr;
-    // pt = 64: the 32-point kernel's windows and lists, applied on the tile order by k_os_wide
-    // (512 threads x 16 points); the time order keeps the 32-point kernel
-    const bool wide = pt == 64;
-    if (wide) pt = 32;
-    CM2_CHECK(pt == 16 || pt == 32, "real_os_create: points per thread must be 16 or 32, got %d", pt);
-    CM2_CHECK(lambda >= 1 && lambda - 1 <= kHalo, "fused overlap-save supports lambda <= 2049, got %lld",
-              (long long)lambda);
-    RealOS *f = new RealOS();
-    f->pt = pt;
-    f->wide = wide;
-    struct Guard { RealOS *f; ~Guard() { if (f) real_os_destroy(f); } } guard{f};
-    if (int rc = (pt == 16 ? real_create<16>(f, d_bands, lambda, off, stream)
-                           : real_create<32>(f, d_bands, lambda, off, stream)))
-        return rc;
     guard.f = nullptr;
     *out = f;
     return 0;
 }
 
-template <int PT, int MODE, int TPT, bool BUF>
-static int real_launch_t(const RealOS *f, const double *d_v, double *d_out, uint32_t nbytes, hipStream_t stream)
+template <int MODE, bool BUF>
+static int os_launch_t(const FusedOS *f, const OsLists *ls, const double *d_v, double *d_out, uint32_t nbytes,
+                       hipStream_t stream)
 {
-    using G = Geo<PT>;
-    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)f->rmax : 0);
+    using G = G32;
+    const int rmax = ls ? ls->rmax : 0;
+    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)rmax : 0);
     static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<PT, MODE, TPT, BUF>, lds, granted));
+    CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<kPT, MODE, BUF>, lds, granted));
     if (f->nwin == 0) return 0;
     const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
-    k_os_real<PT, MODE, TPT, BUF><<<grid, kT, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, f->d_lst_k,
-                                                             f->d_lst_q, f->d_hdrs, f->d_tabs, f->rmax, d_v, d_out,
-                                                             nbytes, f->d_ihdrs, f->d_iflags OS_STAMP_ARG);
+    k_os_real<kPT, MODE, BUF><<<grid, kT, lds, stream>>>(
+        f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, ls ? ls->d_lst_k : nullptr, ls ? ls->d_lst_q : nullptr,
+        ls ? ls->d_hdrs : nullptr, ls ? ls->d_tabs : nullptr, rmax, d_v, d_out, nbytes, ls ? ls->d_ihdrs : nullptr,
+        ls ? ls->d_iflags : nullptr OS_STAMP_ARG);
     CM2_LAUNCH_OK();
     return 0;
 }
 
-// nvalid: doubles in the tile-order buffers (0 = unknown: flat addressing)
-template <int PT>
-static int real_launch(const RealOS *f, int mode, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream)
+// The kernel instance for a list format, a run-table size and a buffer size.  Buffers below 4 GB are
+// addressed through buffer descriptors (BUF), larger ones (or CM2_OS_FLAT) with flat addresses.
+static int os_launch(const FusedOS *f, const OsLists *ls, int64_t nvalid, const double *d_v, double *d_out,
+                     hipStream_t stream)
 {
-    if (mode == 0) return real_launch_t<PT, 0, 1, false>(f, d_v, d_out, 0, stream);
-    // (CM2_OS_FLAT: flat addressing for A/B timing)
-    const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !getenv("CM2_OS_FLAT");
+    const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !f->flat;
     const uint32_t nbytes = buf ? (uint32_t)(nvalid * 8) : 0u;
-    if (mode == 1)
-        return buf ? real_launch_t<PT, 1, 1, true>(f, d_v, d_out, nbytes, stream)
-                   : real_launch_t<PT, 1, 1, false>(f, d_v, d_out, 0, stream);
-    const int tpt = (f->rmax + kT - 1) / kT;
-    if (mode == 3) {
-        if (tpt <= 2)
-            return buf ? real_launch_t<PT, 3, 2, true>(f, d_v, d_out, nbytes, stream)
-                       : real_launch_t<PT, 3, 2, false>(f, d_v, d_out, 0, stream);
-        if (tpt <= 8)
-            return buf ? real_launch_t<PT, 3, 8, true>(f, d_v, d_out, nbytes, stream)
-                       : real_launch_t<PT, 3, 8, false>(f, d_v, d_out, 0, stream);
-    }
-    if (tpt <= 2)
-        return buf ? real_launch_t<PT, 2, 2, true>(f, d_v, d_out, nbytes, stream)
-                   : real_launch_t<PT, 2, 2, false>(f, d_v, d_out, 0, stream);
-    if (tpt <= 8)
-        return buf ? real_launch_t<PT, 2, 8, true>(f, d_v, d_out, nbytes, stream)
-                   : real_launch_t<PT, 2, 8, false>(f, d_v, d_out, 0, stream);
-    set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
+    // (the two run tables of a list pair live in LDS beside the 66 KB exchange buffer: 8 rmax bytes)
+    if (ls->mode == 1)
+        return buf ? os_launch_t<1, true>(f, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<1, false>(f, ls, d_v, d_out, 0, stream);
+    if (ls->mode == 3 && ls->rmax <= 8 * kT)
+        return buf ? os_launch_t<3, true>(f, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<3, false>(f, ls, d_v, d_out, 0, stream);
+    if (ls->mode == 2 && ls->rmax <= 8 * kT)
+        return buf ? os_launch_t<2, true>(f, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<2, false>(f, ls, d_v, d_out, 0, stream);
+    set_error("fused overlap-save: run table of %d words per list does not fit the kernel", ls->rmax);
     return 2;
 }
 
-template <int TPT, bool BUF>
-static int wide_launch_t(const RealOS *f, const double *d_v, double *d_out, uint32_t nbytes, hipStream_t stream)
+int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
-    const size_t lds = sizeof(double) * 2 * (size_t)Geo<16>::LDSD + sizeof(uint32_t) * 2 * (size_t)f->rmax;
-    static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_os_wide<TPT, BUF>, lds, granted));
-    if (f->nwin == 0) return 0;
-    const int grid = (int)(((f->nwin + 7) / 8) * 8);
-    k_os_wide<TPT, BUF><<<grid, kTW, lds, stream>>>(f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_ABw, f->d_lst_q,
-                                                   f->d_ihdrs, f->d_iflags, f->d_tabs, f->rmax, d_v, d_out, nbytes);
-    CM2_LAUNCH_OK();
-    return 0;
-}
-
-static int wide_launch(const RealOS *f, int64_t nvalid, const double *d_v, double *d_out, hipStream_t stream)
-{
-    const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !getenv("CM2_OS_FLAT");
-    const uint32_t nbytes = buf ? (uint32_t)(nvalid * 8) : 0u;
-    const int tpt = (f->rmax + kTW - 1) / kTW;
-    if (tpt <= 1)
-        return buf ? wide_launch_t<1, true>(f, d_v, d_out, nbytes, stream) : wide_launch_t<1, false>(f, d_v, d_out, 0, stream);
-    if (tpt <= 4)
-        return buf ? wide_launch_t<4, true>(f, d_v, d_out, nbytes, stream) : wide_launch_t<4, false>(f, d_v, d_out, 0, stream);
-    set_error("real_os: run table of %d words per list does not fit the kernel", f->rmax);
-    return 2;
-}
-
-int real_os_apply(const RealOS *f, const double *d_v, double *d_out, hipStream_t stream)
-{
-    return f->pt == 16 ? real_launch<16>(f, 0, 0, d_v, d_out, stream) : real_launch<32>(f, 0, 0, d_v, d_out, stream);
+    return os_launch_t<0, false>(f, nullptr, d_v, d_out, 0, stream);
 }
 
 // run-table words per list: one run per pixel tile at most (k_real_rc / k_real_lists)
-template <int PT>
-static int real_rmax(int64_t ntiles)
+static int os_rmax(int64_t ntiles)
 {
-    using G = Geo<PT>;
+    using G = G32;
     int64_t bound = ntiles > 0 ? ntiles : G::N;
     if (bound > G::N) bound = G::N;
     const int rmax = (int)((bound + 63) / 64 * 64);
@@ -2018,124 +1515,94 @@ static int real_rmax(int64_t ntiles)
 }
 
 // The lists straight from the tile plan's offsets (k_real_lists): no keys, no sort, no temporaries.
-template <int PT>
-static int real_build_lists_direct(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                                   int64_t ntiles, bool want_rc, hipStream_t stream)
+static int os_build_lists_direct(const FusedOS *f, OsLists *ls, const OsPlanView &pv, bool want_rc, hipStream_t stream)
 {
-    using G = Geo<PT>;
+    using G = G32;
     const int64_t total = f->nwin * G::PER;
     const int64_t nlists = f->nwin * G::NLIST;
-    CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
-    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
-    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
-    const int rmax = real_rmax<PT>(ntiles);
+    CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
+    const int rmax = os_rmax(pv.ntiles);
     // run-coded lists up to 8 table words per thread (2048 runs a list), plain lists beyond that
     const bool rc = want_rc && rmax <= 8 * kT;
-    const size_t lds = sizeof(uint32_t) * (size_t)(4 * ntiles + 1 + 12) + sizeof(uint16_t) * (size_t)G::N;
+    const size_t lds = sizeof(uint32_t) * (size_t)(4 * pv.ntiles + 1 + 12) + sizeof(uint16_t) * (size_t)G::N;
     static size_t granted[64] = {0};
     DevTemp<uint32_t> d_max;
     CM2_HIP(d_max.alloc(1));
     CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
     if (rc) {
-        CM2_HIP(cm2::dev_malloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
-        CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
-        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, true>, lds, granted));
-        k_real_lists<PT, true><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
-                                                                      f->d_lst_q, nullptr, f->d_hdrs, f->d_tabs, rmax, d_max);
+        CM2_HIP(cm2::dev_malloc(&ls->d_hdrs, sizeof(ListHdr) * nlists));
+        CM2_HIP(cm2::dev_malloc(&ls->d_tabs, sizeof(uint32_t) * nlists * rmax));
+        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<kPT, true>, lds, granted));
+        k_real_lists<kPT, true><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off,
+                                                                       (int)pv.ntiles, ls->d_lst_q, nullptr, ls->d_hdrs,
+                                                                       ls->d_tabs, rmax, d_max);
     } else {
-        CM2_HIP(cm2::dev_malloc(&f->d_lst_k, sizeof(uint32_t) * total));
-        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<PT, false>, lds, granted));
-        k_real_lists<PT, false><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
-                                                                       f->d_lst_q, f->d_lst_k, nullptr, nullptr, rmax, d_max);
+        CM2_HIP(cm2::dev_malloc(&ls->d_lst_k, sizeof(uint32_t) * total));
+        CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<kPT, false>, lds, granted));
+        k_real_lists<kPT, false><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off,
+                                                                        (int)pv.ntiles, ls->d_lst_q, ls->d_lst_k, nullptr,
+                                                                        nullptr, rmax, d_max);
     }
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
     CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CM2_HIP(hipStreamSynchronize(stream));
     if (rc) {
-        CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel "
+        CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel "
                   "tiles allow", h_max, rmax);
-        f->rmax = rmax;
-        f->list_mode = 2;
-        f->list_bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
+        ls->rmax = rmax;
+        ls->mode = 2;
+        ls->bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
     } else {
-        f->list_mode = 1;
-        f->list_bytes_per_window = 6.0 * G::PER;
+        ls->mode = 1;
+        ls->bytes_per_window = 6.0 * G::PER;
     }
-    guard.f = nullptr;
-    f->list_plan = plan_id;
     return 0;
 }
 
 // Inverse lists (k_real_ilists): needs the tile offsets and run tables that fit LDS (<= 2048 runs).
-template <int PT>
-static int real_build_ilists(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                             int64_t ntiles, hipStream_t stream)
+static int os_build_ilists(const FusedOS *f, OsLists *ls, const OsPlanView &pv, hipStream_t stream)
 {
-    using G = Geo<PT>;
-    const int threads = f->wide ? 512 : 256;             // workgroup size of the kernel that reads them
+    using G = G32;
     const int64_t total = f->nwin * G::PER;
     const int64_t nlists = f->nwin * 2;
-    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
-    const int rmax = real_rmax<PT>(ntiles);
-    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
-    CM2_HIP(cm2::dev_malloc(&f->d_ihdrs, sizeof(IListHdr) * nlists));
-    CM2_HIP(cm2::dev_malloc(&f->d_iflags, sizeof(uint32_t) * nlists * 2 * threads));
-    CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
+    const int rmax = os_rmax(pv.ntiles);
+    CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&ls->d_ihdrs, sizeof(IListHdr) * nlists));
+    CM2_HIP(cm2::dev_malloc(&ls->d_iflags, sizeof(uint32_t) * nlists * 2 * kT));
+    CM2_HIP(cm2::dev_malloc(&ls->d_tabs, sizeof(uint32_t) * nlists * rmax));
     DevTemp<uint32_t> d_max;
     CM2_HIP(d_max.alloc(1));
     CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
-    const size_t lds = sizeof(uint32_t) * (size_t)(3 * ntiles + 1 + 20 + 2 * threads);
+    const size_t lds = sizeof(uint32_t) * (size_t)(3 * pv.ntiles + 1 + 20 + 2 * kT);
     static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_real_ilists<PT>, lds, granted));
-    k_real_ilists<PT><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, d_idx, d_tile_off, (int)ntiles,
-                                                             f->d_lst_q, f->d_iflags, f->d_ihdrs, f->d_tabs, rmax, d_max,
-                                                             threads);
+    CM2_HIP(ensure_dynamic_lds((const void *)k_real_ilists<kPT>, lds, granted));
+    k_real_ilists<kPT><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off, (int)pv.ntiles,
+                                                              ls->d_lst_q, ls->d_iflags, ls->d_ihdrs, ls->d_tabs, rmax,
+                                                              d_max, kT);
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
     CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CM2_HIP(hipStreamSynchronize(stream));
-    CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel tiles allow",
-              h_max, rmax);
-    f->rmax = rmax;
-    f->list_mode = 3;
-    f->list_bytes_per_window = 2.0 * G::PER + 2 * (sizeof(IListHdr) + 2048.0 + 4.0 * h_max);
-    guard.f = nullptr;
-    f->list_plan = plan_id;
+    CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel tiles "
+              "allow", h_max, rmax);
+    ls->rmax = rmax;
+    ls->mode = 3;
+    ls->bytes_per_window = 2.0 * G::PER + 2 * (sizeof(IListHdr) + 2048.0 + 4.0 * h_max);
     return 0;
 }
 
-// d_tile_off: first address of every pixel tile ([ntiles + 1], NULL = unknown).  With it the lists
-// are written directly; without it (or CM2_OS_LIST_BUILD=sort, or more tiles than k_real_lists
-// keeps in LDS) they come from a segmented sort of (address, position) pairs.
-template <int PT>
-static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                            int64_t ntiles, int want, hipStream_t stream)
+// The lists from a segmented sort of (address, position) pairs: needs nothing but the index
+// (CM2_OS_LIST_BUILD=sort, a plan without tile offsets, or more tiles than the direct builders keep
+// in LDS).
+static int os_build_lists_sorted(const FusedOS *f, OsLists *ls, const OsPlanView &pv, bool want_rc, hipStream_t stream)
 {
-    const bool want_rc = want >= 2;
-    using G = Geo<PT>;
-    real_free_lists(f);
-    if (f->nwin == 0) {
-        f->list_plan = plan_id;
-        f->list_mode = 1;
-        return 0;
-    }
-    {
-        const char *e = getenv("CM2_OS_LIST_BUILD");         // direct (default) | sort
-        const bool sort = e && strcmp(e, "sort") == 0;
-        if (!sort && d_tile_off && ntiles > 0 && ntiles <= 4096) {
-            if (want == 3 && real_rmax<PT>(ntiles) <= 8 * kT && f->nwin * 2 < ((int64_t)1 << 31))
-                return real_build_ilists<PT>(f, d_idx, d_tile_off, plan_id, ntiles, stream);
-            return real_build_lists_direct<PT>(f, d_idx, d_tile_off, plan_id, ntiles, want_rc, stream);
-        }
-    }
+    using G = G32;
     const int64_t total = f->nwin * G::PER;
-    struct Guard { RealOS *f; ~Guard() { if (f) real_free_lists(f); } } guard{f};
-    CM2_HIP(cm2::dev_malloc(&f->d_lst_k, sizeof(uint32_t) * total));
-    CM2_HIP(cm2::dev_malloc(&f->d_lst_q, sizeof(uint16_t) * total));
+    CM2_HIP(cm2::dev_malloc(&ls->d_lst_k, sizeof(uint32_t) * total));
+    CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
     int64_t chunk_w = ((int64_t)1 << 30) / G::PER;             // hipCUB counts items in int
-    if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS"))      // test hook: force several chunks
-        if (atoll(e) > 0 && atoll(e) < chunk_w) chunk_w = atoll(e);
+    if (f->sort_chunk_windows > 0 && f->sort_chunk_windows < chunk_w) chunk_w = f->sort_chunk_windows;
     const int64_t cw_max = f->nwin < chunk_w ? f->nwin : chunk_w;
     {
         DevTemp<uint32_t> keys_in;
@@ -2144,91 +1611,135 @@ static int real_build_lists(RealOS *f, const uint32_t *d_idx, const int64_t *d_t
         CM2_HIP(keys_in.alloc(cw_max * G::PER));
         CM2_HIP(vals_in.alloc(cw_max * G::PER));
         hipcub::CountingInputIterator<int> seg_id(0);
-        using OffsetIt = hipcub::TransformInputIterator<int, RealListOffset<PT>, hipcub::CountingInputIterator<int>>;
-        OffsetIt seg_begin(seg_id, RealListOffset<PT>{0}), seg_end(seg_id, RealListOffset<PT>{1});
+        using OffsetIt = hipcub::TransformInputIterator<int, RealListOffset<kPT>, hipcub::CountingInputIterator<int>>;
+        OffsetIt seg_begin(seg_id, RealListOffset<kPT>{0}), seg_end(seg_id, RealListOffset<kPT>{1});
         size_t tb = 0;
         CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
-            nullptr, tb, keys_in.p, f->d_lst_k, vals_in.p, f->d_lst_q, (int)(cw_max * G::PER),
+            nullptr, tb, keys_in.p, ls->d_lst_k, vals_in.p, ls->d_lst_q, (int)(cw_max * G::PER),
             (int)(G::NLIST * cw_max), seg_begin, seg_end, 0, 32, stream));
         CM2_HIP(d_temp.alloc(tb + 16));
         for (int64_t p0 = 0; p0 < f->nwin; p0 += chunk_w) {
             const int64_t nw = f->nwin - p0 < chunk_w ? f->nwin - p0 : chunk_w;
-            k_real_keys<PT><<<grid_for(nw * G::PER), kBlock, 0, stream>>>(f->d_wins, p0, nw, d_idx, keys_in, vals_in);
+            k_real_keys<kPT><<<grid_for(nw * G::PER), kBlock, 0, stream>>>(f->d_wins, p0, nw, pv.d_idx, keys_in, vals_in);
             CM2_LAUNCH_OK();
             size_t tbc = tb;
             CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
-                d_temp.p, tbc, keys_in.p, f->d_lst_k + p0 * G::PER, vals_in.p, f->d_lst_q + p0 * G::PER,
+                d_temp.p, tbc, keys_in.p, ls->d_lst_k + p0 * G::PER, vals_in.p, ls->d_lst_q + p0 * G::PER,
                 (int)(nw * G::PER), (int)(G::NLIST * nw), seg_begin, seg_end, 0, 32, stream));
         }
         CM2_HIP(hipStreamSynchronize(stream));
     }
-    f->list_mode = 1;
-    f->list_bytes_per_window = 6.0 * G::PER;
+    ls->mode = 1;
+    ls->bytes_per_window = 6.0 * G::PER;
+    const int64_t nlists = f->nwin * G::NLIST;
     if (want_rc) {
-        const int64_t nlists = f->nwin * G::NLIST;
-        CM2_CHECK(nlists < ((int64_t)1 << 31), "real_os: too many lists (%lld)", (long long)nlists);
-        // one run per pixel tile at most (k_real_rc): the run-table stride follows from the tile count
-        const int rmax = real_rmax<PT>(ntiles);
-        // the two window-half tables live in LDS beside the exchange buffer; run-coded lists only
+        // one run per pixel tile at most (k_real_rc): the run-table stride follows from the tile count;
+        // the two window-half tables live in LDS beside the exchange buffer: run-coded lists only
         // up to 8 table words per thread (2048 runs a list), plain lists beyond that
+        const int rmax = os_rmax(pv.ntiles);
         if (rmax <= 8 * kT) {
             DevTemp<uint32_t> d_max;
             CM2_HIP(d_max.alloc(1));
             CM2_HIP(hipMemsetAsync(d_max.p, 0, sizeof(uint32_t), stream));
-            CM2_HIP(cm2::dev_malloc(&f->d_hdrs, sizeof(ListHdr) * nlists));
-            CM2_HIP(cm2::dev_malloc(&f->d_tabs, sizeof(uint32_t) * nlists * rmax));
-            k_real_rc<PT><<<(unsigned)nlists, 256, 0, stream>>>(nlists, f->d_lst_k, f->d_lst_q, f->d_hdrs,
-                                                               f->d_tabs, rmax, d_max);
+            CM2_HIP(cm2::dev_malloc(&ls->d_hdrs, sizeof(ListHdr) * nlists));
+            CM2_HIP(cm2::dev_malloc(&ls->d_tabs, sizeof(uint32_t) * nlists * rmax));
+            k_real_rc<kPT><<<(unsigned)nlists, 256, 0, stream>>>(nlists, ls->d_lst_k, ls->d_lst_q, ls->d_hdrs,
+                                                                ls->d_tabs, rmax, d_max);
             CM2_LAUNCH_OK();
             uint32_t h_max = 0;
             CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM2_HIP(hipStreamSynchronize(stream));
-            CM2_CHECK((int)h_max <= rmax, "real_os: a list has %u address runs, more than the %d pixel "
+            CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel "
                       "tiles allow", h_max, rmax);
-            (void)cm2::dev_free(f->d_lst_k);                      // the addresses are now in the run tables
-            f->d_lst_k = nullptr;
-            f->rmax = rmax;
-            f->list_mode = 2;
-            f->list_bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
+            (void)cm2::dev_free(ls->d_lst_k);                     // the addresses are now in the run tables
+            ls->d_lst_k = nullptr;
+            ls->rmax = rmax;
+            ls->mode = 2;
+            ls->bytes_per_window = 2.0 * G::PER + G::NLIST * (sizeof(ListHdr) + 4.0 * h_max);
         }
     }
-    guard.f = nullptr;
-    f->list_plan = plan_id;
+    k_real_qperm<kPT><<<(unsigned)nlists, 256, 0, stream>>>(nlists, ls->d_lst_q);
+    CM2_LAUNCH_OK();
+    CM2_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 
-int real_os_apply_indexed(RealOS *f, const uint32_t *d_idx, const int64_t *d_tile_off, uint64_t plan_id,
-                          int64_t ntiles, int64_t nvalid, int want, const double *d_v, double *d_out,
-                          hipStream_t stream)
+// The lists of `f` for the tile plan `pv`, from the operator's cache or built now (under the
+// operator's mutex: two host threads that meet here build once).  List format when the operator was
+// created without CM2_OS_LISTS: lists cut by time (mode 2) keep the pick / place side cheap and win
+// while a half window's address runs are long (512 tiles at C4: 16 entries); from ~768 tiles up the
+// longer runs and whole sectors of the lists cut by address (mode 3) win: C5's 1536 tiles
+// 1.24 -> 1.05 ms, the balanced tiling of an uneven hit map (1015 tiles) 0.92 -> 0.87 ms, 512 tiles
+// 0.76 -> 0.79 ms (profiles/r03_inverse_lists.md).
+static int os_lists_for(FusedOS *f, const OsPlanView &pv, hipStream_t stream, std::shared_ptr<OsLists> *out)
 {
-    // want = 0: by tile count.  Lists cut by time (mode 2) keep the pick / place side cheap and win
-    // while a half window's address runs are long (512 tiles at C4: 16 entries); from ~768 tiles up
-    // the longer runs and whole sectors of the lists cut by address (mode 3) win: C5's 1536 tiles
-    // 1.24 -> 1.05 ms, the balanced tiling of an uneven hit map (1015 tiles) 0.92 -> 0.87 ms, 512 tiles
-    // 0.76 -> 0.79 ms (profiles/r03_inverse_lists.md).
-    if (want == 0) want = ntiles >= 768 ? 3 : 2;
-    if (f->wide) want = 3;                               // k_os_wide reads inverse lists only
-    if (f->list_plan != plan_id || f->list_mode == 0 || f->want != want) {
-        if (int rc = (f->pt == 16 ? real_build_lists<16>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)
-                                  : real_build_lists<32>(f, d_idx, d_tile_off, plan_id, ntiles, want, stream)))
-            return rc;
-        f->want = want;                // (a plan whose run tables do not fit stays on plain lists)
+    std::lock_guard<std::mutex> lock(f->mu);
+    for (size_t i = 0; i < f->cache.size(); ++i)
+        if (f->cache[i]->plan_id == pv.plan_id) {
+            std::shared_ptr<OsLists> hit = f->cache[i];
+            f->cache.erase(f->cache.begin() + (long)i);
+            f->cache.insert(f->cache.begin(), hit);
+            *out = hit;
+            return 0;
+        }
+    const int want = f->want_lists ? f->want_lists : (pv.ntiles >= 768 ? 3 : 2);
+    std::shared_ptr<OsLists> ls = std::make_shared<OsLists>();
+    ls->plan_id = pv.plan_id;
+    if (f->nwin == 0) {
+        ls->mode = 1;
+    } else {
+        CM2_CHECK(f->nwin * G32::NLIST < ((int64_t)1 << 31), "fused overlap-save: too many lists (%lld)",
+                  (long long)(f->nwin * G32::NLIST));
+        int rc;
+        if (!f->build_sort && pv.d_tile_off && pv.ntiles > 0 && pv.ntiles <= 4096) {
+            if (want == 3 && os_rmax(pv.ntiles) <= 8 * kT)
+                rc = os_build_ilists(f, ls.get(), pv, stream);
+            else
+                rc = os_build_lists_direct(f, ls.get(), pv, want >= 2, stream);
+        } else {
+            rc = os_build_lists_sorted(f, ls.get(), pv, want >= 2, stream);
+        }
+        if (rc) return rc;                                   // (ls frees what it holds)
     }
-    if (f->wide && f->list_mode == 3) return wide_launch(f, nvalid, d_v, d_out, stream);
-    return f->pt == 16 ? real_launch<16>(f, f->list_mode, nvalid, d_v, d_out, stream)
-                       : real_launch<32>(f, f->list_mode, nvalid, d_v, d_out, stream);
+    f->cache.insert(f->cache.begin(), ls);
+    while (f->cache.size() > kListCache) f->cache.pop_back();
+    *out = ls;
+    return 0;
 }
 
-// HBM bytes per output sample the tile-order kernel is built to move (lists + gathers + results)
-double real_os_tile_bytes_per_sample(const RealOS *f)
+int fused_os_prepare_indexed(FusedOS *f, const OsPlanView &pv, hipStream_t stream)
 {
+    std::shared_ptr<OsLists> ls;
+    return os_lists_for(f, pv, stream, &ls);
+}
+
+int fused_os_apply_indexed(FusedOS *f, const OsPlanView &pv, const double *d_v, double *d_out, hipStream_t stream)
+{
+    std::shared_ptr<OsLists> ls;
+    if (int rc = os_lists_for(f, pv, stream, &ls)) return rc;
+    return os_launch(f, ls.get(), pv.nvalid, d_v, d_out, stream);
+}
+
+// kernel[0] = complex points per thread of the window kernel (32), kernel[1] = list format of the
+// most recently used plan (1 plain, 2 run-coded, 3 inverse; 0: no lists yet); returns the HBM bytes
+// per output sample the tile-order kernel is built to move (lists + gathered window + results)
+double fused_os_tile_info(const FusedOS *f_, int *kernel)
+{
+    FusedOS *f = const_cast<FusedOS *>(f_);
+    std::shared_ptr<OsLists> ls;
+    if (f) {
+        std::lock_guard<std::mutex> lock(f->mu);
+        if (!f->cache.empty()) ls = f->cache.front();
+    }
+    if (kernel) {
+        kernel[0] = f ? kPT : 0;
+        kernel[1] = ls ? ls->mode : 0;
+    }
     if (!f) return 0.0;
-    const double hop = 512.0 * f->pt - 2.0 * kHalo, win = 512.0 * f->pt;
-    const double lists = f->list_bytes_per_window > 0 ? f->list_bytes_per_window : 6.0 * (win + hop);
+    const double hop = (double)G32::HOP, win = (double)G32::W;
+    const double lists = ls && ls->bytes_per_window > 0 ? ls->bytes_per_window : 6.0 * (win + hop);
     return (lists + 8.0 * win + 8.0 * hop) / hop;
 }
-
-int real_os_list_mode(const RealOS *f) { return f ? f->list_mode : 0; }
 
 #ifdef CM2_OS_STAMPS
 extern "C" int cm2_os_debug_stamps(unsigned long long *d_buf)

@@ -290,6 +290,7 @@ class _TiledNormalLO(_DeviceOp):
     def __init__(self, P, noise):
         self.P, self.noise = P, noise
         self._fused_noise = None
+        self._prepared_plan = None
         self._work = None
         n = P.pol * P.ncols
         super(_TiledNormalLO, self).__init__(n, n, self._mult, symmetric=True)
@@ -324,7 +325,11 @@ class _TiledNormalLO(_DeviceOp):
             self._fused_noise = info is not None and info()["tiles_ok"]
         tiled_apply = getattr(self.noise, "_apply_tiles", None)
         if self._fused_noise:
-            # overlap-save kernel reads and writes the tile order directly
+            # overlap-save kernel reads and writes the tile order directly; its address lists for this
+            # plan are built by the first application (later ones only launch the kernel)
+            if self._prepared_plan != T.plan_id:
+                _hip.call("cm2_noise_prepare_tiles", self.noise._noise.h, T.h, st)
+                self._prepared_plan = T.plan_id
             _hip.call("cm2_noise_apply_tiles", self.noise._noise.h, T.h, D.ptr(d_tb),
                       D.ptr(v_tb), st)
             src = v_tb
@@ -578,12 +583,12 @@ class BlockLO(blk.BlockDiagonalLinearOperator):
                     tiles_ok=bool(info[5]))
 
     def tile_kernel_info(self):
-        """Overlap-save kernel of the tile-order application: points per thread (0 = segment-pair
-        kernel), list format, window length, designed HBM bytes per sample."""
+        """Overlap-save kernel of the tile-order application: complex points per thread, list format of
+        the most recently used tile plan, window length, designed HBM bytes per sample."""
         info = (ctypes.c_int64 * 3)()
         bps = ctypes.c_double(0.0)
         _hip.call("cm2_noise_tile_kernel_info", self._noise.h, info, ctypes.byref(bps))
-        return dict(os_kernel={0: "pair", 64: "wide32"}.get(int(info[0]), "real%d" % info[0]),
+        return dict(os_kernel="real%d" % info[0],
                     os_lists={0: "not built", 1: "plain", 2: "run-coded", 3: "inverse run-coded"}[int(info[1])],
                     os_window=int(info[2]), tile_bytes_per_sample=round(float(bps.value), 2))
 

@@ -18,7 +18,9 @@
  *   - maps are pixel-interleaved doubles [I0,Q0,U0,I1,...] (linearoperators.py:487);
  *     pixel ids are int32, -1 marks a flagged sample (linearoperators.py:372);
  *     all arithmetic is IEEE double, no FMA contraction, reference operand order;
- *   - one context per process per GPU; not thread-safe (the reference is
+ *   - one context per process per GPU.  Objects may be shared by host threads for APPLICATION
+ *     calls once their lazily built parts exist (cm2_tiles_prepare_pt, cm2_noise_prepare_tiles,
+ *     cm2_pointing_build_sell); construction and destruction are not thread-safe (the reference is
  *     single-threaded).
  */
 #ifndef COSMOMAP2_H
@@ -180,8 +182,15 @@ int cm2_noise_destroy(cm2_noise *n);
 /* y = N^-1 v over all blocks (blk_matvec, blkop.py:195-206).  d_out != d_v. */
 int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, void *stream);
 /* y = N^-1 v with v and y both in the tile-bucketed order of `tiles` (CM2_TOEPLITZ_FUSED
- * operators only): the permutation to and from time order is folded into the overlap-save
- * kernel's own loads and stores.  d_out_tb != d_in_tb. */
+ * operators, and CM2_TOEPLITZ_AUTO ones with lambda <= 2049): the permutation to and from time order
+ * is folded into the overlap-save kernel's own loads and stores (ToeplitzLO.mult :582-595 per block,
+ * blkop.py:195-206).  d_out_tb != d_in_tb.
+ * cm2_noise_prepare_tiles builds the address lists of the (operator, tile plan) pair: it allocates,
+ * launches the list builders on `stream` and WAITS for them.  After it, cm2_noise_apply_tiles for the
+ * same plan is one kernel launch -- no allocation, no synchronisation, safe inside a stream capture
+ * and from several host threads.  Without it the first application prepares the lists itself (under
+ * the operator's lock).  An operator keeps the lists of its three most recently used tile plans. */
+int cm2_noise_prepare_tiles(cm2_noise *n, const cm2_tiles *tiles, void *stream);
 int cm2_noise_apply_tiles(cm2_noise *n, const cm2_tiles *tiles, const double *d_in_tb,
                           double *d_out_tb, void *stream);
 /* y = P^T N^-1 P x in ONE call on the tile order (the chain `P.T*N*P` of the reference's scripts,
@@ -197,15 +206,15 @@ int cm2_noise_expand_diag(const cm2_noise *n, double *d_w, void *stream);
  * an AUTO operator that applies the direct sum on the time order still runs the fused
  * overlap-save kernel on a tile order) */
 int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
-/* Which overlap-save kernel cm2_noise_apply_tiles runs for this operator (none of this exists in
- * the reference, whose ToeplitzLO.mult is a NumPy loop, interfaces/linearoperators.py:582-595):
- * h_info[0] = points per thread of the one-real-window kernel (16 or 32; 0 = the segment-pair
- * kernel), h_info[1] = list format (1 plain, 2 run-coded, 0 = lists not built yet), h_info[2] =
- * window length in samples; *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to
- * move (lists + gathered windows + results).  Environment switches read at every application:
- * CM2_OS_KERNEL = real32 (default) | real16 | pair, CM2_OS_LISTS = auto (default: rc below 768
- * pixel tiles, inv from there up) | rc | inv | plain.  h_info[1]: 1 plain, 2 run-coded lists cut by
- * time, 3 run-coded lists cut by address ("inverse"). */
+/* What cm2_noise_apply_tiles runs for this operator (none of this exists in the reference, whose
+ * ToeplitzLO.mult is a NumPy loop, interfaces/linearoperators.py:582-595): h_info[0] = complex points
+ * per thread of the one-real-window kernel (32), h_info[1] = list format of the most recently used
+ * tile plan (1 plain, 2 run-coded lists cut by time, 3 run-coded lists cut by address ("inverse"),
+ * 0 = no lists built yet), h_info[2] = window length in samples; *h_bytes_per_sample = HBM bytes per
+ * TOD sample the kernel is built to move (lists + gathered windows + results).  Environment switches,
+ * read ONCE when the operator is created: CM2_OS_LISTS = auto (default: rc below 768 pixel tiles,
+ * inv from there up) | rc | inv | plain, CM2_OS_LIST_BUILD = direct (default) | sort, CM2_OS_FLAT
+ * (flat addressing also for buffers below 4 GB). */
 int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample);
 
 /* ------------------------------------------------------------------------- *

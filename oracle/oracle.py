@@ -637,34 +637,53 @@ def lib_omp():
 
 class AllCoresMatvec(object):
     """(P^T N^-1 P) x on `threads` host threads for a pol-interleaved map: P and P^T through
-    the OpenMP loops, the banded-Toeplitz blocks (zero boundary) as scipy.signal.fftconvolve
-    'same' with the symmetric 2*lambda-1 kernel, one block per pool thread."""
+    the OpenMP loops (interfaces/linearoperators.py:483-489, :509-516), N^-1 per noise block as
+    interfaces/blkop.py:195-206 dispatches it: banded-Toeplitz blocks (zero boundary,
+    linearoperators.py:582-595) as scipy.signal.fftconvolve 'same' with the symmetric 2*lambda-1
+    kernel, one block per pool thread, or -- `bands` None and `diag` a per-sample weight vector --
+    the diagonal blocks of BlockLO(offdiag=False) as one multiply.  `blocksize`: one int or the
+    per-block sizes."""
 
-    def __init__(self, pol, npix, pix, cos, sin, blocksize, bands, threads):
+    def __init__(self, pol, npix, pix, cos, sin, blocksize, bands, threads, diag=None):
         from concurrent.futures import ThreadPoolExecutor
         self.pol, self.npix, self.threads = pol, int(npix), int(threads)
         self.pix, self.cos, self.sin = _i32(pix), _f64(cos), _f64(sin)
         self.nt = self.pix.size
-        self.bs = int(blocksize)
-        self.kernels = [np.concatenate([np.asarray(b)[:0:-1], np.asarray(b)]) for b in bands]
+        self.diag = None if diag is None else _f64(diag)
+        if bands is not None:
+            self.sizes = block_sizes(blocksize, len(bands))
+            self.offs = np.concatenate([[0], np.cumsum(self.sizes)])
+            self.kernels = [np.concatenate([np.asarray(b)[:0:-1], np.asarray(b)]) for b in bands]
+        else:
+            self.kernels = None
         self.scratch = np.empty(self.threads * pol * self.npix)
-        self.pool = ThreadPoolExecutor(self.threads)
+        self.pool = ThreadPoolExecutor(min(self.threads, 64))
 
-    def __call__(self, x):
-        from scipy.signal import fftconvolve
-        L = lib_omp()
-        x = _f64(x)
+    def P(self, x):
         tod = np.empty(self.nt)
-        L.orc_omp_P_apply(self.pol, ctypes.c_int64(self.nt), self.pix.ctypes.data_as(_I32),
-                          _d(self.cos), _d(self.sin), _d(x), _d(tod), self.threads)
+        lib_omp().orc_omp_P_apply(self.pol, ctypes.c_int64(self.nt), self.pix.ctypes.data_as(_I32),
+                                  _d(self.cos), _d(self.sin), _d(_f64(x)), _d(tod), self.threads)
+        return tod
+
+    def N(self, tod):
+        if self.kernels is None:
+            return self.diag * tod
+        from scipy.signal import fftconvolve
         out_tod = np.empty(self.nt)
 
         def one(b):
-            a, e = b * self.bs, min((b + 1) * self.bs, self.nt)
-            out_tod[a:e] = fftconvolve(tod[a:e], self.kernels[b], mode="same")
+            a, e = int(self.offs[b]), min(int(self.offs[b + 1]), self.nt)
+            if e > a:
+                out_tod[a:e] = fftconvolve(tod[a:e], self.kernels[b], mode="same")
         list(self.pool.map(one, range(len(self.kernels))))
+        return out_tod
+
+    def Pt(self, tod):
         out = np.empty(self.pol * self.npix)
-        L.orc_omp_Pt_apply(self.pol, ctypes.c_int64(self.nt), ctypes.c_int64(self.npix),
-                           self.pix.ctypes.data_as(_I32), _d(self.cos), _d(self.sin), _d(out_tod),
-                           _d(out), _d(self.scratch), self.threads)
+        lib_omp().orc_omp_Pt_apply(self.pol, ctypes.c_int64(self.nt), ctypes.c_int64(self.npix),
+                                   self.pix.ctypes.data_as(_I32), _d(self.cos), _d(self.sin),
+                                   _d(_f64(tod)), _d(out), _d(self.scratch), self.threads)
         return out
+
+    def __call__(self, x):
+        return self.Pt(self.N(self.P(x)))

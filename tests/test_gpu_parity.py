@@ -1267,20 +1267,21 @@ def test_overlap_save_on_tile_order(cm, oracle, tp, lam):
     assert rel_l2(L._TiledNormalLO(P, Nf) * x, exact) < 1e-12
 
 
-@pytest.mark.parametrize("kernel,lists", [("pair", "plain"), ("real16", "rc"), ("real16", "plain"),
-                                          ("real32", "plain"), ("real32", "rc"), ("real32", "inv"),
-                                          ("real16", "inv"), ("wide32", "inv")])
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("lists", ["plain", "rc", "inv"])
 @pytest.mark.parametrize("tp,lam,npix", [(1024, 300, 70000), (2048, 2049, 70000), (64, 40, 200000)])
-def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp, lam, npix):
-    """Every overlap-save kernel behind the switches (CM2_OS_KERNEL = pair | real16 | real32,
-    CM2_OS_LISTS = rc | plain) on the tile order AND on the time order against the direct sum /
-    rocFFT: the segment-pair kernel of round 2, the one-real-window kernel with 16 and 32 points
-    per thread, run-coded and plain lists; the last case has 3125 tiles, more address runs per list
-    than the run tables hold, where run-coding falls back to plain lists by itself."""
+def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, lists, flat, tp, lam, npix):
+    """Every instantiation of the overlap-save kernel the dispatcher can choose (list format
+    CM2_OS_LISTS = plain | rc | inv; buffer descriptors, or flat addressing as for TOD buffers of 4 GB
+    and more, CM2_OS_FLAT) on the tile order AND on the time order against the direct sum / rocFFT;
+    the last case has 3125 tiles, more address runs per list than the run tables hold, where
+    run-coding falls back to plain lists by itself."""
     from types import SimpleNamespace
     from cosmomap2_amd.interfaces import linearoperators as L
-    monkeypatch.setenv("CM2_OS_KERNEL", kernel)
+    kernel = "real32"
     monkeypatch.setenv("CM2_OS_LISTS", lists)
+    if flat:
+        monkeypatch.setenv("CM2_OS_FLAT", "1")
     pol, nt, nblk = 3, 240000, 5
     d, pairs, phi, t, diag = make_problem(oracle, 900 + lam, nt, npix, nblk, pol, flag_frac=0.07)
     c, s = np.cos(2 * phi), np.sin(2 * phi)
@@ -1300,7 +1301,7 @@ def test_overlap_save_kernel_variants(cm, oracle, monkeypatch, kernel, lists, tp
     info = Nf.tile_kernel_info()
     assert info["os_kernel"] == kernel
     many_tiles = npix // tp > 2048
-    assert info["os_lists"] == ("plain" if lists == "plain" or kernel == "pair" or many_tiles
+    assert info["os_lists"] == ("plain" if lists == "plain" or many_tiles
                                 else ("inverse run-coded" if lists == "inv" else "run-coded"))
 
 
@@ -1328,10 +1329,8 @@ def test_overlap_save_lists_built_in_chunks(cm, oracle, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("kernel,lists,tp", [("real32", "rc", 1024), ("real32", "plain", 1024),
-                                             ("real16", "rc", 1024), ("real32", "rc", 64),
-                                             ("real16", "plain", 256)])
-def test_overlap_save_lists_written_directly_equal_the_sorted_ones(cm, oracle, monkeypatch, kernel, lists, tp):
+@pytest.mark.parametrize("lists,tp", [("rc", 1024), ("plain", 1024), ("rc", 64), ("plain", 256)])
+def test_overlap_save_lists_written_directly_equal_the_sorted_ones(cm, oracle, monkeypatch, lists, tp):
     """The address lists of the tile-order overlap-save kernel are written straight from the tile
     plan's offsets (k_real_lists: count / lowest address per tile, a scan, slot = base + address -
     lowest).  They must describe the same gather / scatter as the lists that come out of the
@@ -1347,7 +1346,6 @@ def test_overlap_save_lists_written_directly_equal_the_sorted_ones(cm, oracle, m
     kk = np.arange(lam)
     bands = [(1.0 + 0.1 * b) * np.exp(-kk / (lam / 4.0)) for b in range(nblk)]
     x = np.random.default_rng(2).standard_normal(pol * npix)
-    monkeypatch.setenv("CM2_OS_KERNEL", kernel)
     monkeypatch.setenv("CM2_OS_LISTS", lists)
     outs = []
     for build in ("direct", "sort"):
