@@ -21,7 +21,8 @@ uniform-random pixel per sample, HWP angle ramp, d ~ U[0,1)):
   c3  nside 128 IQU, 1e8 samples, banded-Toeplitz N, lambda 2048 -> P, overlap-save FFT, P^T
   c4  nside 256 IQU, 1e8 samples/GPU, Toeplitz lambda 2048       -> the configuration the
       north_star target (>= 40 % HBM roofline) is quoted on; DEFAULT.
-  c5  one GPU's share of C5: nside 512 IQU, 1.25e8 samples (8 detector blocks of 15 625 000)
+  c5  one GPU's share of C5: nside 512 IQU, 1.25e8 samples (8 detector blocks of 15 625 000);
+      `--config c5 --scaling strong --gpus 1` is C5 WHOLE on one GPU (1e9 samples, 64 blocks)
 
 Byte accounting per stage: "bytes_survey" is SURVEY.md 8(d)'s algorithmic figure (P 28, N^-1 16,
 P^T 28 B/sample + map traffic) -- the figure `roofline.achieved` is computed from;
@@ -29,6 +30,7 @@ P^T 28 B/sample + map traffic) -- the figure `roofline.achieved` is computed fro
 overlap), which is what to compare the PMC traffic with.
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -74,6 +76,25 @@ def toeplitz_band(lam, rng, fknee=0.02, alpha=1.5):
     if Ht.min() < floor:
         a[0] += floor - Ht.min()
     return a * (1.0 + 0.1 * rng.random())
+
+
+def synth_inputs(torch, dev, npix, nt, nb, lam, rank=0):
+    """The synthetic inputs of one rank's shard, generated in HBM (seeded; the seed differs per rank),
+    after the reference's generators (utilities/utilities_functions.py:99-212): uniform-random pixel
+    per sample (pairs_gen :111-122), HWP angle ramp phi = theta0 + 2 pi 2.5/200 i (angles_gen :99-109),
+    d ~ U[0,1) (:197), one banded-Toeplitz first row (`toeplitz_band`) or one diagonal weight in
+    [0.5, 1.5) per noise block.  Shared by bench.py and the full-size parity tests
+    (tests/test_gpu_fullsize.py), which hand the same arrays to the CPU oracle."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20161202 + 1000 * rank)
+    rng = np.random.default_rng(20161202 + 1000 * rank)
+    pix = torch.randint(0, npix, (nt,), generator=gen, device=dev, dtype=torch.int32)
+    theta0 = float(rng.uniform(0, np.pi))
+    phi = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+    d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
+    bands = [toeplitz_band(lam, rng) for _ in range(nb)] if lam else None
+    diag = None if lam else rng.random(nb) + 0.5
+    return dict(gen=gen, rng=rng, theta0=theta0, pix=pix, phi=phi, d=d, bands=bands, diag=diag)
 
 
 def git_head():
@@ -146,6 +167,8 @@ def main():
     ap.add_argument("--lam", type=int, default=0, help="override the Toeplitz band length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the full-size comparison of the timed path with the CPU oracle")
     ap.add_argument("--no-raster", action="store_true",
                     help="skip the secondary run with a coherent raster-scan pointing")
     ap.add_argument("--no-filters", action="store_true",
@@ -226,9 +249,12 @@ def main():
     # ---- a rank's shard in one scaling mode, generated in HBM (seed differs per rank) -------
     def shard_geometry(scaling):
         """(samples, noise blocks) of this rank's shard."""
-        if scaling == "weak" or world == 1:
+        if scaling == "weak":
             nb = cfg["nb"]
             return (cfg["nt"] // nb) * nb, nb
+        # strong: the configuration's TOTAL cut into `world` block-aligned shards (world = 1: the
+        # whole of it on one GPU -- C5: 1e9 samples, 64 detector blocks; the N = 1 point of the
+        # strong-scaling series)
         tnb = cfg["total_nb"]
         bsz = cfg["total"] // tnb
         b0, b1, s0, s1 = shard_blocks([bsz] * tnb, world, rank)
@@ -239,23 +265,18 @@ def main():
         bsize = nt // nb
         tm = {}
         t0 = time.time()
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(20161202 + 1000 * rank)
-        rng = np.random.default_rng(20161202 + 1000 * rank)
-        pix = torch.randint(0, npix, (nt,), generator=gen, device=dev, dtype=torch.int32)
-        theta0 = float(rng.uniform(0, np.pi))
-        phi = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
-        d = torch.rand(nt, generator=gen, device=dev, dtype=torch.float64)
+        inp = synth_inputs(torch, dev, npix, nt, nb, lam, rank)
+        gen, rng, theta0, pix, d = (inp[k] for k in ("gen", "rng", "theta0", "pix", "d"))
+        phi = inp.pop("phi")
         sync()
         tm["generate_inputs"] = time.time() - t0
         t0 = time.time()
+        bands = inp["bands"]
         if lam:
-            bands = [toeplitz_band(lam, rng) for _ in range(nb)]
             N = BlockLO(bsize, bands, offdiag=True, method=(3 if args.toeplitz == "fused" else 2))
             w = None
         else:
-            bands = None
-            N = BlockLO(bsize, list(rng.random(nb) + 0.5), offdiag=False)
+            N = BlockLO(bsize, list(inp["diag"]), offdiag=False)
             w = N._device_diag()
         sync()
         tm["noise_operator"] = time.time() - t0
@@ -323,6 +344,9 @@ def main():
         del y
         return elapsed
 
+    if args.scaling == "strong" and cfg["total"] != cfg["nt"]:
+        cfg["label"] += " [strong scaling: the whole configuration, %d samples in %d blocks, over %d GPU(s)]" % (
+            cfg["total"], cfg["total_nb"], world)
     t_setup = time.time()
     S = build_shard(args.scaling)
     sync()
@@ -843,6 +867,58 @@ def main():
                                  "FFT convolution per noise block (scipy.signal.fftconvolve) on a "
                                  "thread pool" % (nsa, nblk)}
 
+    # ---- parity at full size: the timed operator against the CPU oracle on the SAME inputs -------
+    # (outside the timed region; rank 0 of a one-GPU run).  The inputs are generated again from the
+    # same seeds (the run's own pixel stream has been flagged and renumbered in place by now), copied
+    # to the host, and the oracle does ProcessTimeSamples, one A x, the right-hand side and the PCG
+    # solve with M_BD itself (oracle.HostProblem: serial reference-order loops for the weights and
+    # M_BD, all host threads for P / N^-1 / P^T).  north_star: maps within 1e-6 relative l2,
+    # identical iteration counts.
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu:
+        from oracle import oracle as orc
+        tq = time.perf_counter()
+        inp2 = synth_inputs(torch, dev, npix, nt, nb, lam, rank)
+        pix_h, phi_h, d_h = inp2["pix"].cpu().numpy(), inp2["phi"].cpu().numpy(), inp2["d"].cpu().numpy()
+        bands_h, diag_h = inp2["bands"], inp2["diag"]
+        del inp2
+        H = orc.HostProblem(pol, npix, pix_h, phi_h, bsize, bands=bands_h, diag=diag_h)
+        del phi_h
+        parity = {"oracle": "oracle.HostProblem: ProcessTimeSamples, M_BD serial (reference order); "
+                            "P / N^-1 / P^T on %d host threads" % H.threads,
+                  "same_observed_pixels": bool(H.n == npix_c)}
+        if H.n == npix_c:
+            hx = x.cpu().numpy()
+            t1 = time.perf_counter()
+            yo = H.A(hx)
+            t_mv = time.perf_counter() - t1
+            y = (A * x).cpu().numpy()
+            parity["matvec_rel_l2"] = float(np.linalg.norm(y - yo) / np.linalg.norm(yo))
+            parity["host_matvec_seconds"] = round(t_mv, 2)
+            del y, yo
+            if not args.no_pcg and pcg is not None and t_mv * (pcg["iters"] + 3) < 120.0:
+                bo = H.rhs(d_h)
+                b = P.T * (N * d)
+                parity["rhs_rel_l2"] = float(np.linalg.norm(b.cpu().numpy() - bo) / np.linalg.norm(bo))
+                xo, info_o, its_o = H.solve(bo, rtol=1e-6, maxiter=500)
+                itsg = []
+                xg, info_g = cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=500, callback=lambda xk: itsg.append(1))
+                parity["pcg_iters_gpu"] = len(itsg)
+                parity["pcg_iters_oracle"] = int(its_o)
+                parity["pcg_iters_identical"] = bool(len(itsg) == its_o and info_g == 0 and info_o == 0)
+                parity["map_rel_l2"] = float(np.linalg.norm(xg.cpu().numpy() - xo) / np.linalg.norm(xo))
+                del b, xg, xo, bo
+            else:
+                parity["pcg"] = "skipped (host solve would take %.0f s)" % (t_mv * ((pcg or {}).get("iters", 10) + 3))
+        parity["seconds"] = round(time.perf_counter() - tq, 1)
+        del H, pix_h, d_h
+
+    # device memory at the end of the run: what the library's objects hold, what it keeps cached, and
+    # torch's peak (the vectors of the solves and the TOD-sized scratch of the operator)
+    mem = (ctypes.c_int64 * 4)()
+    _hip.call("cm2_device_memory_info", mem)
+    memory = {"library_live_GB": round(mem[0] / 1e9, 3), "library_cached_GB": round(mem[1] / 1e9, 3),
+              "torch_peak_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3)}
     if rank == 0:
         out = {
             "metric": "TOD samples/s through P^T N^-1 P",
@@ -864,8 +940,10 @@ def main():
             "pcg": pcg,
             "raster_pointing": raster, "uneven_hit_map": uneven,
             "filters": filters,
+            "parity_full_size": parity,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
+            "hbm_memory": memory,
             "setup_seconds": round(t_setup, 2),
             "setup_split_seconds": {k: round(v, 3) for k, v in S_setup.items()},
             "commit": git_head(),

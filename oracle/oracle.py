@@ -687,3 +687,49 @@ class AllCoresMatvec(object):
 
     def __call__(self, x):
         return self.Pt(self.N(self.P(x)))
+
+
+# --------------------------------------------------------------------------
+# the whole solve on the host at a BASELINE configuration's full size (tests/test_gpu_fullsize.py,
+# bench.py's parity_full_size block): ProcessTimeSamples by the serial loops above, P^T N^-1 P by
+# AllCoresMatvec (checked against the serial loops in tests/test_oracle_golden.py), M_BD by the
+# serial per-pixel loop, PCG by `cg` above (scipy's recurrence).
+# --------------------------------------------------------------------------
+class HostProblem(object):
+    """CPU restatement of `A x = b`, A = P^T N^-1 P, b = P^T N^-1 d, M = M_BD for host copies of
+    the inputs: pix (int32, NOT yet flagged: flagged in place like the reference does,
+    process_ces.py:416), phi, d, and either `bands` (one first row per noise block, offdiag=True)
+    or `diag` (one weight per block, offdiag=False).  Call sites restated:
+    src/test_BD_precond_onto_real_data.py:31-47 (ProcessTimeSamples -> SparseLO -> BlockLO ->
+    BlockDiagonalPreconditionerLO -> cg)."""
+
+    def __init__(self, pol, npix, pix, phi, blocksize, bands=None, diag=None, threads=None):
+        if threads is None:
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count()
+        self.pol, self.threads = pol, int(threads)
+        pix = _i32(pix)
+        nt = pix.shape[0]
+        w = None
+        if bands is None:
+            w = blocklo_diag(blocksize, list(diag))            # BlockLO.diag feeds the weights (:677-683)
+        self.ro = process_time_samples(pix, npix, pol=pol, phi=phi, w=w)
+        self.n = self.ro.new_npix
+        self.A = AllCoresMatvec(pol, self.n, pix, self.ro.cos, self.ro.sin, blocksize, bands, self.threads,
+                                diag=w)
+        self.nt = nt
+
+    def M(self, v):
+        return bd_precond_mult(self.pol, self.ro, v)
+
+    def rhs(self, d):
+        return self.A.Pt(self.A.N(_f64(d)))
+
+    def solve(self, b, rtol=1e-6, maxiter=500):
+        """(x, info, iterations counted as callback invocations -- the way the reference's scripts
+        count them, src/test_BD_precond_onto_real_data.py:41-47)."""
+        its = []
+        x, info = cg(self.A, b, rtol=rtol, maxiter=maxiter, M=self.M, callback=lambda xk: its.append(1))
+        return x, info, len(its)
