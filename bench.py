@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--config", default=os.environ.get("CM2_BENCH_CONFIG", "c4"),
                     choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--layout", default="replicated", choices=["replicated", "rows"],
+                    help="N > 1: map-domain vectors replicated on every rank (one all-reduce of the map per "
+                         "matvec) or row-sharded (all-gather + reduce-scatter; M_BD, M2 and the vector updates "
+                         "on a rank's rows only); the other layout's step is measured too (other_layout_point)")
     ap.add_argument("--nt", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--lam", type=int, default=0, help="override the Toeplitz band length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -223,7 +227,8 @@ def main():
     from cosmomap2_amd.interfaces import SparseLO, BlockLO, BlockDiagonalPreconditionerLO
     from cosmomap2_amd.interfaces import linearoperators as L
     from cosmomap2_amd.utilities import ProcessTimeSamples
-    from cosmomap2_amd.sharding import ShardedLO, make_sync, shard_blocks
+    from cosmomap2_amd.sharding import (ShardedLO, make_sync, shard_blocks, RowShards, RowShardedNormalLO,
+                                        row_sharded_bd, row_sharded_two_level)
 
     cfg = dict(CONFIGS[args.config])
     if args.nt:
@@ -293,10 +298,16 @@ def main():
         sync()
         tm["pointing_operator_and_M_BD"] = time.time() - t0
         A_local = P.T * N * P
-        A = ShardedLO(A_local) if world > 1 else A_local
         n = pol * npix_c
         x = torch.rand(n, generator=torch.Generator(device=dev).manual_seed(7), device=dev,
                        dtype=torch.float64)
+        # the distributed operator in both layouts of the map-domain vectors (same seed on every rank:
+        # x is the same whole vector everywhere; x_rows = this rank's rows of it)
+        sh = RowShards(npix_c, pol) if world > 1 else None
+        A_repl = ShardedLO(A_local) if world > 1 else A_local
+        A_rows = RowShardedNormalLO(A_local, sh) if world > 1 else A_local
+        x_rows = sh.local(x) if world > 1 else x
+        A = A_rows if args.layout == "rows" else A_repl
         if lam and L._use_tiles(P):
             t0 = time.time()
             L._sparse_tiles(P)
@@ -318,7 +329,7 @@ def main():
         tm["steady_state_spinup"] = time.time() - t0
         return dict(nt=nt, nb=nb, bsize=bsize, pix=pix, d=d, bands=bands, N=N, w=w, ces=ces,
                     npix_c=npix_c, P=P, Mbd=Mbd, A_local=A_local, A=A, n=n, x=x, rng=rng,
-                    gen=gen, theta0=theta0, setup=tm)
+                    gen=gen, theta0=theta0, setup=tm, sh=sh, A_repl=A_repl, A_rows=A_rows, x_rows=x_rows)
 
     def timed(A, x, steps, warmup):
         for _ in range(warmup):
@@ -357,8 +368,10 @@ def main():
                                                                "d", "pix", "ces"))
     bands, w, gen, theta0 = S["bands"], S["w"], S["gen"], S["theta0"]
 
+    sh, rows = S["sh"], (args.layout == "rows" and world > 1)
+    x_in = S["x_rows"] if rows else x                # the vector the distributed operator acts on
     # ---- timed region: W warmup + exactly K steps ------------------------------------
-    elapsed = timed(A, x, args.steps, args.warmup)
+    elapsed = timed(A, x_in, args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
     nt_all = nt
     if world > 1:
@@ -372,12 +385,23 @@ def main():
     if world > 1:
         el_local = timed(A_local, x, args.steps, args.warmup)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "layout": args.layout,
                      "local_matvec_ms": round(1e3 * el_local / args.steps, 4),
-                     "exposed_allreduce_ms": round(ms_per_step - 1e3 * el_local / args.steps, 4),
-                     "allreduce_bytes": 8 * n,
-                     # the collective choice the operator made (max over ranks of the shard sizes)
-                     "allreduce_chunks": A.allreduce_chunks(nt),
-                     "map_allreduces_per_matvec": A.collectives_issued // (args.steps + args.warmup)}
+                     "exposed_collective_ms": round(ms_per_step - 1e3 * el_local / args.steps, 4)}
+        if rows:
+            dist_info.update({"collectives_per_matvec": "all-gather + reduce-scatter of %d rows per rank" % sh.rows,
+                              "bytes_sent_per_rank_per_matvec": sh.bytes_per_matvec()})
+        else:
+            dist_info.update({"allreduce_bytes": 8 * n,
+                              # the collective choice the operator made (max over ranks of the shard sizes)
+                              "allreduce_chunks": A.allreduce_chunks(nt),
+                              "map_allreduces_per_matvec": A.collectives_issued // (args.steps + args.warmup)})
+        # the same K steps in the OTHER layout of the map-domain vectors
+        A_o, x_o = (S["A_repl"], x) if rows else (S["A_rows"], S["x_rows"])
+        el_o = timed(A_o, x_o, args.steps, args.warmup)
+        dist_info["other_layout_point"] = {"layout": "replicated" if rows else "rows",
+                                           "ms_per_step": round(1e3 * el_o / args.steps, 4),
+                                           "value": nt_all / (el_o / args.steps), "unit": "TOD samples/s"}
 
     # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
     def ev_time(fn, reps):
@@ -525,7 +549,48 @@ def main():
 
     # ---- PCG iterations to 1e-6 (outside the timed region) ----------------------------
     pcg = None
-    if not args.no_pcg:
+    if not args.no_pcg and rows:
+        # PCG on row-sharded vectors: M_BD and the two-level preconditioner act on this rank's rows, the
+        # three dot products of an iteration are 8-byte all-reduces, Z^T r an r-vector all-reduce
+        from cosmomap2_amd.interfaces import ritz_deflation_basis
+        b_loc = sh.reduce_scatter(P.T * (N * d))
+        Mr = row_sharded_bd(ces, sh)
+
+        def solve(Mop):
+            cosmomap2_amd.cg(A, b_loc, M=Mop, rtol=1e-6, maxiter=1, dot_reduce=sh.allreduce_)
+            torch.cuda.synchronize()
+            best, its_ = float("inf"), []
+            for _ in range(2):
+                its_ = []
+                barrier()
+                tp = time.perf_counter()
+                xs_, info_ = cosmomap2_amd.cg(A, b_loc, M=Mop, rtol=1e-6, maxiter=500,
+                                              callback=lambda xk: its_.append(1), dot_reduce=sh.allreduce_)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - tp)
+            return xs_, int(info_), len(its_), best
+        xs, info, nit, t_pcg = solve(Mr)
+        pcg = {"rtol": 1e-6, "layout": "rows", "iters": nit, "info": info, "seconds": round(t_pcg, 4),
+               "ms_per_iteration": round(1e3 * t_pcg / max(1, nit), 4), "timed_runs": 2,
+               "preconditioner": "block-diagonal (a rank's pixels)"}
+        if lam and args.deflation > 0:
+            r = args.deflation
+            tz = time.perf_counter()
+            Zl, theta, AZl = ritz_deflation_basis(A, Mr, b_loc, r, args.arnoldi_steps, with_AZ=True, shards=sh)
+            M2 = row_sharded_two_level(Mr, Zl, AZl, sh, apply='eig')
+            torch.cuda.synchronize()
+            t_build = time.perf_counter() - tz
+            xs2, info2, nit2, t_pcg2 = solve(M2)
+            pcg["two_level"] = {"rank": r, "arnoldi_steps": args.arnoldi_steps, "iters": nit2, "info": info2,
+                                "seconds": round(t_pcg2, 4),
+                                "ms_per_iteration": round(1e3 * t_pcg2 / max(1, nit2), 4),
+                                "build_seconds": round(t_build, 3),
+                                "Z_rows_per_rank": int(sh.rows),
+                                "rel_l2_vs_block_diagonal_solution": float(
+                                    (sh.gather(xs2) - sh.gather(xs)).norm() / sh.gather(xs).norm())}
+            del Zl, AZl, M2, xs2
+        del b_loc, xs, Mr
+    elif not args.no_pcg:
         b = P.T * (N * d)
         if world > 1:
             dist.all_reduce(b)
@@ -795,7 +860,7 @@ def main():
         del A, A_local, P, N, Mbd, ces, x, d, pix, S
         torch.cuda.empty_cache()
         S2 = build_shard(other_mode)
-        el2 = timed(S2["A"], S2["x"], args.steps, args.warmup)
+        el2 = timed(S2["A"], S2["x_rows"] if rows else S2["x"], args.steps, args.warmup)
         el2_local = timed(S2["A_local"], S2["x"], args.steps, args.warmup)
         tot = torch.tensor([float(S2["nt"])], dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
@@ -930,7 +995,9 @@ def main():
                        "noise": ("toeplitz" if lam else "diag"),
                        "lambda": lam, "blocks_per_gpu": nb, "fft_len": fft_len,
                        "tile_plan": tile_info,
-                       "parallelism": "tod-shard x%d + map all-reduce" % world},
+                       "layout": args.layout if world > 1 else None,
+                       "parallelism": ("tod-shard x%d + map all-gather / reduce-scatter (row-sharded vectors)" % world
+                                       if rows else "tod-shard x%d + map all-reduce" % world)},
             "roofline": roofline,
             "step_algorithmic_GBps": round(step_gbs, 1),
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),

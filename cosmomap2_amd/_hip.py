@@ -25,6 +25,7 @@ PROTOTYPES = {
     "cm2_device_info": [_int, ctypes.c_char_p, ctypes.POINTER(_int), ctypes.POINTER(_dbl)],
     "cm2_release_cached_memory": [],
     "cm2_device_memory_info": [ctypes.POINTER(_i64)],
+    "cm2_set_exact_order": [_int],
     "cm2_pointing_create": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i64, _i64, _int, _vp],
     "cm2_pointing_destroy": [_vp],
     "cm2_pointing_info": [_vp, ctypes.POINTER(_i64)],

@@ -11,6 +11,9 @@
 namespace cm2 {
 
 void set_error(const char *fmt, ...);
+// cm2_set_exact_order: 1 = per-pixel sums in the reference's pure serial order everywhere, 0 = the
+// default fixed regroupings of very long runs, -1 = not set (CM2_PT_ORDER / CM2_WEIGHTS_ORDER decide)
+int exact_order_setting();
 
 // device memory of the library (cm2_core.hip): hipMalloc / hipFree semantics, freed blocks cached
 hipError_t dev_malloc_bytes(void **p, size_t bytes);

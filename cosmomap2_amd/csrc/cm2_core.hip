@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -27,7 +28,7 @@ void set_error(const char *fmt, ...)
 // therefore kept per device and handed out again: a request takes the smallest cached block of at
 // least its size and at most 25 % (+ 1 MB) more.  dev_free waits for the device like hipFree does,
 // so a block is never reused while a kernel that was given it may still run.  The cache is capped
-// (CM2_DEVICE_CACHE_MB, default 32768; 0 = no caching): beyond the cap the largest cached blocks go
+// (CM2_DEVICE_CACHE_MB, default: an eighth of the device memory; 0 = no caching): beyond the cap the largest cached blocks go
 // back to the driver.  cm2_release_cached_memory() returns everything.
 namespace {
 struct DevCache {
@@ -61,8 +62,19 @@ hipError_t dev_malloc_bytes(void **p, size_t bytes)
     {
         std::lock_guard<std::mutex> hold(c.lock);
         if (!c.cap_read) {
+            // default cap: an eighth of the device's memory (36 GB on an MI355X, 4 GB on a 32 GB card) --
+            // torch's allocator and other ranks share the device and know nothing of this pool
             const char *env = getenv("CM2_DEVICE_CACHE_MB");
-            c.cap = (size_t)(env ? atoll(env) : 32768) << 20;
+            if (env) {
+                c.cap = (size_t)atoll(env) << 20;
+            } else {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+                    (void)hipGetLastError();
+                    total_b = (size_t)32 << 30;
+                }
+                c.cap = total_b / 8;
+            }
             c.cap_read = true;
         }
         auto it = c.cached.lower_bound({dev, want});
@@ -139,7 +151,17 @@ extern "C" int cm2_release_cached_memory(void)
         c.cached.clear();
         c.cached_bytes = 0;
     }
-    for (void *q : all) CM2_HIP(hipFree(q));
+    // every block goes back to the driver; the first failure is reported afterwards
+    hipError_t first = hipSuccess;
+    for (void *q : all) {
+        const hipError_t e = hipFree(q);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    if (first != hipSuccess) {
+        (void)hipGetLastError();
+        cm2::set_error("cm2_release_cached_memory: hipFree failed: %s", hipGetErrorString(first));
+        return 1;
+    }
     return 0;
 }
 
@@ -152,6 +174,18 @@ extern "C" int cm2_device_memory_info(int64_t *h_info)
     h_info[1] = (int64_t)c.cached_bytes;
     h_info[2] = c.hits;
     h_info[3] = c.misses;
+    return 0;
+}
+
+// process-wide summation-order switch (cm2_set_exact_order): -1 = not set (environment decides)
+namespace cm2 {
+static std::atomic<int> g_exact_order{-1};
+int exact_order_setting() { return g_exact_order.load(); }
+}  // namespace cm2
+
+extern "C" int cm2_set_exact_order(int on)
+{
+    cm2::g_exact_order.store(on < 0 ? -1 : (on ? 1 : 0));
     return 0;
 }
 

@@ -407,11 +407,12 @@ extern "C" int cm2_noise_info(const cm2_noise *n, int64_t *h_info)
 extern "C" int cm2_noise_tile_kernel_info(const cm2_noise *n, int64_t *h_info, double *h_bytes_per_sample)
 {
     CM2_CHECK(n && h_info && h_bytes_per_sample, "cm2_noise_tile_kernel_info: NULL argument");
-    int kernel[2] = {0, 0};
+    int kernel[3] = {0, 0, 0};
     *h_bytes_per_sample = cm2::fused_os_tile_info(n->fused, kernel);
     h_info[0] = kernel[0];
     h_info[1] = kernel[1];
     h_info[2] = 512 * (int64_t)kernel[0];                 // window samples
+    h_info[3] = kernel[2];                                // windows straddling two spans of the plan
     return 0;
 }
 
@@ -512,6 +513,8 @@ extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t);
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t);
 extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t);
+extern "C" int64_t cm2_tiles_nspans(const cm2_tiles *t);
+extern "C" int64_t cm2_tiles_span_samples(const cm2_tiles *t);
 
 static int noise_tiles_ready(cm2_noise *n, const cm2_tiles *tiles, const char *who, void *stream_)
 {
@@ -538,6 +541,8 @@ static cm2::OsPlanView plan_view(const cm2_tiles *tiles)
     pv.plan_id = cm2_tiles_plan_id(tiles);
     pv.ntiles = cm2_tiles_ntiles(tiles);
     pv.nvalid = cm2_tiles_nvalid(tiles);
+    pv.nspans = cm2_tiles_nspans(tiles);
+    pv.span_samples = cm2_tiles_span_samples(tiles);
     return pv;
 }
 

@@ -13,8 +13,10 @@ struct FusedOS;
 // A tile-bucketed TOD order as the overlap-save kernel needs to know it (cm2_tiles fills one in).
 struct OsPlanView {
     const uint32_t *d_idx = nullptr;      // [nt] time sample -> address in the tile order (kInvalidSample: flagged)
-    const int64_t *d_tile_off = nullptr;  // [ntiles + 1] first address of every pixel tile (NULL: unknown --
-                                          // the lists are then sorted instead of written directly)
+    const int64_t *d_tile_off = nullptr;  // [nspans * ntiles + 1] first address of every segment (span, tile)
+                                          // (NULL: unknown -- the lists are then sorted, not written directly)
+    int64_t nspans = 1;                   // the order is [span][tile][time], a span = span_samples consecutive
+    int64_t span_samples = 0;             // time samples (cm2_tiles.h); one span: the global tile order
     uint64_t plan_id = 0;                 // identity of the plan: the lists an operator keeps are keyed on it
     int64_t ntiles = 0;                   // pixel tiles (bounds the address runs of a list; 0 = unknown)
     int64_t nvalid = 0;                   // doubles in the two tile-order buffers (0 = unknown)

@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256) void k_real_lists(const WinDesc *__restrict__ 
                                                      const int64_t *__restrict__ tile_off, int ntiles,
                                                      uint16_t *__restrict__ lq, uint32_t *__restrict__ lk,
                                                      ListHdr *__restrict__ hdrs, uint32_t *__restrict__ tabs,
-                                                     int rmax, uint32_t *__restrict__ max_runs)
+                                                     int rmax, uint32_t *__restrict__ max_runs, int64_t span_samples)
 {
     using G = Geo<PT>;
     constexpr int E = G::N / 256;                        // rows of 64 entries a wave handles at most
@@ -1011,6 +1011,12 @@ __global__ __launch_bounds__(256) void k_real_lists(const WinDesc *__restrict__ 
     const int len = G::list_len(l), quarter = len / 4, rows = quarter / 64;
     const WinDesc wd = wins[win];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (a plan ordered [span][tile][time]: the window lies in ONE span -- the caller keeps the windows
+    // that straddle two out of this builder -- and the tiles' first addresses are that span's)
+    {
+        const int64_t ts0 = wd.start - kHalo > wd.lo ? wd.start - kHalo : wd.lo;
+        tile_off += span_samples ? (ts0 / span_samples) * ntiles : 0;
+    }
     for (int b = t; b <= ntiles; b += 256) toff[b] = (uint32_t)tile_off[b];
     for (int b = t; b < ntiles; b += 256) {
         cnt[b] = 0;
@@ -1144,7 +1150,8 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
                                                       const int64_t *__restrict__ tile_off, int ntiles,
                                                       uint16_t *__restrict__ plist, uint32_t *__restrict__ flags,
                                                       IListHdr *__restrict__ hdrs, uint32_t *__restrict__ tabs,
-                                                      int rmax, uint32_t *__restrict__ max_runs, int threads)
+                                                      int rmax, uint32_t *__restrict__ max_runs, int threads,
+                                                      int64_t span_samples)
 {
     // threads: workgroup size of the kernel that will read the lists (256: k_os_real, 512: k_os_wide);
     // it fixes the slot order of a round (slot = 64 (E wave + u) + lane, E = round / threads)
@@ -1166,6 +1173,10 @@ __global__ __launch_bounds__(256) void k_real_ilists(const WinDesc *__restrict__
     const int rounds = l ? G::RR : 2, rows = len / 256, E = RL / threads, nw = threads / 64;
     const WinDesc wd = wins[win];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {
+        const int64_t ts0 = wd.start - kHalo > wd.lo ? wd.start - kHalo : wd.lo;   // (see k_real_lists)
+        tile_off += span_samples ? (ts0 / span_samples) * ntiles : 0;
+    }
     for (int b = t; b <= ntiles; b += 256) toff[b] = (uint32_t)tile_off[b];
     for (int b = t; b < ntiles; b += 256) {
         cnt[b] = 0;
@@ -1344,11 +1355,16 @@ constexpr int kPT = 32;                  // complex points per thread of the ker
 using G32 = Geo<kPT>;
 constexpr size_t kListCache = 3;         // tile plans whose lists one operator keeps (most recent first)
 
-// Address lists of one (noise operator, tile plan) pair.  Owned by a shared_ptr: an application
-// holds a reference while it launches, so a concurrent eviction cannot free lists that a launch is
-// about to use (dev_free waits for the device before a block can be handed out again).
-struct OsLists {
-    uint64_t plan_id = 0;
+// Address lists of one set of windows.  A plan ordered [span][tile][time] (cm2_tiles.h) has two sets:
+// the windows that lie inside ONE span -- all but one or two per span -- whose lists are written
+// directly from that span's segment table (at most one address run per tile), and the windows that
+// straddle a span boundary (two runs per tile: their run tables would double the LDS of every
+// workgroup of the launch), which get plain lists from the segmented sort and a small launch of
+// their own.  A plan with one span has the first set only.
+struct OsSet {
+    WinDesc *d_wins = nullptr;           // the set's windows (owned unless `borrowed`)
+    bool borrowed = false;
+    int64_t nwin = 0;
     int mode = 0;                        // 1 plain, 2 run-coded (cut by time), 3 inverse (cut by address)
     uint32_t *d_lst_k = nullptr;         // mode 1: addresses
     uint16_t *d_lst_q = nullptr;         // modes 1, 2: position of every slot; mode 3: slot of every position
@@ -1358,17 +1374,26 @@ struct OsLists {
     uint32_t *d_iflags = nullptr;        // mode 3: run-start bits, [list][round][thread]
     int rmax = 0;
     double bytes_per_window = 0.0;
-    ~OsLists()
+    ~OsSet()
     {
-        void *ptrs[] = {d_lst_k, d_lst_q, d_hdrs, d_tabs, d_ihdrs, d_iflags};
+        void *ptrs[] = {borrowed ? nullptr : d_wins, d_lst_k, d_lst_q, d_hdrs, d_tabs, d_ihdrs, d_iflags};
         for (void *q : ptrs)
             if (q) (void)cm2::dev_free(q);
     }
 };
 
+// The lists of one (noise operator, tile plan) pair.  Owned by a shared_ptr: an application holds a
+// reference while it launches, so a concurrent eviction cannot free lists that a launch is about to
+// use (dev_free waits for the device before a block can be handed out again).
+struct OsLists {
+    uint64_t plan_id = 0;
+    OsSet a, b;                          // windows inside one span (or all of them), straddling windows
+};
+
 struct FusedOS {
     int64_t nwin = 0;
     int64_t nb = 0;
+    std::vector<WinDesc> h_wins;
     WinDesc *d_wins = nullptr;
     double2 *d_AB = nullptr;
     double2 *d_W = nullptr;
@@ -1415,7 +1440,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda, const 
     if (const char *e = getenv("CM2_OS_LIST_CHUNK_PAIRS")) f->sort_chunk_windows = atoll(e);
     const int64_t nb = (int64_t)off.size() - 1;
     f->nb = nb;
-    std::vector<WinDesc> wins;
+    std::vector<WinDesc> &wins = f->h_wins;
     for (int64_t b = 0; b < nb; ++b)
         for (int64_t s0 = off[b]; s0 < off[b + 1]; s0 += G::HOP) {
             WinDesc wd;
@@ -1460,18 +1485,18 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda, const 
 }
 
 template <int MODE, bool BUF>
-static int os_launch_t(const FusedOS *f, const OsLists *ls, const double *d_v, double *d_out, uint32_t nbytes,
-                       hipStream_t stream)
+static int os_launch_t(const FusedOS *f, const WinDesc *d_wins, int64_t nwin, const OsSet *ls, const double *d_v,
+                       double *d_out, uint32_t nbytes, hipStream_t stream)
 {
     using G = G32;
     const int rmax = ls ? ls->rmax : 0;
     const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)rmax : 0);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<kPT, MODE, BUF>, lds, granted));
-    if (f->nwin == 0) return 0;
-    const int grid = (int)(((f->nwin + 7) / 8) * 8);       // whole rounds over the 8 XCDs
+    if (nwin == 0) return 0;
+    const int grid = (int)(((nwin + 7) / 8) * 8);          // whole rounds over the 8 XCDs
     k_os_real<kPT, MODE, BUF><<<grid, kT, lds, stream>>>(
-        f->d_wins, (int)f->nwin, f->d_W, f->d_W, f->d_AB, ls ? ls->d_lst_k : nullptr, ls ? ls->d_lst_q : nullptr,
+        d_wins, (int)nwin, f->d_W, f->d_W, f->d_AB, ls ? ls->d_lst_k : nullptr, ls ? ls->d_lst_q : nullptr,
         ls ? ls->d_hdrs : nullptr, ls ? ls->d_tabs : nullptr, rmax, d_v, d_out, nbytes, ls ? ls->d_ihdrs : nullptr,
         ls ? ls->d_iflags : nullptr OS_STAMP_ARG);
     CM2_LAUNCH_OK();
@@ -1480,28 +1505,29 @@ static int os_launch_t(const FusedOS *f, const OsLists *ls, const double *d_v, d
 
 // The kernel instance for a list format, a run-table size and a buffer size.  Buffers below 4 GB are
 // addressed through buffer descriptors (BUF), larger ones (or CM2_OS_FLAT) with flat addresses.
-static int os_launch(const FusedOS *f, const OsLists *ls, int64_t nvalid, const double *d_v, double *d_out,
+static int os_launch(const FusedOS *f, const OsSet *ls, int64_t nvalid, const double *d_v, double *d_out,
                      hipStream_t stream)
 {
+    if (ls->nwin == 0) return 0;
     const bool buf = nvalid > 0 && nvalid * 8 < (int64_t)0xFFFFFFF0u && !f->flat;
     const uint32_t nbytes = buf ? (uint32_t)(nvalid * 8) : 0u;
     // (the two run tables of a list pair live in LDS beside the 66 KB exchange buffer: 8 rmax bytes)
     if (ls->mode == 1)
-        return buf ? os_launch_t<1, true>(f, ls, d_v, d_out, nbytes, stream)
-                   : os_launch_t<1, false>(f, ls, d_v, d_out, 0, stream);
+        return buf ? os_launch_t<1, true>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<1, false>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, 0, stream);
     if (ls->mode == 3 && ls->rmax <= 8 * kT)
-        return buf ? os_launch_t<3, true>(f, ls, d_v, d_out, nbytes, stream)
-                   : os_launch_t<3, false>(f, ls, d_v, d_out, 0, stream);
+        return buf ? os_launch_t<3, true>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<3, false>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, 0, stream);
     if (ls->mode == 2 && ls->rmax <= 8 * kT)
-        return buf ? os_launch_t<2, true>(f, ls, d_v, d_out, nbytes, stream)
-                   : os_launch_t<2, false>(f, ls, d_v, d_out, 0, stream);
+        return buf ? os_launch_t<2, true>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, nbytes, stream)
+                   : os_launch_t<2, false>(f, ls->d_wins, ls->nwin, ls, d_v, d_out, 0, stream);
     set_error("fused overlap-save: run table of %d words per list does not fit the kernel", ls->rmax);
     return 2;
 }
 
 int fused_os_apply(const FusedOS *f, const double *d_v, double *d_out, hipStream_t stream)
 {
-    return os_launch_t<0, false>(f, nullptr, d_v, d_out, 0, stream);
+    return os_launch_t<0, false>(f, f->d_wins, f->nwin, nullptr, d_v, d_out, 0, stream);
 }
 
 // run-table words per list: one run per pixel tile at most (k_real_rc / k_real_lists)
@@ -1515,11 +1541,12 @@ static int os_rmax(int64_t ntiles)
 }
 
 // The lists straight from the tile plan's offsets (k_real_lists): no keys, no sort, no temporaries.
-static int os_build_lists_direct(const FusedOS *f, OsLists *ls, const OsPlanView &pv, bool want_rc, hipStream_t stream)
+static int os_build_lists_direct(const FusedOS *f, OsSet *ls, const OsPlanView &pv, bool want_rc, hipStream_t stream)
 {
     using G = G32;
-    const int64_t total = f->nwin * G::PER;
-    const int64_t nlists = f->nwin * G::NLIST;
+    const int64_t total = ls->nwin * G::PER;
+    const int64_t nlists = ls->nwin * G::NLIST;
+    const int64_t span = pv.nspans > 1 ? pv.span_samples : 0;
     CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
     const int rmax = os_rmax(pv.ntiles);
     // run-coded lists up to 8 table words per thread (2048 runs a list), plain lists beyond that
@@ -1533,15 +1560,15 @@ static int os_build_lists_direct(const FusedOS *f, OsLists *ls, const OsPlanView
         CM2_HIP(cm2::dev_malloc(&ls->d_hdrs, sizeof(ListHdr) * nlists));
         CM2_HIP(cm2::dev_malloc(&ls->d_tabs, sizeof(uint32_t) * nlists * rmax));
         CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<kPT, true>, lds, granted));
-        k_real_lists<kPT, true><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off,
+        k_real_lists<kPT, true><<<(unsigned)nlists, 256, lds, stream>>>(ls->d_wins, nlists, pv.d_idx, pv.d_tile_off,
                                                                        (int)pv.ntiles, ls->d_lst_q, nullptr, ls->d_hdrs,
-                                                                       ls->d_tabs, rmax, d_max);
+                                                                       ls->d_tabs, rmax, d_max, span);
     } else {
         CM2_HIP(cm2::dev_malloc(&ls->d_lst_k, sizeof(uint32_t) * total));
         CM2_HIP(ensure_dynamic_lds((const void *)k_real_lists<kPT, false>, lds, granted));
-        k_real_lists<kPT, false><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off,
+        k_real_lists<kPT, false><<<(unsigned)nlists, 256, lds, stream>>>(ls->d_wins, nlists, pv.d_idx, pv.d_tile_off,
                                                                         (int)pv.ntiles, ls->d_lst_q, ls->d_lst_k, nullptr,
-                                                                        nullptr, rmax, d_max);
+                                                                        nullptr, rmax, d_max, span);
     }
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
@@ -1561,11 +1588,11 @@ static int os_build_lists_direct(const FusedOS *f, OsLists *ls, const OsPlanView
 }
 
 // Inverse lists (k_real_ilists): needs the tile offsets and run tables that fit LDS (<= 2048 runs).
-static int os_build_ilists(const FusedOS *f, OsLists *ls, const OsPlanView &pv, hipStream_t stream)
+static int os_build_ilists(const FusedOS *f, OsSet *ls, const OsPlanView &pv, hipStream_t stream)
 {
     using G = G32;
-    const int64_t total = f->nwin * G::PER;
-    const int64_t nlists = f->nwin * 2;
+    const int64_t total = ls->nwin * G::PER;
+    const int64_t nlists = ls->nwin * 2;
     const int rmax = os_rmax(pv.ntiles);
     CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
     CM2_HIP(cm2::dev_malloc(&ls->d_ihdrs, sizeof(IListHdr) * nlists));
@@ -1577,9 +1604,9 @@ static int os_build_ilists(const FusedOS *f, OsLists *ls, const OsPlanView &pv, 
     const size_t lds = sizeof(uint32_t) * (size_t)(3 * pv.ntiles + 1 + 20 + 2 * kT);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_real_ilists<kPT>, lds, granted));
-    k_real_ilists<kPT><<<(unsigned)nlists, 256, lds, stream>>>(f->d_wins, nlists, pv.d_idx, pv.d_tile_off, (int)pv.ntiles,
+    k_real_ilists<kPT><<<(unsigned)nlists, 256, lds, stream>>>(ls->d_wins, nlists, pv.d_idx, pv.d_tile_off, (int)pv.ntiles,
                                                               ls->d_lst_q, ls->d_iflags, ls->d_ihdrs, ls->d_tabs, rmax,
-                                                              d_max, kT);
+                                                              d_max, kT, pv.nspans > 1 ? pv.span_samples : 0);
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
     CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1593,17 +1620,19 @@ static int os_build_ilists(const FusedOS *f, OsLists *ls, const OsPlanView &pv, 
 }
 
 // The lists from a segmented sort of (address, position) pairs: needs nothing but the index
-// (CM2_OS_LIST_BUILD=sort, a plan without tile offsets, or more tiles than the direct builders keep
-// in LDS).
-static int os_build_lists_sorted(const FusedOS *f, OsLists *ls, const OsPlanView &pv, bool want_rc, hipStream_t stream)
+// (CM2_OS_LIST_BUILD=sort, a plan without tile offsets, more tiles than the direct builders keep in
+// LDS, or the windows that straddle two spans of the plan).  `tile_runs`: an upper bound of the
+// address runs of a list (0: unknown) -- run-coded lists when want_rc and the bound fits the tables.
+static int os_build_lists_sorted(const FusedOS *f, OsSet *ls, const OsPlanView &pv, bool want_rc, int64_t tile_runs,
+                                 hipStream_t stream)
 {
     using G = G32;
-    const int64_t total = f->nwin * G::PER;
+    const int64_t total = ls->nwin * G::PER;
     CM2_HIP(cm2::dev_malloc(&ls->d_lst_k, sizeof(uint32_t) * total));
     CM2_HIP(cm2::dev_malloc(&ls->d_lst_q, sizeof(uint16_t) * total));
     int64_t chunk_w = ((int64_t)1 << 30) / G::PER;             // hipCUB counts items in int
     if (f->sort_chunk_windows > 0 && f->sort_chunk_windows < chunk_w) chunk_w = f->sort_chunk_windows;
-    const int64_t cw_max = f->nwin < chunk_w ? f->nwin : chunk_w;
+    const int64_t cw_max = ls->nwin < chunk_w ? ls->nwin : chunk_w;
     {
         DevTemp<uint32_t> keys_in;
         DevTemp<uint16_t> vals_in;
@@ -1618,9 +1647,9 @@ static int os_build_lists_sorted(const FusedOS *f, OsLists *ls, const OsPlanView
             nullptr, tb, keys_in.p, ls->d_lst_k, vals_in.p, ls->d_lst_q, (int)(cw_max * G::PER),
             (int)(G::NLIST * cw_max), seg_begin, seg_end, 0, 32, stream));
         CM2_HIP(d_temp.alloc(tb + 16));
-        for (int64_t p0 = 0; p0 < f->nwin; p0 += chunk_w) {
-            const int64_t nw = f->nwin - p0 < chunk_w ? f->nwin - p0 : chunk_w;
-            k_real_keys<kPT><<<grid_for(nw * G::PER), kBlock, 0, stream>>>(f->d_wins, p0, nw, pv.d_idx, keys_in, vals_in);
+        for (int64_t p0 = 0; p0 < ls->nwin; p0 += chunk_w) {
+            const int64_t nw = ls->nwin - p0 < chunk_w ? ls->nwin - p0 : chunk_w;
+            k_real_keys<kPT><<<grid_for(nw * G::PER), kBlock, 0, stream>>>(ls->d_wins, p0, nw, pv.d_idx, keys_in, vals_in);
             CM2_LAUNCH_OK();
             size_t tbc = tb;
             CM2_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(
@@ -1631,12 +1660,12 @@ static int os_build_lists_sorted(const FusedOS *f, OsLists *ls, const OsPlanView
     }
     ls->mode = 1;
     ls->bytes_per_window = 6.0 * G::PER;
-    const int64_t nlists = f->nwin * G::NLIST;
+    const int64_t nlists = ls->nwin * G::NLIST;
     if (want_rc) {
         // one run per pixel tile at most (k_real_rc): the run-table stride follows from the tile count;
         // the two window-half tables live in LDS beside the exchange buffer: run-coded lists only
         // up to 8 table words per thread (2048 runs a list), plain lists beyond that
-        const int rmax = os_rmax(pv.ntiles);
+        const int rmax = os_rmax(tile_runs);
         if (rmax <= 8 * kT) {
             DevTemp<uint32_t> d_max;
             CM2_HIP(d_max.alloc(1));
@@ -1685,22 +1714,50 @@ static int os_lists_for(FusedOS *f, const OsPlanView &pv, hipStream_t stream, st
     const int want = f->want_lists ? f->want_lists : (pv.ntiles >= 768 ? 3 : 2);
     std::shared_ptr<OsLists> ls = std::make_shared<OsLists>();
     ls->plan_id = pv.plan_id;
-    if (f->nwin == 0) {
-        ls->mode = 1;
+    const bool direct = !f->build_sort && pv.d_tile_off && pv.ntiles > 0 && pv.ntiles <= 4096;
+    // the two window sets: with several spans (and the direct builders, which look tiles up in ONE
+    // span's table) the windows that reach into two spans go to set b
+    std::vector<WinDesc> wa, wb;
+    if (pv.nspans > 1 && pv.span_samples > 0 && direct) {
+        for (const WinDesc &wd : f->h_wins) {
+            const int64_t t0 = wd.start - kHalo > wd.lo ? wd.start - kHalo : wd.lo;
+            const int64_t t1 = wd.start - kHalo + G32::W < wd.hi ? wd.start - kHalo + G32::W : wd.hi;
+            (t0 / pv.span_samples == (t1 - 1) / pv.span_samples ? wa : wb).push_back(wd);
+        }
+        ls->a.nwin = (int64_t)wa.size();
+        ls->b.nwin = (int64_t)wb.size();
+        for (int k = 0; k < 2; ++k) {
+            OsSet &st = k ? ls->b : ls->a;
+            const std::vector<WinDesc> &w = k ? wb : wa;
+            CM2_HIP(cm2::dev_malloc(&st.d_wins, sizeof(WinDesc) * (w.size() ? w.size() : 1)));
+            if (!w.empty())
+                CM2_HIP(hipMemcpyAsync(st.d_wins, w.data(), sizeof(WinDesc) * w.size(), hipMemcpyHostToDevice, stream));
+        }
+        CM2_HIP(hipStreamSynchronize(stream));               // (wa, wb are locals)
     } else {
-        CM2_CHECK(f->nwin * G32::NLIST < ((int64_t)1 << 31), "fused overlap-save: too many lists (%lld)",
-                  (long long)(f->nwin * G32::NLIST));
+        ls->a.d_wins = f->d_wins;
+        ls->a.borrowed = true;
+        ls->a.nwin = f->nwin;
+    }
+    CM2_CHECK(f->nwin * G32::NLIST < ((int64_t)1 << 31), "fused overlap-save: too many lists (%lld)",
+              (long long)(f->nwin * G32::NLIST));
+    if (ls->a.nwin == 0) {
+        ls->a.mode = 1;
+    } else {
         int rc;
-        if (!f->build_sort && pv.d_tile_off && pv.ntiles > 0 && pv.ntiles <= 4096) {
+        if (direct) {
             if (want == 3 && os_rmax(pv.ntiles) <= 8 * kT)
-                rc = os_build_ilists(f, ls.get(), pv, stream);
+                rc = os_build_ilists(f, &ls->a, pv, stream);
             else
-                rc = os_build_lists_direct(f, ls.get(), pv, want >= 2, stream);
+                rc = os_build_lists_direct(f, &ls->a, pv, want >= 2, stream);
         } else {
-            rc = os_build_lists_sorted(f, ls.get(), pv, want >= 2, stream);
+            // (a plan with several spans whose lists are sorted: up to two runs per tile)
+            rc = os_build_lists_sorted(f, &ls->a, pv, want >= 2, pv.ntiles * (pv.nspans > 1 ? 2 : 1), stream);
         }
         if (rc) return rc;                                   // (ls frees what it holds)
     }
+    if (ls->b.nwin > 0)
+        if (int rc = os_build_lists_sorted(f, &ls->b, pv, false, 0, stream)) return rc;
     f->cache.insert(f->cache.begin(), ls);
     while (f->cache.size() > kListCache) f->cache.pop_back();
     *out = ls;
@@ -1717,11 +1774,13 @@ int fused_os_apply_indexed(FusedOS *f, const OsPlanView &pv, const double *d_v, 
 {
     std::shared_ptr<OsLists> ls;
     if (int rc = os_lists_for(f, pv, stream, &ls)) return rc;
-    return os_launch(f, ls.get(), pv.nvalid, d_v, d_out, stream);
+    if (int rc = os_launch(f, &ls->a, pv.nvalid, d_v, d_out, stream)) return rc;
+    return os_launch(f, &ls->b, pv.nvalid, d_v, d_out, stream);
 }
 
 // kernel[0] = complex points per thread of the window kernel (32), kernel[1] = list format of the
-// most recently used plan (1 plain, 2 run-coded, 3 inverse; 0: no lists yet); returns the HBM bytes
+// most recently used plan (1 plain, 2 run-coded, 3 inverse; 0: no lists yet), kernel[2] = windows of
+// that plan that straddle two spans (plain lists, a launch of their own); returns the HBM bytes
 // per output sample the tile-order kernel is built to move (lists + gathered window + results)
 double fused_os_tile_info(const FusedOS *f_, int *kernel)
 {
@@ -1733,11 +1792,12 @@ double fused_os_tile_info(const FusedOS *f_, int *kernel)
     }
     if (kernel) {
         kernel[0] = f ? kPT : 0;
-        kernel[1] = ls ? ls->mode : 0;
+        kernel[1] = ls ? ls->a.mode : 0;
+        kernel[2] = ls ? (int)ls->b.nwin : 0;
     }
     if (!f) return 0.0;
     const double hop = (double)G32::HOP, win = (double)G32::W;
-    const double lists = ls && ls->bytes_per_window > 0 ? ls->bytes_per_window : 6.0 * (win + hop);
+    const double lists = ls && ls->a.bytes_per_window > 0 ? ls->a.bytes_per_window : 6.0 * (win + hop);
     return (lists + 8.0 * win + 8.0 * hop) / hop;
 }
 

@@ -188,6 +188,7 @@ extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const i
     int64_t hot_min = kWeightsHotMin;
     if (const char *e = getenv("CM2_WEIGHTS_ORDER"))
         if (strcmp(e, "exact") == 0) hot_min = INT64_MAX;
+    if (cm2::exact_order_setting() >= 0) hot_min = cm2::exact_order_setting() ? INT64_MAX : kWeightsHotMin;
     DevTemp<int32_t> d_hot_pix;
     DevTemp<unsigned int> d_hot_n;
     DevTemp<unsigned long long> d_hot_longest;

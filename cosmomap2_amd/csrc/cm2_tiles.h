@@ -13,6 +13,18 @@ struct cm2_tiles {
     std::vector<int64_t> tile_p0;   // [ntiles+1] first pixel of every tile (host)
     int64_t *d_tile_p0 = nullptr;
     int64_t ntiles = 0, nitems = 0;
+    // SPANS (round 4; OFF by default: see span_chunks in cm2_tiles.hip for what was measured).  The tile
+    // order can be cut in time: samples are then ordered [span][tile][time], a span
+    // being `span_samples` consecutive time samples (a whole number of the partition's 8192-sample
+    // chunks).  A window of the overlap-save kernel then finds its 16384 samples in ONE region of
+    // span_samples doubles (8 MB at C4) that the neighbouring windows consume while it is cache
+    // resident, instead of in one run per tile spread over the whole 0.8 GB buffer; P / P^T walk a
+    // tile's SEGMENTS (its samples of one span: ~2000 consecutive addresses) with the tile in LDS.
+    // nspans = 1 is the global tile order of rounds 1-3.  segment (span sp, tile b) = addresses
+    // [seg_off[sp * ntiles + b], seg_off[sp * ntiles + b + 1]).
+    int64_t nspans = 1, span_samples = 0;
+    std::vector<int64_t> seg_off;   // [nspans * ntiles + 1] (host)
+    int64_t *d_seg_off = nullptr;
     uint32_t *d_tb_dst = nullptr;   // [nt]
     uint16_t *d_pl = nullptr;       // [nvalid]
     double *d_cos = nullptr, *d_sin = nullptr;   // [nvalid]  (full-angle mode)
@@ -22,8 +34,11 @@ struct cm2_tiles {
     // sample in each of the two tile kernels
     bool half = false;
     double *d_half = nullptr;                    // [nvalid]
+    // work items of k_P_tiles / k_Pt_tiles: tile, spans [sp0, sp1) of it, clipped to the addresses
+    // [k0, k1) (a segment longer than the slice length is cut into several items)
     int32_t *d_item_tile = nullptr; // [nitems]
-    int64_t *d_item_k0 = nullptr;   // [nitems+1]  (k1 of item i = min(k0[i]+slice, tile end))
+    int2 *d_item_span = nullptr;    // [nitems] {sp0, sp1}
+    int64_t *d_item_k0 = nullptr;   // [nitems]
     int64_t *d_item_k1 = nullptr;
     std::vector<int64_t> tile_item0;   // [ntiles+1] first work item of every tile (host)
     // address-sorted lists of the windowed permutations (built on first use): for every window
@@ -41,9 +56,9 @@ struct cm2_tiles {
     int pt_fixed = 1;
     int fx_S = 0;
     int fx_failed = 0;       // a build of the fixed-order lists failed: not retried on every apply
-    std::vector<int64_t> tile_off;      // [ntiles+1] first TB position of every tile (host)
-    int64_t *d_tile_off = nullptr;
+    std::vector<int64_t> tile_count;    // [ntiles] valid samples of every tile (host)
     int64_t *d_fx_slice0 = nullptr;     // [ntiles+1] first slice of every tile
+    uint2 *d_fx_sk = nullptr;           // [nslices+1] {first TB position, samples} of every slice
     uint2 *d_fx_meta = nullptr;         // [nslices+1] {first group, first tail run | max level << 28}
     uint4 *d_fx_gent = nullptr;         // [ngroups] 4 entries: pl word | offset in slice << 16 | level << 28
     double *d_fx_ga = nullptr, *d_fx_gb = nullptr;   // [4 ngroups] half angle (or cos, sin)
@@ -68,5 +83,10 @@ int fx_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t
               int64_t tile_hi, hipStream_t stream);
 void fx_free(cm2_tiles *t);
 int64_t fx_designed_bytes(const cm2_tiles *t);
+// mean groups per slice of the fixed-order lists and the fraction of slices with more groups than the
+// workgroup has threads, counted on every 8th slice of the plan's segments (slice length: fx_max_slice)
+int fx_groups_estimate(const cm2_tiles *t, hipStream_t st, double *mean_groups, double *over);
+int fx_max_slice(const cm2_tiles *t);      // longest slice (samples) the fixed-order kernel's LDS budget allows
+bool fx_serial_build();                    // CM2_FX_BUILD=serial (the reference builders: global tile order only)
 }  // namespace cm2
 

@@ -131,9 +131,18 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const uint32_t *__restrict_
 constexpr int kSplitChunk = 8192;                        // samples per wave (rank fits 16 bits)
 constexpr int64_t kSplitMaxTiles = 8192;                 // 4 wave histograms of u16 in 64 KB of LDS
 
+// SPANS.  The counts are stored [span][tile][chunk of the span] (G chunks a span, the last span padded
+// with empty chunks): the same exclusive scan then yields the order [span][tile][time] -- every span
+// of G x 8192 consecutive time samples is partitioned by tile on its own, and segment (span, tile)
+// starts at base[(span * ntiles + tile) * G].  G = number of chunks (one span) is the global tile order.
+__host__ __device__ inline int64_t cnt_index(int64_t tile, int64_t chunk, int64_t ntiles, int64_t G)
+{
+    return ((chunk / G) * ntiles + tile) * G + chunk % G;
+}
+
 __global__ __launch_bounds__(256) void k_tile_rank(const int32_t *__restrict__ pix, int64_t nt, int tp,
                                                     const int64_t *__restrict__ p0, uint32_t ntiles,
-                                                    int64_t npix, int64_t nchunks,
+                                                    int64_t npix, int64_t nchunks, int64_t G,
                                                     uint32_t *__restrict__ packed,
                                                     uint32_t *__restrict__ cnt_t,
                                                     unsigned int *__restrict__ bad)
@@ -169,21 +178,22 @@ __global__ __launch_bounds__(256) void k_tile_rank(const int32_t *__restrict__ p
             packed[idx] = 0xFFFFFFFFu;
         }
     }
-    for (uint32_t b = lane; b < ntiles; b += 64) cnt_t[(int64_t)b * nchunks + c] = hist[b];
+    for (uint32_t b = lane; b < ntiles; b += 64) cnt_t[cnt_index(b, c, ntiles, G)] = hist[b];
     if (b_) atomicOr(bad, 1u);
 }
 
-// off[b] = first address of tile b (b <= ntiles: the last one is the number of valid samples)
-__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ base, int64_t nchunks,
-                                                       int64_t ntiles, int64_t *__restrict__ off)
+// off[s] = first address of segment s = span * ntiles + tile (s <= nsegs: the last one is the number of
+// valid samples)
+__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ base, int64_t G,
+                                                       int64_t nsegs, int64_t *__restrict__ off)
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= ntiles) off[b] = base[b * nchunks];
+    const int64_t sg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg <= nsegs) off[sg] = base[sg * G];
 }
 
 template <int POL, bool HALF>
 __global__ __launch_bounds__(256) void k_tile_place(
-    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t nchunks,
+    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t ntiles, int64_t G,
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ base,
     const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
     uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb,
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void k_tile_place(
             continue;
         }
         const int64_t tile = pk >> 16;
-        const uint32_t k = base[tile * nchunks + i / kSplitChunk] + (pk & 0xFFFFu);
+        const uint32_t k = base[cnt_index(tile, i / kSplitChunk, ntiles, G)] + (pk & 0xFFFFu);
         tb_dst[i] = k;
         const int32_t px = pix[i];
         uint16_t w = p0 ? (uint16_t)(px - p0[tile]) : (uint16_t)(px - (int32_t)tile * tp);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void k_tile_place(
 // one-array forms (pol = 1, half angles): 8192 doubles + 2 x 8192 words + two tables per tile.
 template <int POL>
 __global__ __launch_bounds__(256) void k_tile_place_staged(
-    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t nchunks, int ntiles,
+    int64_t nt, int tp, const int64_t *__restrict__ p0, int64_t G, int ntiles,
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ base,
     const int32_t *__restrict__ pix, const double *__restrict__ c, const double *__restrict__ s,
     uint32_t *__restrict__ tb_dst, uint16_t *__restrict__ pl, double *__restrict__ ctb)
@@ -246,7 +256,8 @@ __global__ __launch_bounds__(256) void k_tile_place_staged(
     const int per = (ntiles + 255) / 256;
     uint32_t mine = 0;
     for (int b = t * per; b < (t + 1) * per && b < ntiles; ++b) {
-        const uint32_t g0 = base[(int64_t)b * nchunks + ch], g1 = base[(int64_t)b * nchunks + ch + 1];
+        const int64_t ci = cnt_index(b, ch, ntiles, G);
+        const uint32_t g0 = base[ci], g1 = base[ci + 1];
         gbase[b] = g0;
         lbase[b] = g1 - g0;
         mine += g1 - g0;
@@ -396,11 +407,16 @@ __device__ __forceinline__ void tile_sample(const uint16_t *__restrict__ pl,
     }
 }
 
+constexpr int kSegBatch = 128;           // segments of a work item whose bounds are staged in LDS at a time
+
 // ------------------------------------------------------------------ P (TB) ------
-// one workgroup per work item = (tile, contiguous slice of its bucket)
+// one workgroup per work item = (tile, spans [sp0, sp1) of its samples, clipped to the addresses
+// [k0, k1)): the tile of x is staged once, the item's segments (one per span, ~2000 consecutive
+// addresses each; the whole bucket when the plan has one span) are streamed one after the other
 template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_P_tiles(
     const int64_t *__restrict__ tile_p0, const int32_t *__restrict__ item_tile,
+    const int2 *__restrict__ item_span, const int64_t *__restrict__ seg_off, int64_t ntiles,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
     const double *__restrict__ x, double *__restrict__ d_tb)
@@ -413,20 +429,66 @@ __global__ __launch_bounds__(1024) void k_P_tiles(
     const double *xs = x + p0 * POL;
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = xs[i];
     __syncthreads();
-    const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        int q;
-        double cc, ss;
-        tile_sample<POL, HALF>(pl, c, s, k, q, cc, ss);
-        double r = 0.0;
-        if (POL == 1) {
-            r += tile[q];
-        } else if (POL == 2) {
-            r += tile[2 * q] * cc + tile[2 * q + 1] * ss;
-        } else {
-            r += tile[3 * q] + tile[3 * q + 1] * cc + tile[3 * q + 2] * ss;
+    // The item's segments as ONE index space: their bounds are fetched together (a dependent load per
+    // segment in front of its samples cost 12 % at C4, and a raster scan -- most segments of a tile
+    // empty -- 10 %), scanned in LDS, and sample j of the item is sample j - pre[i] of segment i: no
+    // partly filled pass at the end of every segment.  Batches of kSegBatch segments.
+    __shared__ int64_t seg_k0[kSegBatch];
+    __shared__ uint32_t seg_pre[kSegBatch + 1];
+    const int2 spans = item_span[blockIdx.x];
+    const int64_t c0 = item_k0[blockIdx.x], c1 = item_k1[blockIdx.x];
+    if (spans.y - spans.x == 1) {                        // one segment (always, on the global tile order)
+        const int64_t a0 = seg_off[(int64_t)spans.x * ntiles + b], a1 = seg_off[(int64_t)spans.x * ntiles + b + 1];
+        const int64_t k0 = a0 > c0 ? a0 : c0, k1 = a1 < c1 ? a1 : c1;
+        for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+            int q;
+            double cc, ss;
+            tile_sample<POL, HALF>(pl, c, s, k, q, cc, ss);
+            double r = 0.0;
+            if (POL == 1) {
+                r += tile[q];
+            } else if (POL == 2) {
+                r += tile[2 * q] * cc + tile[2 * q + 1] * ss;
+            } else {
+                r += tile[3 * q] + tile[3 * q + 1] * cc + tile[3 * q + 2] * ss;
+            }
+            d_tb[k] = r;
         }
-        d_tb[k] = r;
+        return;
+    }
+    for (int sp0 = spans.x; sp0 < spans.y; sp0 += kSegBatch) {
+        const int ns = spans.y - sp0 < kSegBatch ? spans.y - sp0 : kSegBatch;
+        if ((int)threadIdx.x < ns) {
+            const int64_t a0 = seg_off[(int64_t)(sp0 + threadIdx.x) * ntiles + b];
+            const int64_t a1 = seg_off[(int64_t)(sp0 + threadIdx.x) * ntiles + b + 1];
+            const int64_t k0 = a0 > c0 ? a0 : c0, k1 = a1 < c1 ? a1 : c1;
+            seg_k0[threadIdx.x] = k0;
+            seg_pre[threadIdx.x + 1] = (uint32_t)(k1 > k0 ? k1 - k0 : 0);
+        }
+        if (threadIdx.x == 0) seg_pre[0] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < ns; ++i) seg_pre[i + 1] += seg_pre[i];
+        __syncthreads();
+        const uint32_t total = seg_pre[ns];
+        int si = 0;
+        for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) {
+            while (j >= seg_pre[si + 1]) ++si;
+            const int64_t k = seg_k0[si] + (int64_t)(j - seg_pre[si]);
+            int q;
+            double cc, ss;
+            tile_sample<POL, HALF>(pl, c, s, k, q, cc, ss);
+            double r = 0.0;
+            if (POL == 1) {
+                r += tile[q];
+            } else if (POL == 2) {
+                r += tile[2 * q] * cc + tile[2 * q + 1] * ss;
+            } else {
+                r += tile[3 * q] + tile[3 * q + 1] * cc + tile[3 * q + 2] * ss;
+            }
+            d_tb[k] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -434,6 +496,7 @@ __global__ __launch_bounds__(1024) void k_P_tiles(
 template <int POL, bool HALF>
 __global__ __launch_bounds__(1024) void k_Pt_tiles(
     const int64_t *__restrict__ tile_p0, const int32_t *__restrict__ item_tile,
+    const int2 *__restrict__ item_span, const int64_t *__restrict__ seg_off, int64_t ntiles,
     const int64_t *__restrict__ item_k0, const int64_t *__restrict__ item_k1,
     const uint16_t *__restrict__ pl, const double *__restrict__ c, const double *__restrict__ s,
     const double *__restrict__ v_tb, double *__restrict__ out)
@@ -445,7 +508,22 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
     const int64_t nvals = np * POL;
     for (int64_t i = threadIdx.x; i < nvals; i += blockDim.x) tile[i] = 0.0;
     __syncthreads();
-    const int64_t k0 = item_k0[blockIdx.x], k1 = item_k1[blockIdx.x];
+    __shared__ int64_t seg_b0[kSegBatch], seg_b1[kSegBatch];
+    const int2 spans = item_span[blockIdx.x];
+    const int64_t clip0 = item_k0[blockIdx.x], clip1 = item_k1[blockIdx.x];
+    for (int sp = spans.x; sp < spans.y; ++sp) {
+    // (the segment bounds of a batch are fetched together, not one dependent load per segment)
+    if ((sp - spans.x) % kSegBatch == 0) {
+        __syncthreads();
+        const int ns = spans.y - sp < kSegBatch ? spans.y - sp : kSegBatch;
+        if ((int)threadIdx.x < ns) {
+            seg_b0[threadIdx.x] = seg_off[(int64_t)(sp + threadIdx.x) * ntiles + b];
+            seg_b1[threadIdx.x] = seg_off[(int64_t)(sp + threadIdx.x) * ntiles + b + 1];
+        }
+        __syncthreads();
+    }
+    const int64_t a0 = seg_b0[(sp - spans.x) % kSegBatch], a1 = seg_b1[(sp - spans.x) % kSegBatch];
+    const int64_t k0 = a0 > clip0 ? a0 : clip0, k1 = a1 < clip1 ? a1 : clip1;
     constexpr int U = 4;                     // independent loads in flight per thread
     int64_t k = k0 + threadIdx.x;
     for (; k + (U - 1) * (int64_t)blockDim.x < k1; k += U * (int64_t)blockDim.x) {
@@ -486,6 +564,7 @@ __global__ __launch_bounds__(1024) void k_Pt_tiles(
             atomicAdd(&tile[3 * q + 1], v * c1);
             atomicAdd(&tile[3 * q + 2], v * s1);
         }
+    }
     }
     __syncthreads();
     double *o = out + p0 * POL;
@@ -615,13 +694,41 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t);
 extern "C" int cm2_tiles_destroy(cm2_tiles *t)
 {
     if (!t) return 0;
-    void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile,
-                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_tile_off, t->d_tile_p0};
+    void *ptrs[] = {t->d_tb_dst, t->d_pl, t->d_cos, t->d_sin, t->d_half, t->d_item_tile, t->d_item_span,
+                    t->d_item_k0, t->d_item_k1, t->d_perm_k, t->d_perm_q, t->d_seg_off, t->d_tile_p0};
     for (void *q : ptrs)
         if (q) (void)cm2::dev_free(q);
     cm2::fx_free(t);
     delete t;
     return 0;
+}
+
+// Chunks of 8192 samples per span (CM2_TILE_SPAN = samples per span; unset or 0: ONE span, the
+// global tile order -- the default).
+//
+// Measured at C4 on one box, same run (profiles/r04_spans_ab.md): with spans of ~9.4e5 samples (a
+// tile's segment = about one slice of the fixed-order P^T: 0.9 x longest slice x ntiles, the value
+// CM2_TILE_SPAN=auto selects) the overlap-save kernel goes from 0.770 to 0.735 ms -- its windows
+// find their samples in one cache-resident 8 MB region -- and k_P_tiles from 0.352 to 0.385 ms: its
+// three streams are cut into 4-15 KB pieces, one per segment.  Step 1.447-1.477 against 1.474 ms: no
+// net gain on the reference generator's uniform pointing, and a loss on a raster scan (1.38 -> 1.45 ms:
+// most segments of a tile are empty or long) and on the uneven hit maps (+1 %).  The probe that
+// preceded the implementation (profiles/r04_chunk_sizes_c4.jsonl, N^-1 alone on plain lists: 0.884 ->
+// 0.798 ms at 2^20 samples per span, 0.819 / 0.805 / 0.812 / 0.821 at 2^18 / 2^19 / 2^21 / 2^22) had
+// promised twice that on the overlap-save side.  The order is therefore OFF by default; everything
+// downstream of it (segment-walking P / P^T, per-slice addresses of the fixed-order lists, the two
+// window sets of the overlap-save lists) stays in place, tested, behind the switch.
+static int64_t span_chunks(const cm2_tiles *t, int64_t nchunks)
+{
+    const char *e = getenv("CM2_TILE_SPAN");
+    if (!e || cm2::fx_serial_build()) return nchunks;
+    int64_t span = atoll(e);
+    if (!strcmp(e, "auto")) span = (int64_t)(0.9 * (double)cm2::fx_max_slice(t)) * t->ntiles;
+    if (span <= 0) return nchunks;
+    int64_t G = (span + kSplitChunk / 2) / kSplitChunk;
+    if (G < 2) G = 2;                                    // (a window of 16384 samples touches <= 2 spans)
+    if (2 * G > nchunks) return nchunks;                 // fewer than two whole spans: not worth a cut
+    return G;
 }
 
 extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
@@ -646,6 +753,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     // order of the per-pixel sums of P^T: fixed (time order, reproducible; default) or atomic
     if (const char *e = getenv("CM2_PT_ORDER"))          // atomic | exact | fixed (default)
         t->pt_fixed = !strcmp(e, "atomic") ? 0 : (!strcmp(e, "exact") ? 2 : 1);
+    if (cm2::exact_order_setting() >= 0 && t->pt_fixed) t->pt_fixed = cm2::exact_order_setting() ? 2 : 1;
 
     // Stable partition of the samples by tile.  Default: the multisplit above (k_tile_rank, one
     // scan, k_tile_place).  With more tiles than its LDS histograms hold, or CM2_TILE_BUILD=sort:
@@ -655,6 +763,8 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     DevTemp<uint32_t> keys_in, keys_out, vals_in, tb_src;      // sort path
     DevTemp<uint32_t> packed, cnt_t;                           // multisplit: tile << 16 | rank; counts -> bases
     const int64_t nchunks = (nt + kSplitChunk - 1) / kSplitChunk;
+    int64_t G = nchunks;                                       // chunks per span (nchunks: one span)
+    int64_t G_override = 0;                                    // a span length corrected by the measured lists
     DevTemp<int64_t> d_off;
     DevTemp<char> d_temp;
     DevTemp<unsigned int> d_bad;
@@ -688,16 +798,17 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         return 0;
     };
     auto partition_split = [&](const int64_t *d_p0) -> int {
-        const int64_t ncnt = t->ntiles * nchunks + 1;          // (+1: the scan's last word = nvalid)
+        const int64_t ncnt = t->nspans * t->ntiles * G + 1;    // (+1: the scan's last word = nvalid)
         if (!packed.p) CM2_HIP(packed.alloc(nt));
         cnt_t.release();
         CM2_HIP(cnt_t.alloc(ncnt));
-        CM2_HIP(hipMemsetAsync(cnt_t.p + (ncnt - 1), 0, sizeof(uint32_t), stream));
+        // (the last span is padded to G chunks: the counts of chunks that do not exist stay 0)
+        CM2_HIP(hipMemsetAsync(cnt_t.p, 0, sizeof(uint32_t) * ncnt, stream));
         const size_t lds = sizeof(uint16_t) * 4 * (size_t)t->ntiles;
         static size_t granted[64] = {0};
         CM2_HIP(ensure_dynamic_lds((const void *)k_tile_rank, lds, granted));
         k_tile_rank<<<(unsigned)((nchunks + 3) / 4), 256, lds, stream>>>(
-            d_pix, nt, tile_pixels, d_p0, (uint32_t)t->ntiles, npix, nchunks, packed, cnt_t, d_bad);
+            d_pix, nt, tile_pixels, d_p0, (uint32_t)t->ntiles, npix, nchunks, G, packed, cnt_t, d_bad);
         CM2_LAUNCH_OK();
         CM2_CHECK(ncnt < ((int64_t)1 << 31), "cm2_tiles_create: %lld tile x chunk counts", (long long)ncnt);
         size_t tb = 0;
@@ -705,20 +816,35 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         d_temp.release();
         CM2_HIP(d_temp.alloc(tb + 16));
         CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb, cnt_t.p, cnt_t.p, (int)ncnt, stream));
-        k_tile_offsets<<<(int)((t->ntiles + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            cnt_t, nchunks, t->ntiles, d_off);
+        const int64_t nsegs = t->nspans * t->ntiles;
+        k_tile_offsets<<<(int)((nsegs + 1 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(cnt_t, G, nsegs, d_off);
         CM2_LAUNCH_OK();
         return 0;
     };
+    // `seg`: first address of every segment (span, tile); `off`: samples of every tile, as offsets
+    std::vector<int64_t> seg;
     auto partition = [&](const int64_t *d_p0) -> int {
         d_off.release();
-        CM2_HIP(d_off.alloc(t->ntiles + 1));
         sorted = use_sort || t->ntiles > kSplitMaxTiles || t->ntiles * nchunks + 1 >= ((int64_t)1 << 31);
+        // spans need the multisplit (its counts are what orders them) and the LDS builders of the
+        // fixed-order lists; the sort paths keep the global tile order
+        G = sorted ? nchunks : (G_override ? G_override : span_chunks(t, nchunks));
+        t->nspans = (nchunks + G - 1) / G;
+        if (t->nspans < 1) t->nspans = 1;
+        t->span_samples = G * kSplitChunk;
+        const int64_t nsegs = t->nspans * t->ntiles;
+        CM2_HIP(d_off.alloc(nsegs + 1));
         if (int rc = sorted ? partition_sort(d_p0) : partition_split(d_p0)) return rc;
-        off.assign((size_t)t->ntiles + 1, 0);
-        CM2_HIP(hipMemcpyAsync(off.data(), d_off, sizeof(int64_t) * (t->ntiles + 1),
-                               hipMemcpyDeviceToHost, stream));
+        seg.assign((size_t)nsegs + 1, 0);
+        CM2_HIP(hipMemcpyAsync(seg.data(), d_off, sizeof(int64_t) * (nsegs + 1), hipMemcpyDeviceToHost, stream));
         CM2_HIP(hipStreamSynchronize(stream));
+        off.assign((size_t)t->ntiles + 1, 0);
+        for (int64_t b = 0; b < t->ntiles; ++b) {
+            int64_t n = 0;
+            for (int64_t sp = 0; sp < t->nspans; ++sp)
+                n += seg[(size_t)(sp * t->ntiles + b + 1)] - seg[(size_t)(sp * t->ntiles + b)];
+            off[(size_t)b + 1] = off[(size_t)b] + n;
+        }
         return 0;
     };
     if (int rc = partition(nullptr)) return rc;
@@ -807,10 +933,17 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     CM2_HIP(hipMemcpy(t->d_tile_p0, t->tile_p0.data(), sizeof(int64_t) * (t->ntiles + 1),
                       hipMemcpyHostToDevice));
     t->nvalid = off[t->ntiles];
-    t->tile_off = off;
-    CM2_HIP(cm2::dev_malloc(&t->d_tile_off, sizeof(int64_t) * (t->ntiles + 1)));
-    CM2_HIP(hipMemcpyAsync(t->d_tile_off, d_off, sizeof(int64_t) * (t->ntiles + 1),
-                           hipMemcpyDeviceToDevice, stream));
+    auto publish_segments = [&]() -> int {
+        t->tile_count.assign((size_t)t->ntiles, 0);
+        for (int64_t b = 0; b < t->ntiles; ++b) t->tile_count[(size_t)b] = off[(size_t)b + 1] - off[(size_t)b];
+        t->seg_off = seg;
+        if (t->d_seg_off) (void)cm2::dev_free(t->d_seg_off);
+        t->d_seg_off = nullptr;
+        CM2_HIP(cm2::dev_malloc(&t->d_seg_off, sizeof(int64_t) * seg.size()));
+        CM2_HIP(hipMemcpyAsync(t->d_seg_off, d_off, sizeof(int64_t) * seg.size(), hipMemcpyDeviceToDevice, stream));
+        return 0;
+    };
+    if (int rc = publish_segments()) return rc;
 
     const int64_t nv = t->nvalid > 0 ? t->nvalid : 1;
     CM2_HIP(cm2::dev_malloc(&t->d_tb_dst, sizeof(uint32_t) * nt));
@@ -840,6 +973,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
             CM2_HIP(cm2::dev_malloc(&t->d_sin, sizeof(double) * nv));
         }
     }
+    auto place = [&]() -> int {
 #define CM2_TF(POL, HALF)                                                                      \
     do {                                                                                       \
         if (sorted)                                                                            \
@@ -854,11 +988,11 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
             static size_t granted[64] = {0};                                                   \
             CM2_HIP(ensure_dynamic_lds((const void *)k_tile_place_staged<POL>, lds, granted));  \
             k_tile_place_staged<POL><<<(unsigned)nchunks, 256, lds, stream>>>(                 \
-                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, nchunks, (int)t->ntiles,    \
+                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, G, (int)t->ntiles,          \
                 packed, cnt_t, d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl, t->d_half);          \
         } else                                                                                 \
             k_tile_place<POL, HALF><<<grid_for(nt), kBlock, 0, stream>>>(                      \
-                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, nchunks, packed, cnt_t,     \
+                nt, tile_pixels, balance ? t->d_tile_p0 : nullptr, t->ntiles, G, packed, cnt_t, \
                 d_pix, d_cos, d_sin, t->d_tb_dst, t->d_pl, HALF ? t->d_half : t->d_cos,        \
                 t->d_sin);                                                                     \
     } while (0)
@@ -867,27 +1001,78 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     else { if (t->half) CM2_TF(3, true); else CM2_TF(3, false); }
 #undef CM2_TF
     CM2_LAUNCH_OK();
+    return 0;
+    };
+    if (int rc = place()) return rc;
+    // Spans: the span length was chosen for segments of ~0.9 x (longest slice) samples, assuming the
+    // fixed-order P^T packs such a slice into fewer groups than the workgroup has threads.  A dense
+    // hit map (many hits per pixel and slice: long runs, more groups per sample) breaks that: the
+    // lists of a sample of the segments are counted (the counting pass of the list builder on every
+    // 8th slice) and, where the mean exceeds 0.95 x 512 groups or more than a tenth of the slices
+    // exceed 512, the span is shortened in proportion and the order rebuilt (3 ms at 1e8 samples).
+    if (t->nspans > 1 && t->pt_fixed && !G_override && getenv("CM2_TILE_SPAN") &&
+        !strcmp(getenv("CM2_TILE_SPAN"), "auto")) {
+        double mean = 0.0, over = 0.0;
+        if (int rc = cm2::fx_groups_estimate(t, stream, &mean, &over)) return rc;
+        double shrink = 1.0;
+        if (mean > 0.95 * 512.0) shrink = 0.92 * 512.0 / mean;
+        if (over > 0.10 && shrink > 0.875) shrink = 0.875;
+        if (shrink < 1.0) {
+            G_override = (int64_t)((double)G * shrink);
+            if (G_override < 2) G_override = 2;
+            if (int rc = partition(balance ? d_p0.p : nullptr)) return rc;
+            if (int rc = publish_segments()) return rc;
+            if (int rc = place()) return rc;
+        }
+    }
 
-    // work items: every tile bucket cut into slices of <= slice_samples
+    // work items: a tile's segments in span order, gathered until they hold >= slice_samples samples; a
+    // segment longer than that (one span: the whole bucket) is cut into address ranges
     std::vector<int32_t> it_tile;
+    std::vector<int2> it_span;
     std::vector<int64_t> it_k0, it_k1;
     t->tile_item0.assign((size_t)t->ntiles + 1, 0);
     for (int64_t b = 0; b < t->ntiles; ++b) {
         t->tile_item0[(size_t)b] = (int64_t)it_tile.size();
-        for (int64_t k = off[b]; k < off[b + 1]; k += slice_samples) {
-            it_tile.push_back((int32_t)b);
-            it_k0.push_back(k);
-            it_k1.push_back(k + slice_samples < off[b + 1] ? k + slice_samples : off[b + 1]);
+        int64_t sp = 0;
+        while (sp < t->nspans) {
+            const int64_t a0 = seg[(size_t)(sp * t->ntiles + b)], a1 = seg[(size_t)(sp * t->ntiles + b + 1)];
+            if (a1 - a0 > slice_samples) {
+                for (int64_t k = a0; k < a1; k += slice_samples) {
+                    it_tile.push_back((int32_t)b);
+                    it_span.push_back(make_int2((int)sp, (int)sp + 1));
+                    it_k0.push_back(k);
+                    it_k1.push_back(k + slice_samples < a1 ? k + slice_samples : a1);
+                }
+                ++sp;
+                continue;
+            }
+            int64_t n = 0, e = sp;
+            while (e < t->nspans) {
+                const int64_t len = seg[(size_t)(e * t->ntiles + b + 1)] - seg[(size_t)(e * t->ntiles + b)];
+                if (len > slice_samples || (n > 0 && n + len > slice_samples)) break;
+                n += len;
+                ++e;
+            }
+            if (n > 0) {
+                it_tile.push_back((int32_t)b);
+                it_span.push_back(make_int2((int)sp, (int)e));
+                it_k0.push_back(0);
+                it_k1.push_back(INT64_MAX);
+            }
+            sp = e;
         }
     }
     t->tile_item0[(size_t)t->ntiles] = (int64_t)it_tile.size();
     t->nitems = (int64_t)it_tile.size();
     const int64_t ni = t->nitems > 0 ? t->nitems : 1;
     CM2_HIP(cm2::dev_malloc(&t->d_item_tile, sizeof(int32_t) * ni));
+    CM2_HIP(cm2::dev_malloc(&t->d_item_span, sizeof(int2) * ni));
     CM2_HIP(cm2::dev_malloc(&t->d_item_k0, sizeof(int64_t) * ni));
     CM2_HIP(cm2::dev_malloc(&t->d_item_k1, sizeof(int64_t) * ni));
     if (t->nitems) {
         CM2_HIP(hipMemcpy(t->d_item_tile, it_tile.data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
+        CM2_HIP(hipMemcpy(t->d_item_span, it_span.data(), sizeof(int2) * ni, hipMemcpyHostToDevice));
         CM2_HIP(hipMemcpy(t->d_item_k0, it_k0.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
         CM2_HIP(hipMemcpy(t->d_item_k1, it_k1.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
     }
@@ -904,6 +1089,7 @@ extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
     h_info[3] = t->ntiles; h_info[4] = t->nitems; h_info[5] = t->half ? 1 : 0;
     h_info[6] = t->pt_fixed; h_info[7] = (int64_t)t->plan_id;
     h_info[8] = t->fx_S; h_info[9] = cm2::fx_designed_bytes(t);
+    h_info[10] = t->nspans; h_info[11] = t->span_samples;
     return 0;
 }
 
@@ -924,8 +1110,11 @@ extern "C" int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed)
 extern "C" uint64_t cm2_tiles_plan_id(const cm2_tiles *t) { return t ? t->plan_id : 0; }
 extern "C" int64_t cm2_tiles_ntiles(const cm2_tiles *t) { return t ? t->ntiles : 0; }
 extern "C" int64_t cm2_tiles_nvalid(const cm2_tiles *t) { return t ? t->nvalid : 0; }
-// first tile-order address of every tile, [ntiles + 1] on the device (internal: cm2_noise.hip)
-extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t) { return t ? t->d_tile_off : nullptr; }
+// first tile-order address of every segment (span, tile), [nspans * ntiles + 1] on the device, and the
+// samples per span (internal: cm2_noise.hip)
+extern "C" const int64_t *cm2_tiles_offsets(const cm2_tiles *t) { return t ? t->d_seg_off : nullptr; }
+extern "C" int64_t cm2_tiles_nspans(const cm2_tiles *t) { return t ? t->nspans : 1; }
+extern "C" int64_t cm2_tiles_span_samples(const cm2_tiles *t) { return t ? t->span_samples : 0; }
 
 // Tile indices bounding `ngroups` consecutive groups of tiles whose PIXEL boundaries are the same on
 // every rank of a sharded run (ranks with different hit maps may have cut their tiles differently):
@@ -978,8 +1167,8 @@ extern "C" int cm2_P_tiles_apply(const cm2_tiles *t, const double *d_x, double *
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PT(POL, HALF)                                                                      \
     k_P_tiles<POL, HALF><<<(int)t->nitems, tile_block(true), lds, stream>>>(                       \
-        t->d_tile_p0, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
-        HALF ? t->d_half : t->d_cos, t->d_sin, d_x, d_tod_tb)
+        t->d_tile_p0, t->d_item_tile, t->d_item_span, t->d_seg_off, t->ntiles, t->d_item_k0,   \
+        t->d_item_k1, t->d_pl, HALF ? t->d_half : t->d_cos, t->d_sin, d_x, d_tod_tb)
     if (t->pol == 1) CM2_PT(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PT(2, true); else CM2_PT(2, false); }
     else { if (t->half) CM2_PT(3, true); else CM2_PT(3, false); }
@@ -1001,8 +1190,8 @@ extern "C" int cm2_Pt_tiles_apply(const cm2_tiles *t, const double *d_tod_tb, do
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PTT(POL, HALF)                                                                     \
     k_Pt_tiles<POL, HALF><<<(int)t->nitems, tile_block(), lds, stream>>>(                      \
-        t->d_tile_p0, t->d_item_tile, t->d_item_k0, t->d_item_k1, t->d_pl,                   \
-        HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
+        t->d_tile_p0, t->d_item_tile, t->d_item_span, t->d_seg_off, t->ntiles, t->d_item_k0,   \
+        t->d_item_k1, t->d_pl, HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
     if (t->pol == 1) CM2_PTT(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PTT(2, true); else CM2_PTT(2, false); }
     else { if (t->half) CM2_PTT(3, true); else CM2_PTT(3, false); }
@@ -1030,8 +1219,9 @@ extern "C" int cm2_Pt_tiles_apply_range(const cm2_tiles *t, const double *d_tod_
     const size_t lds = sizeof(double) * t->tp * t->pol;
 #define CM2_PTR(POL, HALF)                                                                     \
     k_Pt_tiles<POL, HALF><<<(int)(i1 - i0), tile_block(), lds, stream>>>(                      \
-        t->d_tile_p0, t->d_item_tile + i0, t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl,    \
-        HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, d_out)
+        t->d_tile_p0, t->d_item_tile + i0, t->d_item_span + i0, t->d_seg_off, t->ntiles,      \
+        t->d_item_k0 + i0, t->d_item_k1 + i0, t->d_pl, HALF ? t->d_half : t->d_cos, t->d_sin,  \
+        d_tod_tb, d_out)
     if (t->pol == 1) CM2_PTR(1, false);
     else if (t->pol == 2) { if (t->half) CM2_PTR(2, true); else CM2_PTR(2, false); }
     else { if (t->half) CM2_PTR(3, true); else CM2_PTR(3, false); }

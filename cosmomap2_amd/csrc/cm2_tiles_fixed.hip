@@ -68,7 +68,7 @@ constexpr int kFxMaxChunks = 128;       // per slice: S / kFxChunk + long runs <
 // ------------------------------------------------------------------- kernel --------
 template <int POL, bool HALF, int VPT>
 __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
-    int tp, const int64_t *__restrict__ tile_p0, int tile0, int S, const int64_t *__restrict__ tile_off,
+    int tp, const int64_t *__restrict__ tile_p0, int tile0, const uint2 *__restrict__ sk,
     const int64_t *__restrict__ slice0, const uint2 *__restrict__ meta,
     const uint4 *__restrict__ gent, const double2 *__restrict__ ga,
     const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     const int64_t np = tile_p0[b + 1] - p0;
     const int nvals = (int)(np * POL);
     for (int i = tid; i < nvals; i += kFxT) tile[i] = 0.0;
-    const int64_t k_begin = tile_off[b], k_end = tile_off[b + 1];
     const int64_t s0 = slice0[b];
     const int nsl = (int)(slice0[b + 1] - s0);
 
@@ -108,11 +107,12 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     uint2 pm[D][2];                                      // meta of slice j and j + 1
     // {first group, first tail run} of the NEXT slice to fetch and of its successor: loaded one
     // fetch ahead, so that the group addresses never wait for them
-    uint2 nx0 = meta[s0], nx1 = meta[s0 + (nsl > 0 ? 1 : 0)];
+    // ... and {first TB address, samples} of it: the slices of a tile are its segments (one per span
+    // of the plan, cut where longer than the slice length), not consecutive addresses
+    uint2 nx0 = meta[s0], nx1 = meta[s0 + (nsl > 0 ? 1 : 0)], nk = sk[s0];
     auto fetch = [&](int slot, int j) {
-        const int jc = j < nsl ? j : nsl - 1;
-        const int64_t kb = k_begin + (int64_t)jc * S;
-        const int len = (int)((k_end - kb < S) ? k_end - kb : S);
+        const int64_t kb = (int64_t)nk.x;
+        const int len = (int)nk.y;
         const uint2 m0 = nx0, m1 = nx1;
         pm[slot][0] = m0;
         pm[slot][1] = m1;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
             const int jn = j + 1 < nsl ? j + 1 : nsl - 1;
             nx0 = meta[s0 + jn];
             nx1 = meta[s0 + jn + 1];
+            nk = sk[s0 + jn];
         }
         const uint32_t G = m1.x - m0.x;
         const int64_t g = (int64_t)m0.x + ((uint32_t)tid < G ? tid : 0);
@@ -806,13 +807,17 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
     std::vector<int64_t> range, tiles;
     t->hot_chunk0.assign(1, 0);
     for (int64_t b = 0; b < t->ntiles; ++b) {
-        const int64_t n = t->tile_off[(size_t)b + 1] - t->tile_off[(size_t)b];
+        const int64_t n = t->tile_count[(size_t)b];
         if (t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b] != 1 || n < kHotMin) continue;
         flag[(size_t)b] = 1;
         const int64_t c0 = (int64_t)range.size() / 2;
-        for (int64_t k = t->tile_off[(size_t)b]; k < t->tile_off[(size_t)b + 1]; k += kHotChunk) {
-            range.push_back(k);
-            range.push_back(k + kHotChunk < t->tile_off[(size_t)b + 1] ? k + kHotChunk : t->tile_off[(size_t)b + 1]);
+        // (ranges in time order: span after span, kHotChunk consecutive samples of a segment each)
+        for (int64_t sp = 0; sp < t->nspans; ++sp) {
+            const int64_t a0 = t->seg_off[(size_t)(sp * t->ntiles + b)], a1 = t->seg_off[(size_t)(sp * t->ntiles + b + 1)];
+            for (int64_t k = a0; k < a1; k += kHotChunk) {
+                range.push_back(k);
+                range.push_back(k + kHotChunk < a1 ? k + kHotChunk : a1);
+            }
         }
         tiles.push_back(t->tile_p0[(size_t)b]);
         tiles.push_back(c0);
@@ -854,7 +859,7 @@ int hot_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_
 void fx_release(cm2_tiles *t)
 {
     hot_release(t);
-    void **ptrs[] = {(void **)&t->d_fx_slice0, (void **)&t->d_fx_meta, (void **)&t->d_fx_gent,
+    void **ptrs[] = {(void **)&t->d_fx_slice0, (void **)&t->d_fx_sk, (void **)&t->d_fx_meta, (void **)&t->d_fx_gent,
                      (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
                      (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb};
     for (void **q : ptrs) {
@@ -868,8 +873,37 @@ void fx_release(cm2_tiles *t)
 // a tile that k_Pt_hot takes over (hot_plan): its slices do not count when the slice length is tuned
 static bool fx_hot_tile(const cm2_tiles *t, int64_t b)
 {
-    return t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b] == 1 &&
-           t->tile_off[(size_t)b + 1] - t->tile_off[(size_t)b] >= kHotMin;
+    return t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b] == 1 && t->tile_count[(size_t)b] >= kHotMin;
+}
+
+// The slices of the plan for the slice length S, as (first address, end) pairs in the order the
+// kernel walks them: tile after tile, a tile's segments span after span (= in time), a segment cut
+// where it is longer than S -- into pieces of S with a shorter last one when the plan has one span
+// (the tile's whole bucket is one segment: rounds 1-3), into equal pieces otherwise (a segment is
+// about one slice long by the choice of the span: cutting 2100 samples into 1856 + 244 would cost a
+// whole barrier round for the short piece).  slice0[b] = first slice of tile b.
+static void fx_slices(const cm2_tiles *t, int S, std::vector<int64_t> &slice0, std::vector<int64_t> &pairs)
+{
+    slice0.assign((size_t)t->ntiles + 1, 0);
+    pairs.clear();
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        slice0[(size_t)b] = (int64_t)pairs.size() / 2;
+        for (int64_t sp = 0; sp < t->nspans; ++sp) {
+            const int64_t a0 = t->seg_off[(size_t)(sp * t->ntiles + b)], a1 = t->seg_off[(size_t)(sp * t->ntiles + b + 1)];
+            if (a1 <= a0) continue;
+            int64_t piece = S;
+            if (t->nspans > 1) {
+                const int64_t np = (a1 - a0 + S - 1) / S;
+                piece = ((a1 - a0 + np - 1) / np + 63) / 64 * 64;
+                if (piece > S) piece = S;
+            }
+            for (int64_t k = a0; k < a1; k += piece) {
+                pairs.push_back(k);
+                pairs.push_back(k + piece < a1 ? k + piece : a1);
+            }
+        }
+    }
+    slice0[(size_t)t->ntiles] = (int64_t)pairs.size() / 2;
 }
 
 static bool fx_serial()
@@ -885,15 +919,20 @@ int fx_estimate(const cm2_tiles *t, int S, hipStream_t st, double *mean_groups, 
 {
     *mean_groups = 0.0;
     *over = 0.0;
-    std::vector<int64_t> pairs;
+    std::vector<int64_t> pairs, slice0, all;
+    fx_slices(t, S, slice0, all);
     int64_t seen = 0;
+    // (one span: the full slices of S samples; several spans: a slice is a segment, all of them count)
     for (int64_t b = 0; b < t->ntiles; ++b) {
         if (fx_hot_tile(t, b)) continue;
-        for (int64_t k = t->tile_off[(size_t)b]; k + S <= t->tile_off[(size_t)b + 1]; k += S)
+        for (int64_t sl = slice0[(size_t)b]; sl < slice0[(size_t)b + 1]; ++sl) {
+            const int64_t k = all[(size_t)(2 * sl)], e = all[(size_t)(2 * sl + 1)];
+            if (t->nspans == 1 && e - k != S) continue;
             if (seen++ % 8 == 0) {
                 pairs.push_back(k);
-                pairs.push_back(k + S);
+                pairs.push_back(e);
             }
+        }
     }
     const int64_t np = (int64_t)pairs.size() / 2;
     if (np == 0) return 0;
@@ -929,16 +968,19 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
 {
     fx_release(t);
     const int64_t nv = t->nvalid;
-    std::vector<int64_t> slice0((size_t)t->ntiles + 1, 0), k0;
-    for (int64_t b = 0; b < t->ntiles; ++b) {
-        const int64_t lo = t->tile_off[(size_t)b], hi = t->tile_off[(size_t)b + 1];
-        slice0[(size_t)b + 1] = slice0[(size_t)b] + (hi - lo + S - 1) / S;
-        for (int64_t k = lo; k < hi; k += S) k0.push_back(k);
-    }
+    std::vector<int64_t> slice0, k0;                 // k0: (first address, end) of every slice
+    fx_slices(t, S, slice0, k0);
     const int64_t nslices = slice0[(size_t)t->ntiles];
-    k0.push_back(nv);
-    // (a tile's last slice ends where the next tile's first one starts: k0 is the cut list)
     CM2_CHECK(nslices < ((int64_t)1 << 31), "cm2_tiles: too many slices");
+    {
+        std::vector<uint2> sk((size_t)nslices + 1, make_uint2(0, 0));
+        for (int64_t i = 0; i < nslices; ++i)
+            sk[(size_t)i] = make_uint2((uint32_t)k0[(size_t)(2 * i)], (uint32_t)(k0[(size_t)(2 * i + 1)] - k0[(size_t)(2 * i)]));
+        CM2_HIP(cm2::dev_malloc(&t->d_fx_sk, sizeof(uint2) * sk.size()));
+        CM2_HIP(hipMemcpyAsync(t->d_fx_sk, sk.data(), sizeof(uint2) * sk.size(), hipMemcpyHostToDevice, st));
+        CM2_HIP(hipStreamSynchronize(st));           // (sk is a local)
+    }
+    if (k0.empty()) { k0.push_back(0); k0.push_back(0); }
     CM2_HIP(cm2::dev_malloc(&t->d_fx_slice0, sizeof(int64_t) * slice0.size()));
     CM2_HIP(hipMemcpyAsync(t->d_fx_slice0, slice0.data(), sizeof(int64_t) * slice0.size(),
                            hipMemcpyHostToDevice, st));
@@ -955,6 +997,16 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         DevTemp<char> d_temp;
         CM2_HIP(d_k0.alloc(k0.size()));
         CM2_HIP(hipMemcpyAsync(d_k0, k0.data(), sizeof(int64_t) * k0.size(), hipMemcpyHostToDevice, st));
+        // (k_fx_pack, the serial builder of the global order, reads the slices as a cut list: slice s =
+        //  [cut[s], cut[s + 1]))
+        DevTemp<int64_t> d_k0s;
+        std::vector<int64_t> cuts;
+        if (fx_serial() || S > kFbMaxS) {
+            for (int64_t i = 0; i < nslices; ++i) cuts.push_back(k0[(size_t)(2 * i)]);
+            cuts.push_back(nv);
+            CM2_HIP(d_k0s.alloc(cuts.size()));
+            CM2_HIP(hipMemcpyAsync(d_k0s, cuts.data(), sizeof(int64_t) * cuts.size(), hipMemcpyHostToDevice, st));
+        }
         CM2_HIP(ent.alloc(nv));
         CM2_HIP(d_counts.alloc(4 * nslices));
         CM2_HIP(d_overflow.alloc(1));
@@ -968,7 +1020,8 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             CM2_HIP(keys_in.alloc(nv));
             CM2_HIP(keys_out.alloc(nv));
             CM2_HIP(vals_in.alloc(nv));
-            k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_tile_off,
+            CM2_CHECK(t->nspans == 1, "cm2_tiles: the serial list builders need the global tile order");
+            k_fx_keys<<<grid_for(nv), kBlock, 0, st>>>(nv, t->ntiles, S, qmask, t->d_seg_off,
                                                       t->d_fx_slice0, t->d_pl, keys_in, vals_in);
             CM2_LAUNCH_OK();
             int end_bit = 17;
@@ -979,12 +1032,12 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             CM2_HIP(d_temp.alloc(tb + 16));
             CM2_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp.p, tb, keys_in.p, keys_out.p, vals_in.p,
                                                        ent.p, nv, 0, end_bit, st));
-            k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0, ent, nullptr, nullptr, d_counts,
+            k_fx_pack<false, 0><<<pgrid, 64, 0, st>>>(nslices, qmask, d_k0s, ent, nullptr, nullptr, d_counts,
                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                    nullptr, nullptr, nullptr);
         } else {
             k_fx_build<false, 0><<<(unsigned)nslices, kFbT, 0, st>>>(
-                nslices, qmask, d_k0, 1, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr, nullptr,
+                nslices, qmask, d_k0, 2, t->d_pl, ent, nullptr, nullptr, d_counts, nullptr, nullptr, nullptr,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_overflow);
         }
         CM2_LAUNCH_OK();
@@ -1009,7 +1062,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             for (int64_t s = slice0[(size_t)b]; s < slice0[(size_t)b + 1]; ++s) {
                 ++ncounted;
                 if (counts[(size_t)(4 * s)] > (uint32_t)kFxT) ++nover;
-                if (k0[(size_t)s + 1] - k0[(size_t)s] == S) {
+                if (t->nspans > 1 || k0[(size_t)(2 * s + 1)] - k0[(size_t)(2 * s)] == S) {
                     ++nfull;
                     gsum += counts[(size_t)(4 * s)];
                 }
@@ -1046,13 +1099,13 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
     do {                                                                                        \
         if (serial)                                                                             \
             k_fx_pack<true, NANG><<<pgrid, 64, 0, st>>>(                                          \
-                nslices, qmask, d_k0, ent, t->half ? t->d_half : t->d_cos,                       \
+                nslices, qmask, d_k0s, ent, t->half ? t->d_half : t->d_cos,                      \
                 t->half ? nullptr : t->d_sin, nullptr, t->d_fx_meta, d_tent_off,                \
                 reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, t->d_fx_gb, t->d_fx_trun, \
                 t->d_fx_tent, t->d_fx_ta, t->d_fx_tb);                                          \
         else                                                                                    \
             k_fx_build<true, NANG><<<(unsigned)nslices, kFbT, 0, st>>>(                           \
-                nslices, qmask, d_k0, 1, t->d_pl, ent, t->half ? t->d_half : t->d_cos,              \
+                nslices, qmask, d_k0, 2, t->d_pl, ent, t->half ? t->d_half : t->d_cos,              \
                 t->half ? nullptr : t->d_sin, nullptr, t->d_fx_meta, d_tent_off,                \
                 reinterpret_cast<uint32_t *>(t->d_fx_gent), t->d_fx_ga, t->d_fx_gb, t->d_fx_trun, \
                 t->d_fx_tent, t->d_fx_ta, t->d_fx_tb, d_overflow);                              \
@@ -1090,7 +1143,7 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
     k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
-        t->tp, t->d_tile_p0, (int)tile_lo, t->fx_S, t->d_tile_off, t->d_fx_slice0, t->d_fx_meta,
+        t->tp, t->d_tile_p0, (int)tile_lo, t->d_fx_sk, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
         t->d_fx_tb, d_tod_tb, d_out,
@@ -1117,6 +1170,27 @@ int fx_launch_vpt(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int
 namespace cm2 {
 
 void fx_free(cm2_tiles *t) { fx_release(t); }
+
+bool fx_serial_build() { return fx_serial(); }
+
+int fx_groups_estimate(const cm2_tiles *t, hipStream_t st, double *mean_groups, double *over)
+{
+    return fx_estimate(t, fx_max_slice(t), st, mean_groups, over);
+}
+
+// longest slice the kernel can stage beside the tile: 4 values a thread at most, and short enough for
+// two workgroups per CU (<= 79 KB each) whenever some slice length allows that
+int fx_max_slice(const cm2_tiles *t)
+{
+    int smax = 4 * kFxT;
+    {
+        int s2 = smax;
+        while (s2 > 2 * kFxT && fx_lds_bytes(t, s2) > 79 * 1024) s2 -= kFxT;
+        if (fx_lds_bytes(t, s2) <= 79 * 1024) smax = s2;
+    }
+    while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
+    return smax;
+}
 
 int64_t fx_designed_bytes(const cm2_tiles *t)
 {
@@ -1148,16 +1222,11 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
     }
     struct FailMark { cm2_tiles *t; bool ok; ~FailMark() { if (!ok) { t->fx_failed = 1; t->fx_S = 0; } } } mark{t, false};
     if (t->fx_S == 0) {
-        int smax = 4 * kFxT;                             // 4 staged values per thread at most
-        // Two workgroups per CU need <= 79 KB each: a 2048-pixel IQU tile (48 KB) with four staged
-        // values per thread in two buffers (32 KB) would leave ONE workgroup per CU (C5: P^T 0.53 ->
-        // 0.64 ms); the slice is kept short enough for two whenever some slice length allows it.
-        {
-            int s2 = smax;
-            while (s2 > 2 * kFxT && fx_lds_bytes(t, s2) > 79 * 1024) s2 -= kFxT;
-            if (fx_lds_bytes(t, s2) <= 79 * 1024) smax = s2;
-        }
-        while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
+        // (4 staged values per thread at most.  Two workgroups per CU need <= 79 KB each: a 2048-pixel
+        // IQU tile (48 KB) with four staged values per thread in two buffers (32 KB) would leave ONE
+        // workgroup per CU (C5: P^T 0.53 -> 0.64 ms); the slice is kept short enough for two whenever
+        // some slice length allows it.)
+        int smax = fx_max_slice(t);
         if (fx_lds_bytes(t, smax) > 159 * 1024) {        // the tile alone fills LDS: atomics
             t->pt_fixed = 0;
             mark.ok = true;
@@ -1168,6 +1237,10 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
         double mean = 0.0, over = 0.0;
         if (forced >= 64 && forced <= 4 * kFxT) {
             if (int rc = fx_build(t, forced < smax ? forced : smax, st, &mean, &over)) return rc;
+        } else if (t->nspans > 1) {
+            // the slices are the segments of the plan's spans (the span length was chosen for segments
+            // of ~0.9 smax samples): nothing to tune, S only caps the rare longer segment
+            if (int rc = fx_build(t, smax, st, &mean, &over)) return rc;
         } else {
             int S = 1536 < smax ? 1536 : smax;
             auto wanted = [&](int S_now) {

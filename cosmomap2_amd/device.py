@@ -78,14 +78,27 @@ def i32(a):
     return to_dev(a, torch.int32)
 
 
+def _alloc(make):
+    """torch's allocator and the library's own block cache (cm2_core.hip) share the device and do not
+    see each other's idle memory: when torch runs out, the library's cached blocks (and torch's own)
+    go back to the driver and the allocation is tried once more."""
+    try:
+        return make()
+    except torch.cuda.OutOfMemoryError:
+        from . import _hip
+        _hip.call("cm2_release_cached_memory")
+        torch.cuda.empty_cache()
+        return make()
+
+
 def empty(n, dtype=None):
     require_gpu()
-    return torch.empty(int(n), dtype=dtype or torch.float64, device=dev())
+    return _alloc(lambda: torch.empty(int(n), dtype=dtype or torch.float64, device=dev()))
 
 
 def zeros(n, dtype=None):
     require_gpu()
-    return torch.zeros(int(n), dtype=dtype or torch.float64, device=dev())
+    return _alloc(lambda: torch.zeros(int(n), dtype=dtype or torch.float64, device=dev()))
 
 
 def to_host(t):

@@ -200,9 +200,10 @@ class _TileHandle(object):
         self.pt_fixed = bool(info[6])
         self.pt_mode = int(info[6])              # 0 atomic, 1 fixed (hot runs chunked), 2 exact
         self.plan_id = int(info[7])
+        self.nspans, self.span_samples = int(info[10]), int(info[11])
 
     def _info(self):
-        info = (ctypes.c_int64 * 10)()
+        info = (ctypes.c_int64 * 12)()
         _hip.call("cm2_tiles_info", self.h, info)
         return info
 
@@ -585,12 +586,13 @@ class BlockLO(blk.BlockDiagonalLinearOperator):
     def tile_kernel_info(self):
         """Overlap-save kernel of the tile-order application: complex points per thread, list format of
         the most recently used tile plan, window length, designed HBM bytes per sample."""
-        info = (ctypes.c_int64 * 3)()
+        info = (ctypes.c_int64 * 4)()
         bps = ctypes.c_double(0.0)
         _hip.call("cm2_noise_tile_kernel_info", self._noise.h, info, ctypes.byref(bps))
         return dict(os_kernel="real%d" % info[0],
                     os_lists={0: "not built", 1: "plain", 2: "run-coded", 3: "inverse run-coded"}[int(info[1])],
-                    os_window=int(info[2]), tile_bytes_per_sample=round(float(bps.value), 2))
+                    os_window=int(info[2]), os_windows_across_spans=int(info[3]),
+                    tile_bytes_per_sample=round(float(bps.value), 2))
 
     def _apply_all(self, v):
         return _noise_apply(self._noise, self._nt, v)

@@ -125,18 +125,24 @@ def cg(A, b, x0=None, tol=None, maxiter=None, M=None, callback=None, atol=0., rt
 # Pinned 8-byte buffers and events of the deferred reads: allocating page-locked memory costs from
 # 0.1 ms to tens of milliseconds, so they are kept and reused; a pool rather than one buffer because
 # a solve may run inside another one's operator (InverseLO inside a product).
-_deferred_pool = []
+# Keyed by device: an event first recorded on one device cannot be recorded on another.
+_deferred_pool = {}
 
 
 def _deferred_acquire():
-    if _deferred_pool:
-        return _deferred_pool.pop()
+    pool = _deferred_pool.setdefault(torch.cuda.current_device(), [])
+    if pool:
+        return pool.pop()
     return torch.empty(1, dtype=torch.float64).pin_memory(), torch.cuda.Event()
 
 
 def _deferred_release(buf, ev):
-    if len(_deferred_pool) < 8:
-        _deferred_pool.append((buf, ev))
+    # the last queued copy into `buf` may still be in flight (a solve that stopped at maxiter queues
+    # one it never reads): the pair only goes back once that copy is done
+    ev.synchronize()
+    pool = _deferred_pool.setdefault(torch.cuda.current_device(), [])
+    if len(pool) < 8:
+        pool.append((buf, ev))
 
 
 def _cg_loop(A, M, x, r, n, lib, work, st, dot_into, scal, maxiter, atol, callback, host_io, sync,

@@ -32,7 +32,14 @@
 extern "C" {
 #endif
 
-#define CM2_ABI_VERSION 1
+/* 2 (round 4): cm2_noise_prepare_tiles added; cm2_noise_tile_kernel_info reports the one-real-window
+ * kernel only; and the defaults that changed behind unchanged signatures since version 1 --
+ * cm2_pointing_info fields 3..5 are -1 until the pixel-major copy exists, cm2_tiles_set_pt_order has
+ * mode 2 and its default sums runs of more than 256 hits per slice in chunks of 32 terms,
+ * cm2_weights_accumulate sums pixels with >= 8192 samples in chunks (both <= 1e-14 from the serial
+ * sum; CM2_PT_ORDER=exact / CM2_WEIGHTS_ORDER=exact or cm2_set_exact_order(1) restore the serial
+ * order), cm2_pcg calls its callback after the next iteration's work is queued. */
+#define CM2_ABI_VERSION 2
 
 const char *cm2_last_error(void);
 int cm2_abi_version(void);
@@ -41,11 +48,23 @@ int cm2_device_info(int device, char *h_name, int *h_num_cu, double *h_hbm_gib);
 /* Device memory of the library.  Every buffer a cm2_* object owns and every temporary of a plan
  * build comes from a per-device cache of released blocks (a released block is handed out again to
  * a request of at most 25 % less; releasing waits for the device exactly like hipFree).  The cache
- * holds at most CM2_DEVICE_CACHE_MB megabytes (environment, default 32768; 0 = every release goes
- * straight back to the driver).  cm2_release_cached_memory returns all cached blocks to the
+ * holds at most CM2_DEVICE_CACHE_MB megabytes (environment; default: an eighth of the device's memory,
+ * 36 GB on an MI355X; 0 = every release goes straight back to the driver).  Other allocators on the
+ * same device (the host framework's, another rank's) do not see these blocks: a host that runs out of
+ * device memory should call cm2_release_cached_memory and retry (cosmomap2_amd/device.py does).  cm2_release_cached_memory returns all cached blocks to the
  * driver; cm2_device_memory_info fills h_info[4] = bytes in use by live objects, bytes cached,
  * requests served from the cache, requests that went to the driver. */
 int cm2_release_cached_memory(void);
+/* Summation order of the per-pixel sums (process-wide; objects created afterwards follow it).  The
+ * reference adds every pixel's terms serially in time order (linearoperators.py:509-516,
+ * process_ces.py:426-555).  Default (on = 0): that order, except that a pixel with >= 8192 samples
+ * (weights) or a run of more than 256 hits inside one slice of a tile (P^T) is summed in fixed chunks
+ * -- reproducible, independent of the rest of the hit map, <= 1e-14 relative from the serial sum, so
+ * a pixel whose condition number sits within 1e-14 of threshold_cond (process_ces.py:544-550) could
+ * be masked differently.  on = 1: the pure serial order everywhere (bit-equal to the reference's
+ * loops; a stare at one pixel then costs milliseconds to seconds).  on = -1: back to the environment
+ * (CM2_PT_ORDER, CM2_WEIGHTS_ORDER). */
+int cm2_set_exact_order(int on);
 int cm2_device_memory_info(int64_t *h_info);
 
 /* ------------------------------------------------------------------------- *
@@ -100,6 +119,12 @@ int cm2_PtNP_diag_apply(const cm2_pointing *p, const double *d_x, double *d_out,
  * a2-a3 (throughput form)  Tile-bucketed TOD order
  *   Samples grouped by pixel tile (stable, so time order inside a tile); the tile's
  *   slice of the map is staged in LDS, so P and P^T stream HBM with no random access.
+ *   CM2_TILE_SPAN = samples (or "auto") cuts the order in time as well -- [span][tile][time], a span
+ *   being a whole number of 8192-sample chunks -- so that a window of the overlap-save kernel finds
+ *   its samples in one cache-resident region; measured neutral on uniform pointing and slower on
+ *   raster scans, hence off by default.  The order is internal: TB-ordered TODs are only ever produced
+ *   and consumed by the entry points of this section and cm2_noise_apply_tiles /
+ *   cm2_filter_apply_tiles.
  *   Same loops as above (linearoperators.py:483-489, :509-516).  P^T by default adds every
  *   pixel's terms in time order from 0 like the serial loop (one workgroup per tile, per-slice
  *   lists sorted by (pixel, time), no atomics: bitwise reproducible); cm2_tiles_set_pt_order(t, 0)
@@ -110,13 +135,13 @@ int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
                      const double *d_sin, int64_t nt, int64_t npix, int pol, int tile_pixels,
                      int64_t slice_samples, void *stream);
 int cm2_tiles_destroy(cm2_tiles *t);
-/* h_info[0..9] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
+/* h_info[0..11] = nt, valid samples (= length of a TB-ordered TOD), tile pixels, tiles, items,
  * 1 if the plan stores one half-angle value per sample instead of cos and sin (done when every
  * (cos, sin) pair is on the unit circle to 1e-14; the kernels rebuild cos = +-(1-h^2)/(1+h^2),
  * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample), 1 if P^T sums in
  * fixed (time) order, the plan's id (unique per plan in this process), slice length of the
- * fixed-order lists (0 until the first P^T builds them) and the bytes one fixed-order P^T is
- * designed to read (TOD + padded lists) */
+ * fixed-order lists (0 until the first P^T builds them), the bytes one fixed-order P^T is
+ * designed to read (TOD + padded lists), the number of spans and the samples per span */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* fixed == 1 (default): P^T adds each pixel's terms in time order (the reference's order,
  * reproducible bit for bit), except that a pixel hit more than 256 times inside one slice of a
@@ -210,8 +235,10 @@ int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
  * ToeplitzLO.mult is a NumPy loop, interfaces/linearoperators.py:582-595): h_info[0] = complex points
  * per thread of the one-real-window kernel (32), h_info[1] = list format of the most recently used
  * tile plan (1 plain, 2 run-coded lists cut by time, 3 run-coded lists cut by address ("inverse"),
- * 0 = no lists built yet), h_info[2] = window length in samples; *h_bytes_per_sample = HBM bytes per
- * TOD sample the kernel is built to move (lists + gathered windows + results).  Environment switches,
+ * 0 = no lists built yet), h_info[2] = window length in samples, h_info[3] = windows of that plan that
+ * reach into two spans of its [span][tile][time] order (plain lists, a small launch of their own);
+ * *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to move (lists + gathered windows +
+ * results).  Environment switches,
  * read ONCE when the operator is created: CM2_OS_LISTS = auto (default: rc below 768 pixel tiles,
  * inv from there up) | rc | inv | plain, CM2_OS_LIST_BUILD = direct (default) | sort, CM2_OS_FLAT
  * (flat addressing also for buffers below 4 GB). */

@@ -24,24 +24,27 @@ nside = int(os.environ.get("PROBE_NSIDE", "256"))
 nt, nb, lam = int(os.environ.get("PROBE_NT", "100000000")), int(os.environ.get("PROBE_NB", "100")), 2048
 tp = int(os.environ.get("PROBE_TP", "1536"))
 npix = 12 * nside * nside
-assert npix % tp == 0 and nt % nb == 0
+assert npix % tp == 0 and nt % nb == 0 and npix * ((nt + 2**17 - 1) // 2**17) < 2**31
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 pix = torch.randint(0, npix, (nt,), generator=g, device=dev, dtype=torch.int32)
 rng = np.random.default_rng(0)
 bands = [toeplitz_band(lam, rng) for _ in range(nb)]
 tod = torch.rand(nt, generator=g, device=dev, dtype=torch.float64)
-os.environ["CM2_OS_KERNEL"] = "real32"
 N = BlockLO(nt // nb, bands, offdiag=True, method=3)
 want_time = N * tod
 torch.cuda.synchronize()
 
+# PROBE_ORDERS: "global" or "chunked[:samples per chunk]" (default: one chunk per noise block; chunks need
+# not be aligned with blocks or windows -- a window that crosses a chunk boundary just has more runs)
 for order in os.environ.get("PROBE_ORDERS", "global,chunked").split(","):
-    if order == "chunked":
-        blk = (torch.arange(nt, device=dev, dtype=torch.int64) // (nt // nb))
+    if order.startswith("chunked"):
+        clen = int(order.split(":")[1]) if ":" in order else nt // nb
+        nch = (nt + clen - 1) // clen
+        blk = (torch.arange(nt, device=dev, dtype=torch.int64) // clen)
         vp = (blk * npix + pix.to(torch.int64)).to(torch.int32)
         del blk
-        P = SparseLO(npix * nb, nt, vp, pol=1)
+        P = SparseLO(npix * nch, nt, vp, pol=1)
     else:
         P = SparseLO(npix, nt, pix, pol=1)
     h = ctypes.c_void_p()
@@ -52,7 +55,7 @@ for order in os.environ.get("PROBE_ORDERS", "global,chunked").split(","):
     want = D.empty(T.nvalid)
     _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod), D.ptr(a), D.stream())
     _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(want_time), D.ptr(want), D.stream())
-    for lists in (("plain",) if order == "chunked" else ("plain", "rc")):
+    for lists in (("plain",) if order.startswith("chunked") else ("plain", "rc")):
         os.environ["CM2_OS_LISTS"] = lists
         Nv = BlockLO(nt // nb, bands, offdiag=True, method=3)
         b = torch.zeros_like(a)

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("MASTER_PORT", "29541")     # (the test passes a free port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     assert dist.get_backend() == "nccl"

@@ -207,7 +207,7 @@ int main(void)
     normal_op A;
     CHECK_CM2(cm2_tiles_create(&A.T, d_pix, d_c, d_s, nt, npix, pol, 512, 4096, NULL));
     CHECK_CM2(cm2_tiles_prepare_pt(A.T, NULL));      /* fixed-order P^T lists now, not in the first apply */
-    int64_t info[10];
+    int64_t info[12];
     CHECK_CM2(cm2_tiles_info(A.T, info));
     const int64_t nvalid = info[1];
     CHECK_CM2(cm2_noise_create_toeplitz(&A.N, bands, lambda, sizes, nblocks, CM2_TOEPLITZ_FUSED, NULL));

@@ -15,11 +15,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A port nobody listens on right now (a fixed number collides with a lingering rendezvous or a
+    parallel job on the same box)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_ranks_share_one_gpu():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_sharded_worker.py")]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -34,7 +43,7 @@ def test_one_rank_rccl_group():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
-                "MASTER_PORT": "29541"})
+                "MASTER_PORT": str(_free_port())})
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py")],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libcosmomap2_hip.so lacks %s" % s
     # the ctypes table binds exactly the declared interface
     assert sorted(_hip.PROTOTYPES) == syms
-    assert lib.cm2_abi_version() == 1
+    assert lib.cm2_abi_version() == 2
     assert lib.cm2_last_error() is not None
     assert lib.cm2_reduce_work_doubles() > 0 and lib.cm2_gemm_tn_work_doubles(32, 32) > 0
 
