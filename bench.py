@@ -436,8 +436,13 @@ def main():
         for i in range(len(fns)):
             ts = sorted(row[i].elapsed_time(row[i + 1]) for row in evs)
             out.append((float(np.mean(ts)), float(ts[len(ts) // 2])))
+        # the whole sequence between the same events (first to last of a repetition): the stage times
+        # add up to this by construction
+        whole = [row[0].elapsed_time(row[-1]) for row in evs]
+        seq_time.last_step_ms = float(np.mean(whole))
         return out
 
+    seq_time.last_step_ms = None
     reps = max(5, min(args.steps, 20))
     stages = {}          # name -> ((mean ms, median ms), bytes_survey, bytes_designed)
     stage_timing = "each kernel alone, relaunched on its own inputs"
@@ -507,12 +512,30 @@ def main():
         step_bytes = 28.0 * nt + map_bytes
     dom = max(stages, key=lambda k: stages[k][0][0])
     (dom_mean, dom_med), dom_bytes, dom_designed = stages[dom]
-    achieved = dom_bytes / (dom_mean * 1e-3) / 1e9
+    # One consistent set of times.  The K timed steps run WITHOUT events between the kernels
+    # (ms_per_step); the stage times come from the same three launches with an event between every
+    # two, and add up to the step measured between the same events (`step_ms_same_events`, equal to the
+    # sum by construction).  An event between two kernels keeps the command processor from fetching the
+    # next dispatch while the previous kernel drains: `event_gap_ms` = (step with events - step without)
+    # / kernels is what each event interval contains beside its kernel, and `avg_launch_ms` -- the
+    # figure rocprofv3's average duration of the same kernel is to be compared with -- is the interval
+    # minus that gap (`avg_launch_ms_event_interval` is the raw interval).
+    timing = {"kind": stage_timing}
+    gap = 0.0
+    if seq_time.last_step_ms is not None and world == 1:
+        nk = len(stages)
+        ssum = sum(v[0][0] for v in stages.values())
+        gap = max(0.0, (seq_time.last_step_ms - ms_per_step) / nk)
+        timing.update({"stages_sum_ms": round(ssum, 4), "step_ms_same_events": round(seq_time.last_step_ms, 4),
+                       "step_ms_no_events": round(ms_per_step, 4), "event_gap_ms": round(gap, 4),
+                       "stages_sum_minus_gaps_ms": round(ssum - nk * gap, 4)})
+    dom_net = dom_mean - gap
+    achieved = dom_bytes / (dom_net * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_measured_in_run": False,
                 "algorithmic_bytes": dom_bytes, "designed_bytes": dom_designed,
-                "avg_launch_ms": round(dom_mean, 4)}
+                "avg_launch_ms": round(dom_net, 4), "avg_launch_ms_event_interval": round(dom_mean, 4)}
     # HBM traffic of the dominant kernel from the PMC counters.  FETCH_SIZE / WRITE_SIZE need
     # rocprofv3 passes of their own, so the figure is NOT measured in this run: it is copied from
     # the newest committed summary of this command (profiles/make_summary.py), only when workload
@@ -1001,7 +1024,7 @@ def main():
             "roofline": roofline,
             "step_algorithmic_GBps": round(step_gbs, 1),
             "step_frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
-            "stages": stage_report, "stage_timing": stage_timing,
+            "stages": stage_report, "stage_timing": timing,
             "distributed": dist_info,
             "other_scaling_point": other,
             "pcg": pcg,
