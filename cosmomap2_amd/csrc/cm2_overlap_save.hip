@@ -425,6 +425,10 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
     const double *__restrict__ r0 = buf + A0;
     const double *__restrict__ r1 = buf + A1;
     const bool self0 = (t == 0);            // bin k = 0 (and N/2 through the formula) pairs with itself
+    // the first batch of (alpha, beta) is requested here: it arrives behind the three exchanges below
+    // instead of costing the first of the eight dependent L2 round trips of the loop
+    ab_request<PT, BA>(ab, 0, c);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < PT; ++m) wp[m] = zr[reg_slot<16>(m)];
     __syncthreads();
@@ -440,7 +444,7 @@ __device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT
     __syncthreads();
 #pragma unroll
     for (int m0 = 0; m0 < PT; m0 += BA) {
-        ab_request<PT, BA>(ab, m0, c);
+        if (m0 > 0) ab_request<PT, BA>(ab, m0, c);
 #pragma unroll
         for (int i0 = 0; i0 < BA; i0 += 4) {
             double pim[4];
