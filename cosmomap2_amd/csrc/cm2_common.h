@@ -15,6 +15,12 @@ void set_error(const char *fmt, ...);
 // default fixed regroupings of very long runs, -1 = not set (CM2_PT_ORDER / CM2_WEIGHTS_ORDER decide)
 int exact_order_setting();
 
+// host <-> device copies through a page-locked staging buffer of the calling thread; both return when
+// the copy is complete.  Never pass the caller's pageable memory to hipMemcpy (cm2_core.hip says why).
+hipError_t upload(void *d_dst, const void *h_src, size_t bytes, hipStream_t stream);
+hipError_t download(void *h_dst, const void *d_src, size_t bytes, hipStream_t stream);
+hipError_t read_back(void *dst, const void *d_src, size_t bytes, hipStream_t stream);
+
 // device memory of the library (cm2_core.hip): hipMalloc / hipFree semantics, freed blocks cached
 hipError_t dev_malloc_bytes(void **p, size_t bytes);
 hipError_t dev_free(void *p);

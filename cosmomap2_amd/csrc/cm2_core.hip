@@ -20,6 +20,65 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ---- host <-> device copies of the library -------------------------------------------------------
+// Every copy between host memory and the device goes through a page-locked staging buffer of the
+// calling thread (1 MB, in pieces), never straight from / into the caller's pageable memory.  Why: the
+// HIP runtime PINS pageable host memory for copies of 1 MB and more (GPU_PINNED_MIN_XFER_SIZE); when the
+// host later frees that memory (a NumPy array of noise bands, a std::vector of plan offsets), the
+// kernel driver's MMU notifier evicts the process's GPU queues and restores them some 10-30 ms later
+// -- a kernel launched in that moment completes 11-36 ms late (the "stall in cm2_bd_det_mask" of
+// rounds 3-4: profiles/r04_stall_probe.md; with pinning switched off in the runtime it never occurs).
+// Both calls return when the copy is complete (the host buffer may be reused / is filled).
+namespace {
+constexpr size_t kStage = (size_t)1 << 20;
+void *stage_buffer()
+{
+    static thread_local void *pinned = nullptr;
+    if (!pinned && hipHostMalloc(&pinned, kStage, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        pinned = nullptr;
+    }
+    return pinned;
+}
+}  // namespace
+
+hipError_t upload(void *d_dst, const void *h_src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    void *st = stage_buffer();
+    if (!st) return hipErrorOutOfMemory;
+    for (size_t o = 0; o < bytes; o += kStage) {
+        const size_t n = bytes - o < kStage ? bytes - o : kStage;
+        memcpy(st, static_cast<const char *>(h_src) + o, n);
+        hipError_t e = hipMemcpyAsync(static_cast<char *>(d_dst) + o, st, n, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t download(void *h_dst, const void *d_src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    void *st = stage_buffer();
+    if (!st) return hipErrorOutOfMemory;
+    for (size_t o = 0; o < bytes; o += kStage) {
+        const size_t n = bytes - o < kStage ? bytes - o : kStage;
+        hipError_t e = hipMemcpyAsync(st, static_cast<const char *>(d_src) + o, n, hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        memcpy(static_cast<char *>(h_dst) + o, st, n);
+    }
+    return hipSuccess;
+}
+
+hipError_t read_back(void *dst, const void *d_src, size_t bytes, hipStream_t stream)
+{
+    return download(dst, d_src, bytes, stream);
+}
+
 // ---- device memory of the library ---------------------------------------------------------------
 // Plans are built from many large temporaries (hundreds of MB each) and hold GBs of lists.  The
 // driver's hipMalloc / hipFree cost 0.1 .. 0.6 ms a call at these sizes and, when an allocation

@@ -526,7 +526,7 @@ template <typename T>
 int upload(T **dst, const T *src, size_t count, hipStream_t st)
 {
     CM2_HIP(cm2::dev_malloc(dst, sizeof(T) * (count ? count : 1)));
-    if (count) CM2_HIP(hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, st));
+    if (count) CM2_HIP(cm2::upload(*dst, src, sizeof(T) * count, st));
     return 0;
 }
 
@@ -609,7 +609,7 @@ int filter_fill(cm2_filter *f, int64_t nt, int64_t nseg, const int64_t *h_start,
         if (rc) return rc;
         std::vector<uint8_t> h_kind((size_t)nseg);
         if (nseg)
-            CM2_HIP(hipMemcpyAsync(h_kind.data(), f->d_kind, (size_t)nseg, hipMemcpyDeviceToHost, st));
+            CM2_HIP(cm2::download(h_kind.data(), f->d_kind, (size_t)nseg, st));
         CM2_HIP(hipStreamSynchronize(st));
         for (uint8_t k : h_kind) f->nkind[k < 3 ? k : 0]++;
     }
@@ -733,8 +733,7 @@ int filter_windows_build(cm2_filter *f, const uint32_t *d_idx, uint64_t plan_id,
     }
     CM2_CHECK(f->nseg < ((int64_t)1 << 31) && f->nwin < ((int64_t)1 << 31), "too many chunks");
     CM2_HIP(cm2::dev_malloc(&f->d_wins, sizeof(FilterWin) * wins.size()));
-    CM2_HIP(hipMemcpyAsync(f->d_wins, wins.data(), sizeof(FilterWin) * wins.size(),
-                           hipMemcpyHostToDevice, st));
+    CM2_HIP(cm2::upload(f->d_wins, wins.data(), sizeof(FilterWin) * wins.size(), st));
     const int64_t total = f->nwin * kWinLen;
     DevTemp<uint64_t> keys_in, keys_out;
     DevTemp<uint16_t> vals_in;

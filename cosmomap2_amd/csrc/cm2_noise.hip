@@ -248,7 +248,7 @@ static int noise_common(cm2_noise *n, const int64_t *h_sizes, int64_t nb,
     n->nt = off[nb];
     n->bsize = h_sizes[0];
     CM2_HIP(cm2::dev_malloc(&n->d_off, sizeof(int64_t) * (nb + 1)));
-    CM2_HIP(hipMemcpy(n->d_off, off.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice));
+    CM2_HIP(cm2::upload(n->d_off, off.data(), sizeof(int64_t) * (nb + 1), nullptr));
     return 0;
 }
 
@@ -278,7 +278,7 @@ extern "C" int cm2_noise_create_diag(cm2_noise **out, const double *h_t, const i
     n->lambda = 0;
     n->method = 0;
     CM2_HIP(cm2::dev_malloc(&n->d_t, sizeof(double) * nblocks));
-    CM2_HIP(hipMemcpy(n->d_t, h_t, sizeof(double) * nblocks, hipMemcpyHostToDevice));
+    CM2_HIP(cm2::upload(n->d_t, h_t, sizeof(double) * nblocks, nullptr));
     *out = n;
     return 0;
 }
@@ -319,7 +319,7 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
                                                                    : CM2_TOEPLITZ_FFT);
     n->method = method;
     CM2_HIP(cm2::dev_malloc(&n->d_t, sizeof(double) * nblocks * lambda));
-    CM2_HIP(hipMemcpy(n->d_t, h_bands, sizeof(double) * nblocks * lambda, hipMemcpyHostToDevice));
+    CM2_HIP(cm2::upload(n->d_t, h_bands, sizeof(double) * nblocks * lambda, nullptr));
     if (method == CM2_TOEPLITZ_DIRECT) {
         *out = n;
         return 0;
@@ -358,9 +358,8 @@ extern "C" int cm2_noise_create_toeplitz(cm2_noise **out, const double *h_bands,
     CM2_CHECK(n->nseg < 65536LL * 32768LL, "too many FFT segments (%lld)", (long long)n->nseg);
     CM2_HIP(cm2::dev_malloc(&n->d_seg, sizeof(int64_t) * seg.size()));
     CM2_HIP(cm2::dev_malloc(&n->d_seg_blk, sizeof(int32_t) * seg_blk.size()));
-    CM2_HIP(hipMemcpy(n->d_seg, seg.data(), sizeof(int64_t) * seg.size(), hipMemcpyHostToDevice));
-    CM2_HIP(hipMemcpy(n->d_seg_blk, seg_blk.data(), sizeof(int32_t) * seg_blk.size(),
-                      hipMemcpyHostToDevice));
+    CM2_HIP(cm2::upload(n->d_seg, seg.data(), sizeof(int64_t) * seg.size(), nullptr));
+    CM2_HIP(cm2::upload(n->d_seg_blk, seg_blk.data(), sizeof(int32_t) * seg_blk.size(), nullptr));
     CM2_HIP(cm2::dev_malloc(&n->d_X, sizeof(double) * n->nseg * n->L));
     CM2_HIP(cm2::dev_malloc(&n->d_F, sizeof(double2) * n->nseg * n->nfreq));
     CM2_HIP(cm2::dev_malloc(&n->d_H, sizeof(double) * nblocks * n->nfreq));
@@ -459,8 +458,7 @@ extern "C" int cm2_noise_apply(cm2_noise *n, const double *d_v, double *d_out, v
             n->ndirtiles = (int64_t)tl.size();
             CM2_HIP(cm2::dev_malloc(&n->d_dirtiles, sizeof(DirTile) * (tl.size() ? tl.size() : 1)));
             if (!tl.empty())
-                CM2_HIP(hipMemcpy(n->d_dirtiles, tl.data(), sizeof(DirTile) * tl.size(),
-                                  hipMemcpyHostToDevice));
+                CM2_HIP(cm2::upload(n->d_dirtiles, tl.data(), sizeof(DirTile) * tl.size(), nullptr));
             if (lds > 64 * 1024)
                 CM2_HIP(hipFuncSetAttribute((const void *)k_toeplitz_direct_tiled,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1460,7 +1460,7 @@ int fused_os_create(FusedOS **out, const double *d_bands, int64_t lambda, const 
     CM2_CHECK(f->nwin * 4 < ((int64_t)1 << 31), "fused overlap-save: too many windows (%lld)", (long long)f->nwin);
     CM2_HIP(cm2::dev_malloc(&f->d_wins, sizeof(WinDesc) * (wins.size() ? wins.size() : 1)));
     if (!wins.empty())
-        CM2_HIP(hipMemcpy(f->d_wins, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice));
+        CM2_HIP(cm2::upload(f->d_wins, wins.data(), sizeof(WinDesc) * wins.size(), nullptr));
     CM2_HIP(cm2::dev_malloc(&f->d_AB, sizeof(double2) * (nb > 0 ? nb : 1) * G::N));
     if (nb > 0) {
         DevTemp<double> Hs;
@@ -1576,7 +1576,7 @@ static int os_build_lists_direct(const FusedOS *f, OsSet *ls, const OsPlanView &
     }
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
-    CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(cm2::download(&h_max, d_max.p, sizeof(uint32_t), stream));
     CM2_HIP(hipStreamSynchronize(stream));
     if (rc) {
         CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel "
@@ -1613,7 +1613,7 @@ static int os_build_ilists(const FusedOS *f, OsSet *ls, const OsPlanView &pv, hi
                                                               d_max, kT, pv.nspans > 1 ? pv.span_samples : 0);
     CM2_LAUNCH_OK();
     uint32_t h_max = 0;
-    CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(cm2::download(&h_max, d_max.p, sizeof(uint32_t), stream));
     CM2_HIP(hipStreamSynchronize(stream));
     CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel tiles "
               "allow", h_max, rmax);
@@ -1680,7 +1680,7 @@ static int os_build_lists_sorted(const FusedOS *f, OsSet *ls, const OsPlanView &
                                                                 ls->d_tabs, rmax, d_max);
             CM2_LAUNCH_OK();
             uint32_t h_max = 0;
-            CM2_HIP(hipMemcpyAsync(&h_max, d_max.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            CM2_HIP(cm2::download(&h_max, d_max.p, sizeof(uint32_t), stream));
             CM2_HIP(hipStreamSynchronize(stream));
             CM2_CHECK((int)h_max <= rmax, "fused overlap-save: a list has %u address runs, more than the %d pixel "
                       "tiles allow", h_max, rmax);
@@ -1735,7 +1735,7 @@ static int os_lists_for(FusedOS *f, const OsPlanView &pv, hipStream_t stream, st
             const std::vector<WinDesc> &w = k ? wb : wa;
             CM2_HIP(cm2::dev_malloc(&st.d_wins, sizeof(WinDesc) * (w.size() ? w.size() : 1)));
             if (!w.empty())
-                CM2_HIP(hipMemcpyAsync(st.d_wins, w.data(), sizeof(WinDesc) * w.size(), hipMemcpyHostToDevice, stream));
+                CM2_HIP(cm2::upload(st.d_wins, w.data(), sizeof(WinDesc) * w.size(), stream));
         }
         CM2_HIP(hipStreamSynchronize(stream));               // (wa, wb are locals)
     } else {

@@ -207,8 +207,8 @@ extern "C" int cm2_weights_accumulate(int pol, int64_t nt, int64_t npix, const i
     CM2_LAUNCH_OK();
     unsigned int nhot = 0;
     unsigned long long longest = 0;
-    CM2_HIP(hipMemcpyAsync(&nhot, d_hot_n.p, sizeof(nhot), hipMemcpyDeviceToHost, stream));
-    CM2_HIP(hipMemcpyAsync(&longest, d_hot_longest.p, sizeof(longest), hipMemcpyDeviceToHost, stream));
+    CM2_HIP(cm2::download(&nhot, d_hot_n.p, sizeof(nhot), stream));
+    CM2_HIP(cm2::download(&longest, d_hot_longest.p, sizeof(longest), stream));
     CM2_HIP(hipStreamSynchronize(stream));
     if (nhot > 0) {
         const int64_t max_chunks = ((int64_t)longest + kWeightsChunk - 1) / kWeightsChunk;
@@ -312,10 +312,8 @@ extern "C" int cm2_pixel_compact(int64_t npix, const uint8_t *d_keep, int32_t *d
     CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb, flags.p, d_old2new, npix, stream));
     int32_t last_rank = 0;
     uint8_t last_keep = 0;
-    CM2_HIP(hipMemcpyAsync(&last_rank, d_old2new + (npix - 1), sizeof(int32_t),
-                           hipMemcpyDeviceToHost, stream));
-    CM2_HIP(hipMemcpyAsync(&last_keep, d_keep + (npix - 1), sizeof(uint8_t),
-                           hipMemcpyDeviceToHost, stream));
+    CM2_HIP(cm2::download(&last_rank, d_old2new + (npix - 1), sizeof(int32_t), stream));
+    CM2_HIP(cm2::download(&last_keep, d_keep + (npix - 1), sizeof(uint8_t), stream));
     k_rank_to_old2new<<<grid_for(npix), kBlock, 0, stream>>>(npix, d_keep, d_old2new);
     CM2_LAUNCH_OK();
     CM2_HIP(hipStreamSynchronize(stream));
@@ -548,7 +546,7 @@ static int check_obspix(int64_t npix, const int64_t *d_obspix, int64_t nfull, hi
     k_obspix_range<<<grid_for(npix), kBlock, 0, st>>>(npix, d_obspix, nfull, d_bad);
     CM2_LAUNCH_OK();
     unsigned int h_bad = 0;
-    CM2_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, st));
+    CM2_HIP(cm2::download(&h_bad, d_bad, sizeof(h_bad), st));
     CM2_HIP(hipStreamSynchronize(st));
     CM2_CHECK(h_bad == 0, "%u observed-pixel ids lie outside the full-sky map of %lld pixels", h_bad,
               (long long)nfull);

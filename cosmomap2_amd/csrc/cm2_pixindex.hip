@@ -84,9 +84,8 @@ int build_pixindex(PixIndex &ix, const int32_t *d_pix, int64_t nt, int64_t npix,
 
     unsigned int h_bad = 0;
     int64_t h_nvalid = 0;
-    CM2_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, stream));
-    CM2_HIP(hipMemcpyAsync(&h_nvalid, ix.d_ptr + npix, sizeof(int64_t), hipMemcpyDeviceToHost,
-                           stream));
+    CM2_HIP(cm2::download(&h_bad, d_bad, sizeof(h_bad), stream));
+    CM2_HIP(cm2::download(&h_nvalid, ix.d_ptr + npix, sizeof(int64_t), stream));
     CM2_HIP(hipStreamSynchronize(stream));
     CM2_CHECK(h_bad == 0, "%u samples have a pixel id outside [-1, npix=%lld)", h_bad,
               (long long)npix);

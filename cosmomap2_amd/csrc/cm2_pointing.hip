@@ -363,8 +363,7 @@ extern "C" int cm2_pointing_create(cm2_pointing **out, const int32_t *d_pix,
         CM2_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(h_cnt), stream));
         k_check_pix<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, d_cnt.p);
         CM2_LAUNCH_OK();
-        CM2_HIP(hipMemcpyAsync(h_cnt, d_cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream));
-        CM2_HIP(hipStreamSynchronize(stream));
+        CM2_HIP(cm2::read_back(h_cnt, d_cnt.p, sizeof(h_cnt), stream));
     }
     CM2_CHECK(h_cnt[0] == 0, "%llu samples have a pixel id outside [-1, npix=%lld)", h_cnt[0],
               (long long)npix);
@@ -439,8 +438,7 @@ static int ensure_sell(const cm2_pointing *cp, hipStream_t stream)
     CM2_LAUNCH_OK();
     CM2_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp.p, tb2, d_len.p, p->d_slice_ptr,
                                              p->nslices + 1, stream));
-    CM2_HIP(hipMemcpyAsync(&p->sell_len, p->d_slice_ptr + p->nslices, sizeof(int64_t),
-                           hipMemcpyDeviceToHost, stream));
+    CM2_HIP(cm2::download(&p->sell_len, p->d_slice_ptr + p->nslices, sizeof(int64_t), stream));
     CM2_HIP(hipStreamSynchronize(stream));
 
     const int64_t L = p->sell_len > 0 ? p->sell_len : 1;

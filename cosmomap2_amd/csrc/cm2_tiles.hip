@@ -836,7 +836,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         CM2_HIP(d_off.alloc(nsegs + 1));
         if (int rc = sorted ? partition_sort(d_p0) : partition_split(d_p0)) return rc;
         seg.assign((size_t)nsegs + 1, 0);
-        CM2_HIP(hipMemcpyAsync(seg.data(), d_off, sizeof(int64_t) * (nsegs + 1), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(cm2::download(seg.data(), d_off, sizeof(int64_t) * (nsegs + 1), stream));
         CM2_HIP(hipStreamSynchronize(stream));
         off.assign((size_t)t->ntiles + 1, 0);
         for (int64_t b = 0; b < t->ntiles; ++b) {
@@ -849,7 +849,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     };
     if (int rc = partition(nullptr)) return rc;
     unsigned int h_bad = 0;
-    CM2_HIP(hipMemcpy(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost));
+    CM2_HIP(cm2::download(&h_bad, d_bad, sizeof(h_bad), nullptr));
     CM2_CHECK(h_bad == 0, "cm2_tiles_create: a pixel index is outside [-1, npix=%lld)",
               (long long)npix);
     t->tile_p0.assign((size_t)t->ntiles + 1, 0);
@@ -878,7 +878,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         k_pix_hist<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, d_hits);
         CM2_LAUNCH_OK();
         std::vector<unsigned int> hits((size_t)npix);
-        CM2_HIP(hipMemcpyAsync(hits.data(), d_hits, sizeof(unsigned int) * npix, hipMemcpyDeviceToHost, stream));
+        CM2_HIP(cm2::download(hits.data(), d_hits, sizeof(unsigned int) * npix, stream));
         CM2_HIP(hipStreamSynchronize(stream));
         // as many tiles as before would have had at equal load, 2 % slack so that rounding does
         // not spill a 513th tile; a tile ends when the next pixel would exceed the target or the
@@ -925,13 +925,12 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         t->ntiles = (int64_t)p0v.size() - 1;
         t->tile_p0 = p0v;
         CM2_HIP(d_p0.alloc(p0v.size()));
-        CM2_HIP(hipMemcpy(d_p0.p, p0v.data(), sizeof(int64_t) * p0v.size(), hipMemcpyHostToDevice));
+        CM2_HIP(cm2::upload(d_p0.p, p0v.data(), sizeof(int64_t) * p0v.size(), nullptr));
         if (int rc = partition(d_p0.p)) return rc;
     }
     t->balanced = balance;
     CM2_HIP(cm2::dev_malloc(&t->d_tile_p0, sizeof(int64_t) * (t->ntiles + 1)));
-    CM2_HIP(hipMemcpy(t->d_tile_p0, t->tile_p0.data(), sizeof(int64_t) * (t->ntiles + 1),
-                      hipMemcpyHostToDevice));
+    CM2_HIP(cm2::upload(t->d_tile_p0, t->tile_p0.data(), sizeof(int64_t) * (t->ntiles + 1), nullptr));
     t->nvalid = off[t->ntiles];
     auto publish_segments = [&]() -> int {
         t->tile_count.assign((size_t)t->ntiles, 0);
@@ -960,7 +959,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
             k_unit_circle<<<grid_for(nt), kBlock, 0, stream>>>(nt, d_cos, d_sin, d_off_circle);
             CM2_LAUNCH_OK();
             unsigned int h_off = 0;
-            CM2_HIP(hipMemcpyAsync(&h_off, d_off_circle, sizeof(h_off), hipMemcpyDeviceToHost, stream));
+            CM2_HIP(cm2::download(&h_off, d_off_circle, sizeof(h_off), stream));
             CM2_HIP(hipStreamSynchronize(stream));
             t->half = (h_off == 0);
         }
@@ -1071,10 +1070,10 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     CM2_HIP(cm2::dev_malloc(&t->d_item_k0, sizeof(int64_t) * ni));
     CM2_HIP(cm2::dev_malloc(&t->d_item_k1, sizeof(int64_t) * ni));
     if (t->nitems) {
-        CM2_HIP(hipMemcpy(t->d_item_tile, it_tile.data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
-        CM2_HIP(hipMemcpy(t->d_item_span, it_span.data(), sizeof(int2) * ni, hipMemcpyHostToDevice));
-        CM2_HIP(hipMemcpy(t->d_item_k0, it_k0.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
-        CM2_HIP(hipMemcpy(t->d_item_k1, it_k1.data(), sizeof(int64_t) * ni, hipMemcpyHostToDevice));
+        CM2_HIP(cm2::upload(t->d_item_tile, it_tile.data(), sizeof(int32_t) * ni, nullptr));
+        CM2_HIP(cm2::upload(t->d_item_span, it_span.data(), sizeof(int2) * ni, nullptr));
+        CM2_HIP(cm2::upload(t->d_item_k0, it_k0.data(), sizeof(int64_t) * ni, nullptr));
+        CM2_HIP(cm2::upload(t->d_item_k1, it_k1.data(), sizeof(int64_t) * ni, nullptr));
     }
     CM2_HIP(hipStreamSynchronize(stream));
     guard.t = nullptr;

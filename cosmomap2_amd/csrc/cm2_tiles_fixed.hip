@@ -830,9 +830,9 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
     CM2_HIP(cm2::dev_malloc(&t->d_hot_range, sizeof(int64_t) * range.size()));
     CM2_HIP(cm2::dev_malloc(&t->d_hot_tiles, sizeof(int64_t) * tiles.size()));
     CM2_HIP(cm2::dev_malloc(&t->d_hot_partial, sizeof(double) * 3 * (range.size() / 2)));
-    CM2_HIP(hipMemcpyAsync(t->d_hot_flag, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
-    CM2_HIP(hipMemcpyAsync(t->d_hot_range, range.data(), sizeof(int64_t) * range.size(), hipMemcpyHostToDevice, st));
-    CM2_HIP(hipMemcpyAsync(t->d_hot_tiles, tiles.data(), sizeof(int64_t) * tiles.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(cm2::upload(t->d_hot_flag, flag.data(), flag.size(), st));
+    CM2_HIP(cm2::upload(t->d_hot_range, range.data(), sizeof(int64_t) * range.size(), st));
+    CM2_HIP(cm2::upload(t->d_hot_tiles, tiles.data(), sizeof(int64_t) * tiles.size(), st));
     CM2_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -940,7 +940,7 @@ int fx_estimate(const cm2_tiles *t, int S, hipStream_t st, double *mean_groups, 
     DevTemp<uint32_t> ent, d_counts;
     DevTemp<unsigned int> d_overflow;
     CM2_HIP(d_pairs.alloc(pairs.size()));
-    CM2_HIP(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(int64_t) * pairs.size(), hipMemcpyHostToDevice, st));
+    CM2_HIP(cm2::upload(d_pairs, pairs.data(), sizeof(int64_t) * pairs.size(), st));
     CM2_HIP(ent.alloc(t->nvalid));
     CM2_HIP(d_counts.alloc(4 * np));
     CM2_HIP(d_overflow.alloc(1));
@@ -949,7 +949,7 @@ int fx_estimate(const cm2_tiles *t, int S, hipStream_t st, double *mean_groups, 
         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_overflow);
     CM2_LAUNCH_OK();
     std::vector<uint32_t> counts((size_t)(4 * np));
-    CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(), hipMemcpyDeviceToHost, st));
+    CM2_HIP(cm2::download(counts.data(), d_counts, sizeof(uint32_t) * counts.size(), st));
     CM2_HIP(hipStreamSynchronize(st));
     double gsum = 0.0;
     int64_t nover = 0;
@@ -977,13 +977,12 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         for (int64_t i = 0; i < nslices; ++i)
             sk[(size_t)i] = make_uint2((uint32_t)k0[(size_t)(2 * i)], (uint32_t)(k0[(size_t)(2 * i + 1)] - k0[(size_t)(2 * i)]));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_sk, sizeof(uint2) * sk.size()));
-        CM2_HIP(hipMemcpyAsync(t->d_fx_sk, sk.data(), sizeof(uint2) * sk.size(), hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(t->d_fx_sk, sk.data(), sizeof(uint2) * sk.size(), st));
         CM2_HIP(hipStreamSynchronize(st));           // (sk is a local)
     }
     if (k0.empty()) { k0.push_back(0); k0.push_back(0); }
     CM2_HIP(cm2::dev_malloc(&t->d_fx_slice0, sizeof(int64_t) * slice0.size()));
-    CM2_HIP(hipMemcpyAsync(t->d_fx_slice0, slice0.data(), sizeof(int64_t) * slice0.size(),
-                           hipMemcpyHostToDevice, st));
+    CM2_HIP(cm2::upload(t->d_fx_slice0, slice0.data(), sizeof(int64_t) * slice0.size(), st));
     std::vector<uint2> meta((size_t)nslices + 1, make_uint2(0, 0));
     std::vector<uint32_t> tent_off((size_t)nslices + 1, 0);
     int64_t ngroups = 0, ntrun = 0, ntent = 0;
@@ -996,7 +995,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         DevTemp<unsigned int> d_overflow;
         DevTemp<char> d_temp;
         CM2_HIP(d_k0.alloc(k0.size()));
-        CM2_HIP(hipMemcpyAsync(d_k0, k0.data(), sizeof(int64_t) * k0.size(), hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(d_k0, k0.data(), sizeof(int64_t) * k0.size(), st));
         // (k_fx_pack, the serial builder of the global order, reads the slices as a cut list: slice s =
         //  [cut[s], cut[s + 1]))
         DevTemp<int64_t> d_k0s;
@@ -1005,7 +1004,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             for (int64_t i = 0; i < nslices; ++i) cuts.push_back(k0[(size_t)(2 * i)]);
             cuts.push_back(nv);
             CM2_HIP(d_k0s.alloc(cuts.size()));
-            CM2_HIP(hipMemcpyAsync(d_k0s, cuts.data(), sizeof(int64_t) * cuts.size(), hipMemcpyHostToDevice, st));
+            CM2_HIP(cm2::upload(d_k0s, cuts.data(), sizeof(int64_t) * cuts.size(), st));
         }
         CM2_HIP(ent.alloc(nv));
         CM2_HIP(d_counts.alloc(4 * nslices));
@@ -1042,8 +1041,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         }
         CM2_LAUNCH_OK();
         std::vector<uint32_t> counts((size_t)(4 * nslices));
-        CM2_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * counts.size(),
-                               hipMemcpyDeviceToHost, st));
+        CM2_HIP(cm2::download(counts.data(), d_counts, sizeof(uint32_t) * counts.size(), st));
         CM2_HIP(hipStreamSynchronize(st));
         int64_t nfull = 0, nover = 0;
         double gsum = 0.0;
@@ -1077,11 +1075,9 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
         // (+1 group: a slice without groups at the very end still loads "its" group 0)
         const int64_t ng1 = ngroups + 1, nt1 = ntent ? ntent : 1;
         CM2_HIP(cm2::dev_malloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
-        CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
-                               hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(), st));
         CM2_HIP(d_tent_off.alloc(tent_off.size()));
-        CM2_HIP(hipMemcpyAsync(d_tent_off, tent_off.data(), sizeof(uint32_t) * tent_off.size(),
-                               hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(d_tent_off, tent_off.data(), sizeof(uint32_t) * tent_off.size(), st));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_gent, sizeof(uint4) * ng1));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_trun, sizeof(uint2) * (ntrun + 1)));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_tent, sizeof(uint32_t) * nt1));
@@ -1094,7 +1090,7 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
             }
         }
         const uint2 last = make_uint2((uint32_t)ntent, 0);
-        CM2_HIP(hipMemcpyAsync(t->d_fx_trun + ntrun, &last, sizeof(uint2), hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(t->d_fx_trun + ntrun, &last, sizeof(uint2), st));
 #define CM2_FX_PACK(NANG)                                                                       \
     do {                                                                                        \
         if (serial)                                                                             \
@@ -1116,14 +1112,13 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
 #undef CM2_FX_PACK
         CM2_LAUNCH_OK();
         unsigned int h_over = 0;
-        CM2_HIP(hipMemcpyAsync(&h_over, d_overflow.p, sizeof(h_over), hipMemcpyDeviceToHost, st));
+        CM2_HIP(cm2::download(&h_over, d_overflow.p, sizeof(h_over), st));
         CM2_HIP(hipStreamSynchronize(st));
         CM2_CHECK(h_over == 0, "cm2_tiles: a slice of %d samples packs into more than %d groups", S,
                   kFbMaxGroups);
     } else {
         CM2_HIP(cm2::dev_malloc(&t->d_fx_meta, sizeof(uint2) * meta.size()));
-        CM2_HIP(hipMemcpyAsync(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(),
-                               hipMemcpyHostToDevice, st));
+        CM2_HIP(cm2::upload(t->d_fx_meta, meta.data(), sizeof(uint2) * meta.size(), st));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_gent, sizeof(uint4)));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_trun, sizeof(uint2)));
         CM2_HIP(cm2::dev_malloc(&t->d_fx_tent, sizeof(uint32_t)));

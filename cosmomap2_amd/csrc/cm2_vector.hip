@@ -205,7 +205,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
     double *rho[2] = {sc.p, sc.p + 1}, *pq = sc.p + 2, *rr = sc.p + 3, *tmp = sc.p + 4;
     double h = 0.0;
     auto fetch = [&](const double *d) -> int {
-        CM2_HIP(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(cm2::download(&h, d, sizeof(double), stream));
         CM2_HIP(hipStreamSynchronize(stream));
         return 0;
     };
@@ -239,6 +239,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
     CM2_HIP(hipHostMalloc((void **)&df.host, sizeof(double), hipHostMallocDefault));
     CM2_HIP(hipEventCreateWithFlags(&df.ev, hipEventDisableTiming));
     auto post = [&](const double *d) -> int {
+        // (df.host is the caller's PAGE-LOCKED buffer and this copy is deliberately not waited for)
         CM2_HIP(hipMemcpyAsync(df.host, d, sizeof(double), hipMemcpyDeviceToHost, stream));
         CM2_HIP(hipEventRecord(df.ev, stream));
         return 0;
@@ -326,7 +327,7 @@ extern "C" int cm2_arnoldi(int64_t n, cm2_apply_fn A, void *A_ctx, const double 
     double h = 0.0;
     auto dot = [&](const double *a, const double *b2) -> int {
         if (int rc = cm2_dot(n, a, b2, sc.p, work, stream)) return rc;
-        CM2_HIP(hipMemcpyAsync(&h, sc.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CM2_HIP(cm2::download(&h, sc.p, sizeof(double), stream));
         CM2_HIP(hipStreamSynchronize(stream));
         return 0;
     };
@@ -363,7 +364,7 @@ extern "C" int cm2_arnoldi(int64_t n, cm2_apply_fn A, void *A_ctx, const double 
         if (int rc = cm2_scal(n, 1.0 / hn, vnew, stream_)) return rc;
         double vj = 0.0;
         if (j < n) {
-            CM2_HIP(hipMemcpyAsync(&vj, vnew + j, sizeof(double), hipMemcpyDeviceToHost, stream));
+            CM2_HIP(cm2::download(&vj, vnew + j, sizeof(double), stream));
             CM2_HIP(hipStreamSynchronize(stream));
         }
         *h_steps = j;

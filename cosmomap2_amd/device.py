@@ -53,6 +53,74 @@ def ptr(t):
     return t.data_ptr()
 
 
+# Host <-> device copies of NumPy arrays go through page-locked staging buffers, in pieces: the HIP
+# runtime pins pageable host memory for copies of 1 MB and more, and when that memory is freed later the
+# kernel driver evicts the process's GPU queues for 10-30 ms (cm2_core.hip, profiles/r04_stall_probe.md).
+_STAGE_BYTES = 8 << 20
+_stage = {}
+
+
+def _stage_pair():
+    d = torch.cuda.current_device()
+    if d not in _stage:
+        _stage[d] = [(torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+                     for _ in range(2)]
+    return _stage[d]
+
+
+def _upload(arr):
+    """Contiguous NumPy array -> new tensor on the current GPU."""
+    t = _alloc(lambda: torch.empty(arr.shape, dtype=torch.from_numpy(arr.reshape(-1)[:0]).dtype, device=dev()))
+    nbytes = arr.nbytes
+    if nbytes == 0:
+        return t
+    src = torch.from_numpy(arr.reshape(-1).view(np.uint8))
+    dst = t.reshape(-1).view(torch.uint8)
+    pair = _stage_pair()
+    used = [False, False]
+    for k, o in enumerate(range(0, nbytes, _STAGE_BYTES)):
+        buf, ev = pair[k & 1]
+        if used[k & 1]:
+            ev.synchronize()                         # the copy that last read this buffer is done
+        m = min(_STAGE_BYTES, nbytes - o)
+        buf[:m].copy_(src[o:o + m])
+        dst[o:o + m].copy_(buf[:m], non_blocking=True)
+        ev.record()
+        used[k & 1] = True
+    for (buf, ev), u in zip(pair, used):
+        if u:
+            ev.synchronize()
+    return t
+
+
+def _download(t):
+    """Device tensor -> new NumPy array."""
+    t = t.detach().contiguous()
+    out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+    nbytes = out.nbytes
+    if nbytes == 0:
+        return out
+    dst = torch.from_numpy(out.reshape(-1).view(np.uint8))
+    src = t.reshape(-1).view(torch.uint8)
+    pair = _stage_pair()
+    pending = [None, None]
+    for k, o in enumerate(range(0, nbytes, _STAGE_BYTES)):
+        buf, ev = pair[k & 1]
+        if pending[k & 1] is not None:
+            ev.synchronize()
+            po, pm = pending[k & 1]
+            dst[po:po + pm].copy_(buf[:pm])
+        m = min(_STAGE_BYTES, nbytes - o)
+        buf[:m].copy_(src[o:o + m], non_blocking=True)
+        ev.record()
+        pending[k & 1] = (o, m)
+    for (buf, ev), pend in zip(pair, pending):
+        if pend is not None:
+            ev.synchronize()
+            dst[pend[0]:pend[0] + pend[1]].copy_(buf[:pend[1]])
+    return out
+
+
 def to_dev(a, dtype=None):
     """Upload (or pass through) as a contiguous tensor on the current GPU."""
     require_gpu()
@@ -64,10 +132,11 @@ def to_dev(a, dtype=None):
             t = t.to(dev())
         return t.contiguous()
     arr = np.ascontiguousarray(a)
-    t = torch.from_numpy(arr)
-    if dtype is not None and t.dtype != dtype:
-        t = t.to(dtype)
-    return t.to(dev())
+    if dtype is not None:
+        want = torch.empty(0, dtype=dtype).numpy().dtype
+        if arr.dtype != want:
+            arr = arr.astype(want)
+    return _upload(arr)
 
 
 def f64(a):
@@ -104,7 +173,9 @@ def zeros(n, dtype=None):
 def to_host(t):
     if isinstance(t, np.ndarray):
         return t
-    return t.detach().cpu().numpy()
+    if t.is_cuda:
+        return _download(t)
+    return t.detach().numpy()
 
 
 def like_input(result_dev, x):

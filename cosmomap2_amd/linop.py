@@ -320,5 +320,5 @@ class DiagonalOperator(LinearOperator):
         if isinstance(x, np.ndarray):
             return self._diag_host * x
         if self._diag_dev is None or self._diag_dev.device != x.device:
-            self._diag_dev = torch.from_numpy(self._diag_host).to(x.device)
+            self._diag_dev = _vec.f64(self._diag_host) if x.is_cuda else torch.from_numpy(self._diag_host)
         return _vec.multiply(self._diag_dev, x)

@@ -90,5 +90,10 @@ for rep in range(reps):
                       "calls_that_went_to_the_driver": [[n, m] for n, _, _, m in log if m],
                       "torch_segments_total": torch.cuda.memory_stats().get("segment.all.allocated", 0),
                       "slow_calls": slow, **extra}), flush=True)
+    if os.environ.get("PROBE_KEEP"):
+        # nothing of a repetition is released (host or device): does the delay need the previous build's
+        # objects to be destroyed?
+        keep = globals().setdefault("_keep", [])
+        keep.append((N, ces, P, M, A, T, y, pix, phi, x, bands))
     del N, ces, P, M, A, T, y, pix, phi, x
     gc.collect(); torch.cuda.synchronize()
