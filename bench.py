@@ -985,6 +985,9 @@ def main():
             y = (A * x).cpu().numpy()
             parity["matvec_rel_l2"] = float(np.linalg.norm(y - yo) / np.linalg.norm(yo))
             parity["host_matvec_seconds"] = round(t_mv, 2)
+            # the all-cores host figure at the FULL size of the workload (the bounded slice of the
+            # cpu_baseline_all_cores leg keeps fewer threads busy: fewer noise blocks than threads)
+            parity["host_all_cores_samples_per_s"] = round(nt / t_mv, 1)
             del y, yo
             if not args.no_pcg and pcg is not None and t_mv * (pcg["iters"] + 3) < 120.0:
                 bo = H.rhs(d_h)
