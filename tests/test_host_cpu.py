@@ -268,3 +268,60 @@ def test_bench_launcher_command_line(monkeypatch):
     assert bench.launch_ranks(2, ["--gpus", "2"]) == 3
     seen["result"] = _Done("no json here")
     assert bench.launch_ranks(2, ["--gpus", "2"]) != 0
+
+
+def test_kernel_resource_table_of_the_shipped_build():
+    """cosmomap2_amd/build.py keeps hipcc's per-kernel resource remarks of the objects it links
+    (csrc/build/*.resources.json) and refuses a build in which a kernel of the default path spills
+    registers: the table of the shipped library must list the overlap-save, tile and deflation kernels,
+    and none of them may have spilled VGPRs or scratch."""
+    from cosmomap2_amd import kernel_resources as KR
+    text = ("x.hip:1:1: remark: Function Name: _Z3fooPd [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:1:1: remark:     VGPRs: 250 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 36 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:1:1: remark:     Occupancy [waves/SIMD]: 2 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:1:1: remark:     VGPRs Spill: 8 [-Rpass-analysis=kernel-resource-usage]\n")
+    parsed = KR.parse_remarks(text)
+    assert parsed == {"_Z3fooPd": {"vgpr": 250, "scratch_bytes_per_lane": 36, "occupancy": 2, "vgpr_spill": 8}}
+    assert KR.short("void (anonymous namespace)::k_os_real<32, 2, true>(int, double*)") == "k_os_real<32, 2, true>"
+    bad = KR.offenders([dict(unit="u", kernel="k_os_real<32, 2, true>", vgpr_spill=8, scratch_bytes_per_lane=36),
+                        dict(unit="u", kernel="k_helper", vgpr_spill=3)])
+    assert [r["kernel"] for r in bad] == ["k_os_real<32, 2, true>"]
+    rows = KR.load_all()
+    names = {r["kernel"] for r in rows}
+    for k in ("k_os_real<32, 0, false>", "k_os_real<32, 2, true>", "k_os_real<32, 3, false>", "k_P_tiles<3, true>",
+              "k_Pt_tiles_fixed<3, true, 4>", "k_gemm_tn_mfma_pairs<1>"):
+        assert k in names, k
+    assert not KR.offenders(rows)
+    assert not any(r.get("vgpr_spill", 0) or r.get("scratch_bytes_per_lane", 0) for r in KR.own_kernels(rows))
+
+
+def test_host_problem_equals_the_serial_oracle(oracle):
+    """oracle.HostProblem (the full-size checker of tests/test_gpu_fullsize.py and bench.py: all-cores
+    P / N^-1 / P^T, serial ProcessTimeSamples and M_BD) against the serial reference-order oracle on a
+    small problem: same right-hand side and matvec to 1e-13, the same PCG iteration count."""
+    rng = np.random.default_rng(5)
+    nt, npix, nb, pol = 60000, 400, 4, 3
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    pairs[rng.random(nt) < 0.03] = -1
+    kk = np.arange(20)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / 5.0) for b in range(nb)]
+    H = oracle.HostProblem(pol, npix, pairs.copy(), phi, nt // nb, bands=bands, threads=3)
+    po = pairs.copy()
+    ro = oracle.process_time_samples(po, npix, pol=pol, phi=phi)
+    assert H.n == ro.new_npix
+
+    def A(v):
+        return oracle.sparse_rmult(pol, ro.new_npix, po, ro.cos, ro.sin, oracle.blocklo_mult(
+            nt // nb, bands, True, oracle.sparse_mult(pol, po, ro.cos, ro.sin, v)))
+    b = oracle.sparse_rmult(pol, ro.new_npix, po, ro.cos, ro.sin, oracle.blocklo_mult(nt // nb, bands, True, d))
+    bh = H.rhs(d)
+    assert np.linalg.norm(bh - b) / np.linalg.norm(b) < 1e-13
+    x = rng.standard_normal(pol * H.n)
+    assert np.linalg.norm(H.A(x) - A(x)) / np.linalg.norm(A(x)) < 1e-13
+    its = []
+    xs, info = oracle.cg(A, b, rtol=1e-6, M=lambda v: oracle.bd_precond_mult(pol, ro, v),
+                         callback=lambda v: its.append(1))
+    xh, info_h, its_h = H.solve(bh, rtol=1e-6)
+    assert info == 0 and info_h == 0 and its_h == len(its)
+    assert np.linalg.norm(xh - xs) / np.linalg.norm(xs) < 1e-9
