@@ -398,11 +398,18 @@ def main():
                               "allreduce_chunks": A.allreduce_chunks(nt),
                               "map_allreduces_per_matvec": A.collectives_issued // (args.steps + args.warmup)})
         # the same K steps in the OTHER layout of the map-domain vectors
+        # (auxiliary: a failure here is reported in the line, it does not take the headline down.  Every
+        # rank takes the same branch: an exception on one rank only would leave the others in a collective,
+        # which the launcher's timeout then ends.)
         A_o, x_o = (S["A_repl"], x) if rows else (S["A_rows"], S["x_rows"])
-        el_o = timed(A_o, x_o, args.steps, args.warmup)
-        dist_info["other_layout_point"] = {"layout": "replicated" if rows else "rows",
-                                           "ms_per_step": round(1e3 * el_o / args.steps, 4),
-                                           "value": nt_all / (el_o / args.steps), "unit": "TOD samples/s"}
+        try:
+            el_o = timed(A_o, x_o, args.steps, args.warmup)
+            dist_info["other_layout_point"] = {"layout": "replicated" if rows else "rows",
+                                               "ms_per_step": round(1e3 * el_o / args.steps, 4),
+                                               "value": nt_all / (el_o / args.steps), "unit": "TOD samples/s"}
+        except Exception as exc:                          # noqa: BLE001
+            dist_info["other_layout_point"] = {"layout": "replicated" if rows else "rows",
+                                               "error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---- per-kernel HIP-event timing on the launch stream (rank 0) --------------------
     def ev_time(fn, reps):
