@@ -73,6 +73,39 @@ def test_write_to_hdf5_reproduces_the_reference_files_content(U, tmp_path):
         os.path.join(GOLD, "testcase_block_diag_3.hdf5"), "sum")[0x03]     # IEEE_F64BE
 
 
+@pytest.mark.parametrize("case", [3, 4])
+def test_written_files_are_read_by_the_independent_walker(U, tmp_path, case):
+    """The writer's second reader: the minimal walker of tests/golden/make_hdf5_fixtures.py shares
+    no code with hdf5_lite (it was written against the h5py files of the reference, where it
+    produced the committed golden arrays) and follows the format by fixed offsets -- superblock
+    v0, root symbol table, one B-tree leaf, one SNOD, v1 object headers, contiguous v3 layout.  A
+    file from write_to_hdf5 (IOfiles.py:277-300) goes through it unchanged."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_hdf5_fixtures", os.path.join(GOLD, "make_hdf5_fixtures.py"))
+    walker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(walker)                           # defines parse(); main() is not run
+    ref = np.load(os.path.join(GOLD, "reference_inputs.npz"))
+    want = {k: ref["case%d_%s" % (case, k)] for k in ("pixel", "pol_angle", "sum", "weight")}
+    assert set(walker.parse(os.path.join(GOLD, "testcase_block_diag_%d.hdf5" % case))) == set(want)
+    p = str(tmp_path / "w.hdf5")
+    U.write_to_hdf5(p, want["pixel"], want["weight"], want["sum"], phi=want["pol_angle"])
+    got = walker.parse(p)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+        np.testing.assert_array_equal(got[k], want[k])
+    # and a file of other sizes and values than the reference's two
+    rng = np.random.default_rng(case)
+    n = 1000 * case + 7
+    pix = rng.integers(0, 12 * 64 * 64, n).astype(np.int32)
+    w = rng.standard_normal((case, 5))
+    s, phi = rng.standard_normal(n), rng.uniform(0, np.pi, n)
+    U.write_to_hdf5(p, pix, w, s, phi=phi)
+    got = walker.parse(p)
+    for k, v in (("pixel", pix), ("weight", w), ("sum", s), ("pol_angle", phi)):
+        np.testing.assert_array_equal(got[k], v)
+
+
 def test_hdf5_lite_round_trip_groups_scalars_and_many_links(tmp_path):
     from cosmomap2_amd.utilities import hdf5_lite as h5
     rng = np.random.default_rng(0)
