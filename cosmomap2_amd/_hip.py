@@ -76,6 +76,8 @@ PROTOTYPES = {
     "cm2_Zt_apply": [_i64, _int, _vp, _vp, _vp, _vp, _vp],
     "cm2_pcg": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _i64, _vp, _vp,
                 ctypes.POINTER(_i64), ctypes.POINTER(_int), _vp],
+    "cm2_pcg_sharded": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _dbl, _dbl, _i64, _vp, _vp, _int, _vp, _vp,
+                        ctypes.POINTER(_i64), ctypes.POINTER(_int), _vp],
     "cm2_arnoldi": [_i64, _vp, _vp, _vp, _vp, _dbl, _int, _vp, ctypes.POINTER(_dbl),
                     ctypes.POINTER(_int), _vp],
     "cm2_PtNP_tiles_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -186,13 +186,36 @@ extern "C" int cm2_pcg_update_xr(int64_t n, const double *d_rho, const double *d
 // tests/test_2level_preconditioner.py:52) for hosts that are not Python: the operator and the
 // preconditioner are callbacks working on device vectors on `stream`; alpha and beta never leave
 // HBM, one 8-byte copy per iteration brings ||r||^2 to the host for the stopping test.
-extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
-                       const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
-                       int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters,
-                       int *h_info, void *stream_)
+//
+// Sharded solves use the same driver: `reduce` (the HOST's collective: RCCL, MPI ...; the
+// library links none) combines device scalars over the ranks in place, queued on `stream`.
+//   layout CM2_LAYOUT_REPLICATED: every rank holds whole vectors and the operator callback returns the
+//     all-reduced product; the dots are computed redundantly and only ||r||^2 is MAX-reduced, so that
+//     every rank takes the same stop decision whatever the collective's rounding did to the copies;
+//   layout CM2_LAYOUT_ROWS: every vector is the rank's rows; b.b, rho, p.q and ||r||^2 are SUM-reduced
+//     (the callback gathers p and reduce-scatters the product).
+static int pcg_run(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+                   const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+                   int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int layout,
+                   cm2_reduce_fn reduce, void *reduce_ctx, int64_t *h_iters, int *h_info, void *stream_)
 {
-    CM2_CHECK(n >= 1 && A && d_b && d_x && h_iters && h_info, "cm2_pcg: NULL argument or n < 1");
     hipStream_t stream = as_stream(stream_);
+    // a dot product of whole-vector meaning / the squared residual norm, after the local kernel
+    auto red_dot = [&](double *d) -> int {
+        if (reduce && layout == CM2_LAYOUT_ROWS && reduce(reduce_ctx, d, 1, CM2_REDUCE_SUM, stream_)) {
+            set_error("cm2_pcg_sharded: the reduction callback failed");
+            return 1;
+        }
+        return 0;
+    };
+    auto red_rr = [&](double *d) -> int {
+        if (reduce && reduce(reduce_ctx, d, 1, layout == CM2_LAYOUT_ROWS ? CM2_REDUCE_SUM : CM2_REDUCE_MAX,
+                             stream_)) {
+            set_error("cm2_pcg_sharded: the reduction callback failed");
+            return 1;
+        }
+        return 0;
+    };
     *h_iters = 0;
     *h_info = 0;
     DevTemp<double> r, z, p, q, sc, work;
@@ -210,6 +233,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         return 0;
     };
     if (int rc = cm2_dot(n, d_b, d_b, tmp, work, stream)) return rc;
+    if (int rc = red_rr(tmp)) return rc;                   // atol is the same number on every rank
     if (int rc = fetch(tmp)) return rc;
     const double bnrm2 = sqrt(h);
     if (bnrm2 == 0.0) {                                    // x = b = 0
@@ -218,7 +242,16 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         return 0;
     }
     if (rtol * bnrm2 > atol) atol = rtol * bnrm2;
-    if (maxiter < 0) maxiter = 10 * n;
+    if (maxiter < 0) {                                     // scipy's default 10 n, n the WHOLE vector's length
+        maxiter = 10 * n;
+        if (reduce && layout == CM2_LAYOUT_ROWS) {
+            const double nl = (double)n;
+            CM2_HIP(cm2::upload(tmp, &nl, sizeof(double), stream));
+            if (int rc = red_dot(tmp)) return rc;
+            if (int rc = fetch(tmp)) return rc;
+            maxiter = 10 * (int64_t)h;
+        }
+    }
     if (x_is_zero) {
         CM2_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * n, stream));
         CM2_HIP(hipMemcpyAsync(r.p, d_b, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
@@ -245,6 +278,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
         return 0;
     };
     if (int rc = cm2_dot(n, r.p, r.p, rr, work, stream)) return rc;
+    if (int rc = red_rr(rr)) return rc;
     if (int rc = post(rr)) return rc;
     int cur = 0;
     // z = M r, rho, p of iteration `it` (cheap: always queued ahead of the stop test) and
@@ -257,13 +291,15 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
             zz = z.p;
         }
         if (int rc = cm2_dot(n, r.p, zz, rho[cur], work, stream)) return rc;
+        if (int rc = red_dot(rho[cur])) return rc;
         if (it > 0) return cm2_pcg_update_p(n, rho[cur], rho[1 - cur], zz, p.p, stream_);
         CM2_HIP(hipMemcpyAsync(p.p, zz, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
         return 0;
     };
     auto ahead_matvec = [&]() -> int {
         if (A(A_ctx, p.p, q.p, stream_)) { set_error("cm2_pcg: the operator callback failed"); return 1; }
-        return cm2_dot(n, p.p, q.p, pq, work, stream);
+        if (int rc = cm2_dot(n, p.p, q.p, pq, work, stream)) return rc;
+        return red_dot(pq);
     };
     // Running ahead with the matvec costs one iteration of GPU time when the stop test then says
     // "converged", so it is skipped when the last two residuals the host has seen predict
@@ -291,6 +327,7 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
             if (int rc = ahead_matvec()) return rc;
         if (int rc = cm2_pcg_update_xr(n, rho[cur], pq, p.p, q.p, d_x, r.p, rr, work, stream_)) return rc;
         cur = 1 - cur;
+        if (int rc = red_rr(rr)) return rc;
         if (int rc = post(rr)) return rc;
     }
     if (maxiter > 0) {
@@ -301,6 +338,30 @@ extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, v
     }
     *h_info = (int)maxiter;                                // not converged within maxiter
     return 0;
+}
+
+extern "C" int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+                       const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+                       int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters,
+                       int *h_info, void *stream_)
+{
+    CM2_CHECK(n >= 1 && A && d_b && d_x && h_iters && h_info, "cm2_pcg: NULL argument or n < 1");
+    return pcg_run(n, A, A_ctx, M, M_ctx, d_b, d_x, x_is_zero, rtol, atol, maxiter, callback, cb_ctx,
+                   CM2_LAYOUT_REPLICATED, nullptr, nullptr, h_iters, h_info, stream_);
+}
+
+extern "C" int cm2_pcg_sharded(int64_t n_local, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+                               const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+                               int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int layout,
+                               cm2_reduce_fn reduce, void *reduce_ctx, int64_t *h_iters, int *h_info,
+                               void *stream_)
+{
+    CM2_CHECK(n_local >= 1 && A && d_b && d_x && h_iters && h_info && reduce,
+              "cm2_pcg_sharded: NULL argument or n_local < 1");
+    CM2_CHECK(layout == CM2_LAYOUT_REPLICATED || layout == CM2_LAYOUT_ROWS,
+              "cm2_pcg_sharded: layout must be CM2_LAYOUT_REPLICATED or CM2_LAYOUT_ROWS");
+    return pcg_run(n_local, A, A_ctx, M, M_ctx, d_b, d_x, x_is_zero, rtol, atol, maxiter, callback, cb_ctx,
+                   layout, reduce, reduce_ctx, h_iters, h_info, stream_);
 }
 
 // Modified Gram-Schmidt Arnoldi with the reference's conventions (interfaces/deflationlib.py:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): cm2_noise_prepare_tiles added; cm2_noise_tile_kernel_info reports the one-real-window
+/* 2 (round 4): cm2_noise_prepare_tiles, cm2_set_exact_order and cm2_pcg_sharded added; cm2_noise_tile_kernel_info reports the one-real-window
  * kernel only; and the defaults that changed behind unchanged signatures since version 1 --
  * cm2_pointing_info fields 3..5 are -1 until the pixel-major copy exists, cm2_tiles_set_pt_order has
  * mode 2 and its default sums runs of more than 256 hits per slice in chunks of 32 terms,
@@ -340,6 +340,30 @@ int cm2_pcg(int64_t n, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
             const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
             int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int64_t *h_iters, int *h_info,
             void *stream);
+
+/* (e) The same solve on TOD shards, one process per GPU (the reference is one process: its
+ * block independence, interfaces/blkop.py:195-206, is what makes the cut exact).  The library links no
+ * collective library: the HOST passes its own reduction -- `reduce` combines `count` doubles at d_vals
+ * over all ranks IN PLACE, queued on `stream`, CM2_REDUCE_SUM or CM2_REDUCE_MAX (INTEGRATION.md shows
+ * the three-line RCCL form) -- and does the map-sized exchange inside its operator callback.
+ *   CM2_LAYOUT_REPLICATED: every rank holds whole map vectors (n_local = n); the A callback applies the
+ *     rank's P^T N^-1 P and all-reduces the product; dots are computed redundantly, b.b and ||r||^2 are
+ *     MAX-reduced so that every rank takes the same stop decision.
+ *   CM2_LAYOUT_ROWS: every vector (d_b, d_x, the callbacks' arguments) is the rank's n_local rows; the A
+ *     callback all-gathers its input and reduce-scatters the product; b.b, rho, p.q and ||r||^2 are
+ *     SUM-reduced (three 8-byte reductions an iteration); maxiter < 0 means 10 x the summed n_local.
+ * Every rank must make the call with the same rtol / atol / maxiter; they return the same *h_iters and
+ * *h_info.  Same recurrence and stop rule as cm2_pcg. */
+#define CM2_REDUCE_SUM 0
+#define CM2_REDUCE_MAX 1
+#define CM2_LAYOUT_REPLICATED 0
+#define CM2_LAYOUT_ROWS 1
+typedef int (*cm2_reduce_fn)(void *ctx, double *d_vals, int64_t count, int op, void *stream);
+int cm2_pcg_sharded(int64_t n_local, cm2_apply_fn A, void *A_ctx, cm2_apply_fn M, void *M_ctx,
+                    const double *d_b, double *d_x, int x_is_zero, double rtol, double atol,
+                    int64_t maxiter, cm2_iter_fn callback, void *cb_ctx, int layout,
+                    cm2_reduce_fn reduce, void *reduce_ctx, int64_t *h_iters, int *h_info,
+                    void *stream);
 
 /* a13  arnoldi (interfaces/deflationlib.py:17-113) as a C entry point, operator as a callback:
  * modified Gram-Schmidt on r0 = b - A x0 (d_x0 may be NULL = 0) with the reference's early exit
