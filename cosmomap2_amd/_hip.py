@@ -41,6 +41,7 @@ PROTOTYPES = {
     "cm2_tiles_group_tiles": [_vp, _int, ctypes.POINTER(_i64)],
     "cm2_tiles_set_pt_order": [_vp, _int],
     "cm2_tiles_prepare_pt": [_vp, _vp],
+    "cm2_tiles_pt_parts": [_vp, ctypes.POINTER(_i64)],
     "cm2_P_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_Pt_tiles_apply": [_vp, _vp, _vp, _vp],
     "cm2_i32_time_to_tiles": [_vp, _vp, _vp, _vp],

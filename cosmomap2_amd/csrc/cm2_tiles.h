@@ -5,6 +5,8 @@
 
 #include <vector>
 
+constexpr int64_t kHotTileMin = 32768;   // samples that make a one-pixel tile a hot tile (cm2_tiles_fixed.hip)
+
 struct cm2_tiles {
     int64_t nt = 0, npix = 0, nvalid = 0;
     int pol = 0;
@@ -70,6 +72,21 @@ struct cm2_tiles {
     // a source; the balanced tiling makes such a pixel a tile of its own) is reduced by many
     // workgroups, each summing a fixed range of kHotChunk consecutive samples of the bucket, and
     // the range sums are added in time order (cm2_tiles_fixed.hip)
+    // PARTS of the fixed-order P^T (round 4, cm2_tiles_fixed.hip): on a hit map that is far from
+    // uniform the tiles keep their width (only a pixel heavy enough for the hot-tile path becomes a
+    // tile of its own) and the SLICES of a heavy tile are shared out to several workgroups, each
+    // summing its consecutive slices in time order into its own copy of the tile; k_parts_combine adds
+    // the copies in time order.  Part boundaries depend on the plan only: reproducible bit for bit;
+    // a regrouped sum, ~1e-16 relative away from the serial one.  pt_split = the plan may do this
+    // (set at create: unbalanced hit map, neither the equal-load cut nor the exact order asked for).
+    bool pt_split = false;
+    std::vector<int64_t> tile_part0;    // [ntiles+1] first part of every tile (empty: no parts)
+    std::vector<int64_t> multi_tile;    // tiles with more than one part, ascending
+    int4 *d_parts = nullptr;            // [nparts] {tile, slices, first slice, scratch slot or -1}
+    int64_t *d_multi = nullptr;         // [nmulti][4] offset in the map, values, first scratch slot, parts
+    double *d_part_buf = nullptr;       // [scratch slots][tp * pol]
+    int64_t nparts = 0, part_slots = 0;
+    double part_makespan = 0.0;         // simulated finish time / ideal, 2 workgroups per CU
     std::vector<int64_t> hot_tile, hot_chunk0;   // tile index, first chunk of every hot tile (+ total)
     uint8_t *d_hot_flag = nullptr;               // [ntiles]
     int64_t *d_hot_range = nullptr;              // [chunks][2] first / one-past-last TB position
@@ -86,6 +103,7 @@ int64_t fx_designed_bytes(const cm2_tiles *t);
 // mean groups per slice of the fixed-order lists and the fraction of slices with more groups than the
 // workgroup has threads, counted on every 8th slice of the plan's segments (slice length: fx_max_slice)
 int fx_groups_estimate(const cm2_tiles *t, hipStream_t st, double *mean_groups, double *over);
+int fx_parts_info(const cm2_tiles *t, int64_t *h_info);   // cm2_tiles_pt_parts
 int fx_max_slice(const cm2_tiles *t);      // longest slice (samples) the fixed-order kernel's LDS budget allows
 bool fx_serial_build();                    // CM2_FX_BUILD=serial (the reference builders: global tile order only)
 }  // namespace cm2

@@ -860,16 +860,33 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     // waiting for the heaviest tiles.  When some uniform tile holds over 25 % more than the mean,
     // the pixel ranges are re-cut to equal sample counts (width <= tile_pixels): every pixel is
     // still summed by one workgroup in time order, so results do not change by a bit.
+    // Round 4: by default such a hit map keeps the uniform tile width instead, and the fixed-order P^T
+    // shares the slices of its heavy tiles out to several workgroups (pt_split; cm2_tiles.h, "PARTS"):
+    // narrow dense tiles see many hits per pixel and slice (runs of 5-8 list entries in two level
+    // passes) and halve the address runs of the overlap-save kernel.  Only a pixel heavy enough for
+    // the hot-tile path is cut out as a tile of its own.  CM2_TILE_BALANCE: 0 = uniform tiles, one
+    // workgroup each; 1 / cut = the equal-load cut (also chosen when the exact summation order is
+    // asked for: it does not change a bit); parts = split even when the hit map is even.
     const char *bal = getenv("CM2_TILE_BALANCE");
-    bool balance = false;
+    bool balance = false, split = false;
+    double mean_load = 0.0;
     {
         int64_t nmax = 0;
         for (int64_t b = 0; b < t->ntiles; ++b)
             if (off[(size_t)b + 1] - off[(size_t)b] > nmax) nmax = off[(size_t)b + 1] - off[(size_t)b];
-        const double mean = (double)off[(size_t)t->ntiles] / (double)(t->ntiles > 0 ? t->ntiles : 1);
-        balance = t->ntiles >= 64 && off[(size_t)t->ntiles] >= (1 << 20) && (double)nmax > 1.25 * mean;
-        if (bal) balance = atoi(bal) != 0 && off[(size_t)t->ntiles] > 0;
+        mean_load = (double)off[(size_t)t->ntiles] / (double)(t->ntiles > 0 ? t->ntiles : 1);
+        const bool uneven = t->ntiles >= 64 && off[(size_t)t->ntiles] >= (1 << 20) && (double)nmax > 1.25 * mean_load;
+        const bool some = off[(size_t)t->ntiles] > 0;
+        if (!bal) {
+            balance = uneven && t->pt_fixed == 2;      // (CM2_PT_ORDER=exact / cm2_set_exact_order(1), read above)
+            split = uneven && !balance;
+        } else if (strcmp(bal, "parts") == 0) {
+            split = some;
+        } else if (strcmp(bal, "cut") == 0 || atoi(bal) != 0) {
+            balance = some;
+        }
     }
+    t->pt_split = split;
     DevTemp<int64_t> d_p0;
     if (balance) {
         DevTemp<unsigned int> d_hits;
@@ -927,6 +944,38 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
         CM2_HIP(d_p0.alloc(p0v.size()));
         CM2_HIP(cm2::upload(d_p0.p, p0v.data(), sizeof(int64_t) * p0v.size(), nullptr));
         if (int rc = partition(d_p0.p)) return rc;
+    }
+    if (split) {
+        int64_t nmax = 0;
+        for (int64_t b = 0; b < t->ntiles; ++b)
+            if (off[(size_t)b + 1] - off[(size_t)b] > nmax) nmax = off[(size_t)b + 1] - off[(size_t)b];
+        const int64_t hot_min = (int64_t)(0.5 * mean_load) > kHotTileMin ? (int64_t)(0.5 * mean_load) : kHotTileMin;
+        if (nmax >= hot_min) {                              // (otherwise no pixel can be that heavy)
+            DevTemp<unsigned int> d_hits;
+            CM2_HIP(d_hits.alloc(npix));
+            CM2_HIP(hipMemsetAsync(d_hits, 0, sizeof(unsigned int) * npix, stream));
+            k_pix_hist<<<grid_for(nt), kBlock, 0, stream>>>(d_pix, nt, npix, d_hits);
+            CM2_LAUNCH_OK();
+            std::vector<unsigned int> hits((size_t)npix);
+            CM2_HIP(cm2::download(hits.data(), d_hits, sizeof(unsigned int) * npix, stream));
+            CM2_HIP(hipStreamSynchronize(stream));
+            std::vector<int64_t> p0v(1, 0);
+            bool any = false;
+            for (int64_t p = 1; p < npix; ++p) {
+                const bool hot_here = (int64_t)hits[(size_t)p] >= hot_min, hot_before = (int64_t)hits[(size_t)p - 1] >= hot_min;
+                if (p % tile_pixels == 0 || hot_here || hot_before) p0v.push_back(p);
+                any = any || hot_here || hot_before;
+            }
+            p0v.push_back(npix);
+            if (any) {
+                t->ntiles = (int64_t)p0v.size() - 1;
+                t->tile_p0 = p0v;
+                CM2_HIP(d_p0.alloc(p0v.size()));
+                CM2_HIP(cm2::upload(d_p0.p, p0v.data(), sizeof(int64_t) * p0v.size(), nullptr));
+                if (int rc = partition(d_p0.p)) return rc;
+                balance = true;                             // (the kernels below read the re-cut boundaries)
+            }
+        }
     }
     t->balanced = balance;
     CM2_HIP(cm2::dev_malloc(&t->d_tile_p0, sizeof(int64_t) * (t->ntiles + 1)));
@@ -1090,6 +1139,12 @@ extern "C" int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info)
     h_info[8] = t->fx_S; h_info[9] = cm2::fx_designed_bytes(t);
     h_info[10] = t->nspans; h_info[11] = t->span_samples;
     return 0;
+}
+
+extern "C" int cm2_tiles_pt_parts(const cm2_tiles *t, int64_t *h_info)
+{
+    CM2_CHECK(t && h_info, "cm2_tiles_pt_parts: NULL argument");
+    return cm2::fx_parts_info(t, h_info);
 }
 
 extern "C" int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream_)

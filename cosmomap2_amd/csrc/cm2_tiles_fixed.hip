@@ -39,6 +39,7 @@
 //     thread and slice, and no dependent round trip).
 #include "cm2_tiles.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     const double2 *__restrict__ gb, const uint2 *__restrict__ trun,
     const uint32_t *__restrict__ tent, const double *__restrict__ ta,
     const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out,
-    uint32_t chunk_min, const uint8_t *__restrict__ hot)
+    uint32_t chunk_min, const uint8_t *__restrict__ hot, const int4 *__restrict__ parts,
+    int part0, double *__restrict__ scratch)
 {
     constexpr int D = kFxDepth;
     constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
@@ -89,14 +91,27 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     double *vbuf1 = vbuf0 + VPT * kFxT;
     double *part = vbuf1 + VPT * kFxT;                   // 3 x kFxMaxChunks chunk sums of hot runs
     const int tid = threadIdx.x;
-    const int b = tile0 + blockIdx.x;
+    // the workgroup's work: a whole tile, or (plans with parts) some consecutive slices of one, summed
+    // into a scratch copy of the tile that k_parts_combine adds to the other parts' copies
+    int b = tile0 + (int)blockIdx.x, nsl = 0;
+    int64_t s0 = 0;
+    double *o_part = nullptr;
+    if (parts) {
+        const int4 pd = parts[part0 + (int)blockIdx.x];
+        b = pd.x;
+        nsl = pd.y;
+        s0 = pd.z;
+        if (pd.w >= 0) o_part = scratch + (int64_t)pd.w * ((int64_t)tp * POL);
+    }
     if (hot && hot[b]) return;                           // reduced by k_Pt_hot (many workgroups)
     const int64_t p0 = tile_p0[b];
     const int64_t np = tile_p0[b + 1] - p0;
     const int nvals = (int)(np * POL);
     for (int i = tid; i < nvals; i += kFxT) tile[i] = 0.0;
-    const int64_t s0 = slice0[b];
-    const int nsl = (int)(slice0[b + 1] - s0);
+    if (!parts) {
+        s0 = slice0[b];
+        nsl = (int)(slice0[b + 1] - s0);
+    }
 
     // register ring: slice j lives in slot j % D from the moment slice j - D has been staged.
     // All loads are unconditional (indices clamped) and kept together per slice, so that the
@@ -308,8 +323,22 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
         }
     }
     __syncthreads();
-    double *o = out + p0 * POL;
+    double *o = o_part ? o_part : out + p0 * POL;
     for (int i = tid; i < nvals; i += kFxT) o[i] = tile[i];
+}
+
+// the copies of a split tile added in time order (part after part), written to the map
+__global__ __launch_bounds__(256) void k_parts_combine(const int64_t *__restrict__ multi, int64_t m0,
+                                                        int64_t stride, const double *__restrict__ scratch,
+                                                        double *__restrict__ out)
+{
+    const int64_t *m = multi + 4 * (m0 + blockIdx.x);
+    const int64_t o = m[0], nvals = m[1], slot = m[2], k = m[3];
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;       // one value per thread: the launch is short
+    if (i >= nvals) return;
+    double acc = scratch[slot * stride + i];
+    for (int64_t j = 1; j < k; ++j) acc += scratch[(slot + j) * stride + i];
+    out[o + i] = acc;
 }
 
 // ------------------------------------------------------------------- hot tiles ------
@@ -320,7 +349,8 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
 // order depends on the bucket's length only: reproducible bit for bit, independent of the rest of
 // the hit map; a regrouping of the serial sum, ~1e-16 relative per level away from it.
 constexpr int kHotChunk = 16384, kHotT = 256;
-constexpr int64_t kHotMin = 2 * kHotChunk;              // samples that make a one-pixel tile hot
+constexpr int64_t kHotMin = kHotTileMin;                // samples that make a one-pixel tile hot
+static_assert(kHotMin == 2 * kHotChunk, "hot tiles: at least two ranges");
 
 template <int POL, bool HALF>
 __global__ __launch_bounds__(kHotT) void k_Pt_hot(const int64_t *__restrict__ range, int64_t c0,
@@ -861,11 +891,17 @@ void fx_release(cm2_tiles *t)
     hot_release(t);
     void **ptrs[] = {(void **)&t->d_fx_slice0, (void **)&t->d_fx_sk, (void **)&t->d_fx_meta, (void **)&t->d_fx_gent,
                      (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
-                     (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb};
+                     (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb,
+                     (void **)&t->d_parts, (void **)&t->d_multi,
+                     (void **)&t->d_part_buf};
     for (void **q : ptrs) {
         if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
     }
+    t->tile_part0.clear();
+    t->multi_tile.clear();
+    t->nparts = t->part_slots = 0;
+    t->part_makespan = 0.0;
     t->fx_S = 0;
     t->fx_ngroups = t->fx_nslices = 0;
 }
@@ -1130,6 +1166,151 @@ int fx_build(cm2_tiles *t, int S, hipStream_t st, double *mean_groups, double *o
     return 0;
 }
 
+// ------------------------------------------------------------------- parts ----------
+// Finish time of `items` (samples each, in dispatch order) over the ideal (total / slots).  `slots`
+// workgroups are resident and take the next item as one finishes; the kernel is bandwidth bound, so the
+// resident workgroups share the chip's rate equally -- but one workgroup alone cannot use more than
+// about 1.5 x its share of the full chip (measured at C4 size: a slice takes 3.7 us with 512 workgroups
+// resident, 2.5 us with 51), which is what makes a few items left over at the end expensive.
+static double parts_makespan(const std::vector<int64_t> &items, int slots)
+{
+    const double rmax = 1.5;
+    std::vector<double> heap;                               // min-heap: finish "virtual time" of the active items
+    auto cmp = [](double a, double b2) { return a > b2; };
+    double V = 0.0, T = 0.0, total = 0.0;                   // virtual time (work done per active item), real time
+    size_t next = 0;
+    auto rate = [&]() {
+        const double fair = (double)slots / (double)(heap.empty() ? 1 : heap.size());
+        return fair < rmax ? fair : rmax;
+    };
+    for (; next < items.size() && (int)heap.size() < slots; ++next) {
+        heap.push_back((double)items[next] + 4096.0);      // (+ zeroing and writing the tile copy)
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    for (int64_t x : items) total += (double)x + 4096.0;
+    while (!heap.empty()) {
+        const double vf = heap.front();
+        T += (vf - V) / rate();
+        V = vf;
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.pop_back();
+        if (next < items.size()) {
+            heap.push_back(V + (double)items[next++] + 4096.0);
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    return total > 0.0 ? T * (double)slots / total : 1.0;
+}
+
+// Shares the slices of heavy tiles out to several workgroups (see cm2_tiles.h).  The part length is
+// chosen by simulation: a tile of more than 1.1 x target samples is cut into ceil(load / target) parts
+// of equal slice counts, for targets between 1.25 and 0.2 of the mean load per resident workgroup; the
+// target with the earliest simulated finish wins (fewer parts on a tie).  Parts are dispatched in tile
+// order, i.e. by ascending address: dispatched by descending load instead (which scatters the
+// workgroups' streams over the buffers) the same parts took 0.45 instead of 0.42 ms at C4 size
+// (profiles/r04_uneven_parts.md).  CM2_PT_PARTS=0 keeps one workgroup per tile, CM2_PT_PARTS=<samples>
+// fixes the target.
+int parts_plan(cm2_tiles *t, hipStream_t st)
+{
+    if (!t->pt_split || t->fx_nslices == 0) return 0;
+    int forced = -1;
+    if (const char *e = getenv("CM2_PT_PARTS")) forced = atoi(e);
+    if (forced == 0) return 0;
+    std::vector<int64_t> slice0, k0;
+    fx_slices(t, t->fx_S, slice0, k0);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // (two workgroups per CU when their LDS fits twice, fx_max_slice)
+    const int slots = (fx_lds_bytes(t, t->fx_S) <= 79 * 1024 ? 2 : 1) * (cus > 0 ? cus : 256);
+    std::vector<int64_t> load((size_t)t->ntiles, 0);
+    int64_t total = 0;
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        if (fx_hot_tile(t, b)) continue;
+        load[(size_t)b] = t->tile_count[(size_t)b];
+        total += load[(size_t)b];
+    }
+    if (total == 0) return 0;
+    auto parts_of = [&](int64_t b, int64_t target) -> int64_t {
+        const int64_t ns = slice0[(size_t)b + 1] - slice0[(size_t)b];
+        if (load[(size_t)b] * 10 <= target * 11 || ns <= 1) return 1;
+        int64_t k = (load[(size_t)b] + target - 1) / target;
+        return k < ns ? k : ns;
+    };
+    auto items_for = [&](int64_t target, std::vector<int64_t> &items) {
+        items.clear();
+        for (int64_t b = 0; b < t->ntiles; ++b) {
+            if (load[(size_t)b] == 0) continue;
+            const int64_t k = parts_of(b, target);
+            for (int64_t j = 0; j < k; ++j) items.push_back(load[(size_t)b] / k);
+        }
+    };
+    const double per_slot = (double)total / (double)slots;
+    int64_t best_target = 0;
+    double best = 1e30;
+    size_t best_items = 0;
+    std::vector<int64_t> items;
+    if (forced > 0) {
+        best_target = forced;
+        items_for(best_target, items);
+        best = parts_makespan(items, slots);
+    } else {
+        // one workgroup per tile is kept unless some split finishes at least 5 % earlier; among the
+        // splits the earliest finish, and the fewest parts within 1 % of it
+        items_for(INT64_MAX / 16, items);
+        const double whole = parts_makespan(items, slots);
+        for (int step = 0; step <= 42; ++step) {
+            const int64_t target = (int64_t)(per_slot * (1.25 - 0.025 * step)) + 1;
+            if (target < 4 * t->fx_S) break;                // (parts of a few slices only: not worth a copy)
+            items_for(target, items);
+            const double mk = parts_makespan(items, slots);
+            if (mk < best - 0.01 || (mk < best + 0.01 && items.size() < best_items)) {
+                best = mk;
+                best_target = target;
+                best_items = items.size();
+            }
+        }
+        if (best > 0.95 * whole) best_target = 0;
+    }
+    if (best_target == 0) return 0;
+    // the parts in tile order (= dispatch order), their scratch slots (split tiles only)
+    std::vector<int4> parts;
+    std::vector<int64_t> multi;
+    t->tile_part0.assign((size_t)t->ntiles + 1, 0);
+    int64_t slot = 0;
+    for (int64_t b = 0; b < t->ntiles; ++b) {
+        t->tile_part0[(size_t)b] = (int64_t)parts.size();
+        const int64_t s0 = slice0[(size_t)b], ns = slice0[(size_t)b + 1] - s0;
+        const int64_t k = load[(size_t)b] ? parts_of(b, best_target) : 1;
+        if (k > 1) {
+            t->multi_tile.push_back(b);
+            multi.push_back(t->tile_p0[(size_t)b] * t->pol);
+            multi.push_back((t->tile_p0[(size_t)b + 1] - t->tile_p0[(size_t)b]) * t->pol);
+            multi.push_back(slot);
+            multi.push_back(k);
+        }
+        for (int64_t j = 0; j < k; ++j) {
+            const int64_t a = s0 + ns * j / k, e = s0 + ns * (j + 1) / k;
+            parts.push_back(make_int4((int)b, (int)(e - a), (int)a, k > 1 ? (int)(slot + j) : -1));
+        }
+        if (k > 1) slot += k;
+    }
+    t->tile_part0[(size_t)t->ntiles] = (int64_t)parts.size();
+    if (t->multi_tile.empty()) {                            // nothing to split after all
+        t->tile_part0.clear();
+        return 0;
+    }
+    t->nparts = (int64_t)parts.size();
+    t->part_slots = slot;
+    t->part_makespan = best;
+    CM2_HIP(cm2::dev_malloc(&t->d_parts, sizeof(int4) * parts.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_multi, sizeof(int64_t) * multi.size()));
+    CM2_HIP(cm2::dev_malloc(&t->d_part_buf, sizeof(double) * (size_t)slot * (size_t)t->tp * (size_t)t->pol));
+    CM2_HIP(cm2::upload(t->d_parts, parts.data(), sizeof(int4) * parts.size(), st));
+    CM2_HIP(cm2::upload(t->d_multi, multi.data(), sizeof(int64_t) * multi.size(), st));
+    CM2_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 template <int POL, bool HALF, int VPT>
 int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
                    int64_t tile_hi, hipStream_t stream)
@@ -1137,14 +1318,30 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
     const size_t lds = fx_lds_bytes(t, t->fx_S);
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
-    k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(tile_hi - tile_lo), kFxT, lds, stream>>>(
+    // plans with parts (and not the exact order): the workgroups are the parts of the tiles in range, in
+    // tile (= address) order; then the copies of the split tiles are added up
+    const bool parts = t->d_parts && t->pt_fixed != 2;
+    const int64_t q0 = parts ? t->tile_part0[(size_t)tile_lo] : tile_lo;
+    const int64_t q1 = parts ? t->tile_part0[(size_t)tile_hi] : tile_hi;
+    k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(q1 - q0), kFxT, lds, stream>>>(
         t->tp, t->d_tile_p0, (int)tile_lo, t->d_fx_sk, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
         t->d_fx_tb, d_tod_tb, d_out,
         t->pt_fixed == 2 ? 0xFFFFFFFFu : (uint32_t)kFxChunkMinDefault,
-        t->pt_fixed == 2 ? nullptr : t->d_hot_flag);
+        t->pt_fixed == 2 ? nullptr : t->d_hot_flag, parts ? t->d_parts : nullptr, (int)q0, t->d_part_buf);
     CM2_LAUNCH_OK();
+    if (parts) {
+        int64_t m0 = 0, m1 = (int64_t)t->multi_tile.size();
+        while (m0 < m1 && t->multi_tile[(size_t)m0] < tile_lo) ++m0;
+        while (m1 > m0 && t->multi_tile[(size_t)m1 - 1] >= tile_hi) --m1;
+        if (m1 > m0) {
+            const dim3 cgrid((unsigned)(m1 - m0), (unsigned)(((int64_t)t->tp * t->pol + 255) / 256));
+            k_parts_combine<<<cgrid, 256, 0, stream>>>(t->d_multi, m0, (int64_t)t->tp * t->pol,
+                                                                     t->d_part_buf, d_out);
+            CM2_LAUNCH_OK();
+        }
+    }
     if (t->pt_fixed != 2 && t->d_hot_flag)
         return hot_launch<POL, HALF>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
     return 0;
@@ -1185,6 +1382,15 @@ int fx_max_slice(const cm2_tiles *t)
     }
     while (smax > 256 && fx_lds_bytes(t, smax) > 159 * 1024) smax -= 256;
     return smax;
+}
+
+int fx_parts_info(const cm2_tiles *t, int64_t *h_info)
+{
+    h_info[0] = t->d_parts ? t->nparts : t->ntiles;
+    h_info[1] = (int64_t)t->multi_tile.size();
+    h_info[2] = (int64_t)sizeof(double) * t->part_slots * t->tp * t->pol;
+    h_info[3] = (int64_t)(1000.0 * t->part_makespan + 0.5);
+    return 0;
 }
 
 int64_t fx_designed_bytes(const cm2_tiles *t)
@@ -1259,8 +1465,10 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
             }
         }
     }
-    if (!t->d_hot_flag && t->hot_chunk0.empty())
+    if (!t->d_hot_flag && t->hot_chunk0.empty()) {
         if (int rc = hot_plan(t, st)) return rc;
+        if (int rc = parts_plan(t, st)) return rc;
+    }
     mark.ok = true;
     *use = true;
     return 0;

@@ -213,6 +213,15 @@ class _TileHandle(object):
         info = self._info()
         return int(info[8]), int(info[9])
 
+    def pt_parts(self):
+        """Work items of the fixed-order P^T (after the lists exist): workgroups per application,
+        tiles whose slices are shared out to several workgroups (uneven hit maps), bytes of the tile
+        copies they write, simulated finish time over the ideal."""
+        info = (ctypes.c_int64 * 4)()
+        _hip.call("cm2_tiles_pt_parts", self.h, info)
+        return {"workgroups": int(info[0]), "tiles_split": int(info[1]), "copy_bytes": int(info[2]),
+                "simulated_finish_over_ideal": int(info[3]) / 1000.0}
+
     def pixel_range(self, tile_lo, tile_hi):
         """Pixels [p0, p1) covered by the tiles [tile_lo, tile_hi) (tiles are not of equal width when
         the plan balanced them for an uneven hit map)."""

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): cm2_noise_prepare_tiles, cm2_set_exact_order and cm2_pcg_sharded added; cm2_noise_tile_kernel_info reports the one-real-window
+/* 2 (round 4): cm2_noise_prepare_tiles, cm2_set_exact_order, cm2_pcg_sharded and cm2_tiles_pt_parts added;
+ * uneven hit maps keep uniform tiles and split the heavy ones over workgroups (cm2_tiles_pixel_range); cm2_noise_tile_kernel_info reports the one-real-window
  * kernel only; and the defaults that changed behind unchanged signatures since version 1 --
  * cm2_pointing_info fields 3..5 are -1 until the pixel-major copy exists, cm2_tiles_set_pt_order has
  * mode 2 and its default sums runs of more than 256 hits per slice in chunks of 32 terms,
@@ -157,11 +158,21 @@ int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
  * launches kernels, so it may be captured into a graph or issued from several host threads.  A plan
  * that was not prepared builds the lists on its first P^T under a lock.  No-op for the atomic form. */
 int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream);
+/* Work items of the fixed-order P^T after cm2_tiles_prepare_pt: h_info[0..3] = workgroups per
+ * application (= tiles when no tile is split), tiles that are split, bytes of the tile copies, and
+ * 1000 x (simulated finish time of the items on two resident workgroups per CU / ideal). */
+int cm2_tiles_pt_parts(const cm2_tiles *t, int64_t *h_info);
 /* h_p0p1[0..1] = pixel range [p0, p1) covered by the tiles [tile_lo, tile_hi).  Tiles are uniform
- * (tile_pixels wide) unless the hit map is uneven: when a uniform tile would hold over 25 % more
- * samples than the mean, the pixel ranges are cut to equal sample counts instead (never wider than
- * tile_pixels), because the fixed-order P^T gives a tile to one workgroup.  Results are the same
- * bit for bit either way.  CM2_TILE_BALANCE=0 / 1 forces the choice. */
+ * (tile_pixels wide).  On an uneven hit map (a uniform tile holding over 25 % more samples than the
+ * mean) the fixed-order P^T shares the slices of the heavy tiles out to several workgroups, each
+ * summing consecutive slices in time order into its own copy of the tile, and adds the copies in time
+ * order: a fixed regrouping of the serial sum (part boundaries depend on the plan only: reproducible
+ * bit for bit; ~1e-16 relative away from the serial sum); a pixel with at least 32768 samples and half
+ * a tile's mean load becomes a one-pixel tile of its own (summed as described at
+ * cm2_tiles_set_pt_order).  CM2_TILE_BALANCE: 0 = uniform tiles, one workgroup each; 1 / cut = pixel
+ * ranges re-cut to equal sample counts (never wider than tile_pixels), one workgroup each -- the same
+ * bits as the uniform tiling, chosen automatically when the exact order is asked for
+ * (cm2_set_exact_order, CM2_PT_ORDER=exact); parts = the default on uneven maps, forced. */
 int cm2_tiles_pixel_range(const cm2_tiles *t, int64_t tile_lo, int64_t tile_hi, int64_t *h_p0p1);
 /* h_tiles[0..ngroups]: group g = tiles [h_tiles[g], h_tiles[g+1]) -- consecutive pieces of the map
  * for cm2_Pt_tiles_apply_range whose pixel boundaries depend on npix and tile_pixels only, so that

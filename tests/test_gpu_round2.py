@@ -795,10 +795,12 @@ def test_tile_plan_without_a_sort_equals_the_sorted_plan(cm, oracle, monkeypatch
 
 
 def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkeypatch):
-    """Half of the samples on a tenth of the map: the tile plan re-cuts its pixel ranges to equal
-    sample counts (the fixed-order P^T gives a tile to one workgroup), P^T N^-1 P does not change
-    by a bit against the uniform tiling, and the groups of tiles a sharded run reduces cover the
-    same pixels in both plans."""
+    """Half of the samples on a tenth of the map.  CM2_TILE_BALANCE=cut re-cuts the pixel ranges to
+    equal sample counts (the fixed-order P^T gives a tile to one workgroup): P^T N^-1 P does not
+    change by a bit against the uniform tiling.  The default (round 4) keeps the uniform tiles and
+    shares the slices of the heavy ones out to several workgroups whose tile copies are added in time
+    order: a fixed regrouping, within 1e-14 of the serial order.  The groups of tiles a sharded run
+    reduces cover the same pixels in every plan."""
     import ctypes
     from types import SimpleNamespace
     from cosmomap2_amd import _hip
@@ -815,8 +817,9 @@ def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkey
     kk = np.arange(lam)
     bands = [(1.0 + 0.1 * b) * np.exp(-kk / 9.0) for b in range(nblk)]
     x = rng.standard_normal(pol * npix)
-    out, tiles, groups = {}, {}, {}
-    for mode in ("0", None):
+    out, tiles, groups, split = {}, {}, {}, {}
+    monkeypatch.setenv("CM2_PT_PARTS", "9000")      # (parts of 9000 samples: the automatic choice needs
+    for mode in ("0", "cut", None):                 #  more samples per workgroup than this problem has)
         if mode is None:
             monkeypatch.delenv("CM2_TILE_BALANCE", raising=False)
         else:
@@ -826,9 +829,13 @@ def test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkey
         N = cm.I.BlockLO(nt // nblk, bands, offdiag=True, method=3)
         out[mode] = np.asarray(L._TiledNormalLO(P, N) * x)
         tiles[mode] = T.ntiles
+        split[mode] = T.pt_parts()
         cuts = (ctypes.c_int64 * 5)()
         _hip.call("cm2_tiles_group_tiles", T.h, 4, cuts)
         groups[mode] = [T.pixel_range(int(cuts[g]), int(cuts[g + 1])) for g in range(4)]
-    assert tiles["0"] == npix // 128 and tiles[None] != tiles["0"]          # re-cut on its own
-    assert np.array_equal(out["0"], out[None])
-    assert groups["0"] == groups[None] and groups[None][0][0] == 0 and groups[None][-1][1] == npix
+    assert tiles["0"] == npix // 128 and tiles["cut"] != tiles["0"] and tiles[None] == tiles["0"]
+    assert np.array_equal(out["0"], out["cut"])
+    assert split["0"]["tiles_split"] == 0 and split["cut"]["tiles_split"] == 0
+    assert split[None]["tiles_split"] >= 30 and split[None]["workgroups"] > tiles[None] + 60, split[None]
+    assert np.abs(out[None] - out["0"]).max() <= 1e-14 * np.abs(out["0"]).max()
+    assert groups["0"] == groups["cut"] == groups[None] and groups[None][0][0] == 0 and groups[None][-1][1] == npix

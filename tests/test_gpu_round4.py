@@ -286,3 +286,86 @@ def test_span_auto_follows_the_measured_lists(cm, oracle, monkeypatch):
     _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(D.f64(v)), D.ptr(v_tb), D.stream())
     _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), D.stream())
     np.testing.assert_array_equal(out.cpu().numpy(), oracle.sparse_rmult(pol, npix, pairs, c, s, v))
+
+
+@pytest.mark.parametrize("parts,pol,angles,hot_pixel", [("6000", 3, "full", False), ("20000", 3, "half", False),
+                                                      ("6000", 1, "half", False), ("9000", 2, "full", False),
+                                                      ("6000", 3, "full", True), (None, 3, "half", False)])
+def test_heavy_tiles_are_shared_out_to_several_workgroups(cm, oracle, monkeypatch, parts, pol, angles, hot_pixel):
+    """Uneven hit map, uniform tiles, the slices of the heavy tiles summed by several workgroups and
+    their tile copies added in time order (cm2_tiles.h "PARTS").  Against the oracle's serial loop
+    (1e-13; the one-workgroup-per-tile plan gives its bits), reproducible from call to call, the same
+    bits whether P^T is applied at once or group of tiles by group of tiles, and the exact order
+    (cm2_tiles_set_pt_order(t, 2)) back to the serial bits.  A pixel with a large share of the samples
+    becomes a tile of its own inside the uniform grid."""
+    import ctypes
+    from types import SimpleNamespace
+    from cosmomap2_amd import _hip, device as D
+    from cosmomap2_amd.interfaces import linearoperators as L
+    monkeypatch.setenv("CM2_TILE_ANGLES", angles)
+    if parts is None:
+        monkeypatch.delenv("CM2_PT_PARTS", raising=False)
+        nt, npix, tp = 1 << 23, 49152, 256           # large enough for the automatic part length
+    else:
+        monkeypatch.setenv("CM2_PT_PARTS", parts)
+        nt, npix, tp = 1 << 21, 49152, 128
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, npix, nt).astype(np.int32)
+    dense = rng.random(nt) < 0.5
+    pairs[dense] = pairs[dense] % (npix // 10)
+    if hot_pixel:
+        pairs[rng.random(nt) < 0.1] = 777
+    pairs[rng.random(nt) < 0.02] = -1
+    phi = 0.3 + 0.0785 * np.arange(nt)
+    c, s = np.cos(2 * phi), np.sin(2 * phi)
+    v = rng.standard_normal(nt)
+    want = oracle.sparse_rmult(pol, npix, pairs, c, s, v)
+    st = D.stream()
+
+    def plan():
+        P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
+        T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
+        v_tb = D.empty(T.nvalid)
+        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(D.f64(v)), D.ptr(v_tb), st)
+        return P, T, v_tb
+
+    def apply(T, v_tb):
+        out = D.empty(pol * npix)
+        out.fill_(np.nan)
+        _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), st)
+        return out.cpu().numpy()
+
+    monkeypatch.setenv("CM2_TILE_BALANCE", "0")
+    P0, T0, v0 = plan()
+    one_wg = apply(T0, v0)
+    if angles == "full" and not hot_pixel:
+        np.testing.assert_array_equal(one_wg, want)
+    monkeypatch.delenv("CM2_TILE_BALANCE")
+    P1, T1, v1 = plan()
+    info = T1.pt_parts()
+    nuniform = (npix + tp - 1) // tp
+    assert T1.ntiles == nuniform + (2 if hot_pixel else 0), (T1.ntiles, nuniform)
+    assert info["tiles_split"] >= 10 and info["workgroups"] >= T1.ntiles + info["tiles_split"], info
+    assert info["copy_bytes"] > 0 and 0.9 < info["simulated_finish_over_ideal"] < 3.0, info
+    got = apply(T1, v1)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-13 * scale
+    if not hot_pixel:
+        assert np.abs(got - one_wg).max() <= 1e-14 * scale      # (two orders of ~850 terms: rounding only)
+    np.testing.assert_array_equal(apply(T1, v1), got)                       # reproducible
+    # group of tiles by group of tiles (what a sharded run does): the same bits
+    cuts = (ctypes.c_int64 * 5)()
+    _hip.call("cm2_tiles_group_tiles", T1.h, 4, cuts)
+    pieces = D.empty(pol * npix)
+    pieces.fill_(np.nan)
+    for g in (2, 0, 3, 1):
+        _hip.call("cm2_Pt_tiles_apply_range", T1.h, D.ptr(v1), D.ptr(pieces), int(cuts[g]), int(cuts[g + 1]), st)
+    np.testing.assert_array_equal(pieces.cpu().numpy(), got)
+    # exact order: one workgroup per tile again, the serial bits
+    T1.set_pt_order(2)
+    T0.set_pt_order(2)
+    np.testing.assert_array_equal(apply(T1, v1), apply(T0, v0))
+    if angles == "full":
+        np.testing.assert_array_equal(apply(T1, v1), want)
+    T1.set_pt_order(1)
+    np.testing.assert_array_equal(apply(T1, v1), got)
