@@ -343,12 +343,12 @@ __global__ __launch_bounds__(256) void k_parts_combine(const int64_t *__restrict
 
 // ------------------------------------------------------------------- hot tiles ------
 // A tile that is one pixel with very many samples: its bucket is cut into ranges of kHotChunk
-// consecutive samples; one workgroup per range, thread t adding the terms at positions t, t + 256,
-// ... of the range in that order, the 256 thread sums combined by a fixed halving tree; k_hot_combine
+// consecutive samples; one workgroup per range, thread t adding the terms at positions t, t + 1024,
+// ... of the range in that order, the 1024 thread sums combined by a fixed halving tree; k_hot_combine
 // then adds the range sums of a tile in time order and writes the pixel.  Every boundary and every
 // order depends on the bucket's length only: reproducible bit for bit, independent of the rest of
 // the hit map; a regrouping of the serial sum, ~1e-16 relative per level away from it.
-constexpr int kHotChunk = 16384, kHotT = 256;
+constexpr int kHotChunk = 16384, kHotT = 1024;          // (1024 threads: 306 workgroups of 256 left the chip with one wave per SIMD, 45 us for 5e6 samples)
 constexpr int64_t kHotMin = kHotTileMin;                // samples that make a one-pixel tile hot
 static_assert(kHotMin == 2 * kHotChunk, "hot tiles: at least two ranges");
 
@@ -365,22 +365,38 @@ __global__ __launch_bounds__(kHotT) void k_Pt_hot(const int64_t *__restrict__ ra
     const int64_t k0 = range[2 * c], k1 = range[2 * c + 1];
     const int t = threadIdx.x;
     double sv = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int64_t k = k0 + t; k < k1; k += kHotT) {
-        const double v = v_tb[k];
-        sv += v;
-        if (POL > 1) {
-            double cc, ss;
-            if (HALF) {
-                const double h = a_tb[k], h2 = h * h, inv = 1.0 / (1.0 + h2);
-                cc = (1.0 - h2) * inv;
-                ss = (h + h) * inv;
-                if (pl[k] & 0x8000u) cc = -cc;
-            } else {
-                cc = a_tb[k];
-                ss = b_tb[k];
+    // (four positions' loads in flight at a time; the terms are added in the order of the positions)
+    constexpr int U = 4;
+    for (int64_t kk = k0 + t; kk < k1; kk += (int64_t)U * kHotT) {
+        double v[U], a[U], b2[U];
+        uint16_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = kk + (int64_t)u * kHotT;
+            const int64_t kc = k < k1 ? k : k1 - 1;
+            v[u] = v_tb[kc];
+            a[u] = POL > 1 ? a_tb[kc] : 0.0;
+            b2[u] = (POL > 1 && !HALF) ? b_tb[kc] : 0.0;
+            w[u] = (POL > 1 && HALF) ? pl[kc] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kk + (int64_t)u * kHotT >= k1) break;
+            sv += v[u];
+            if (POL > 1) {
+                double cc, ss;
+                if (HALF) {
+                    const double h = a[u], h2 = h * h, inv = 1.0 / (1.0 + h2);
+                    cc = (1.0 - h2) * inv;
+                    ss = (h + h) * inv;
+                    if (w[u] & 0x8000u) cc = -cc;
+                } else {
+                    cc = a[u];
+                    ss = b2[u];
+                }
+                s1 += v[u] * cc;
+                s2 += v[u] * ss;
             }
-            s1 += v * cc;
-            s2 += v * ss;
         }
     }
     red[0][t] = sv;
@@ -402,19 +418,31 @@ __global__ __launch_bounds__(kHotT) void k_Pt_hot(const int64_t *__restrict__ ra
     }
 }
 
+// One workgroup per hot tile: the range sums are staged in LDS 256 ranges at a time (coalesced loads: one
+// thread walking them in HBM paid a memory round trip every few terms -- 305 ranges for 5e6 samples), and
+// thread 0 adds them in time order.
 template <int POL>
-__global__ void k_hot_combine(const int64_t *__restrict__ tiles, int64_t h0, int64_t nh,
-                              const double *__restrict__ partial, double *__restrict__ out)
+__global__ __launch_bounds__(256) void k_hot_combine(const int64_t *__restrict__ tiles, int64_t h0,
+                                                      const double *__restrict__ partial,
+                                                      double *__restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nh) return;
-    const int64_t p0 = tiles[3 * (h0 + i)], c0 = tiles[3 * (h0 + i) + 1], nc = tiles[3 * (h0 + i) + 2];
+    __shared__ double st[3 * 256];
+    const int64_t h = h0 + blockIdx.x;
+    const int64_t p0 = tiles[3 * h], c0 = tiles[3 * h + 1], nc = tiles[3 * h + 2];
     double sv = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int64_t c = c0; c < c0 + nc; ++c) {               // range sums in time order
-        sv += partial[3 * c];
-        s1 += partial[3 * c + 1];
-        s2 += partial[3 * c + 2];
+    for (int64_t base = 0; base < nc; base += 256) {
+        const int64_t n = nc - base < 256 ? nc - base : 256;
+        for (int64_t i = threadIdx.x; i < 3 * n; i += 256) st[i] = partial[3 * (c0 + base) + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int64_t c = 0; c < n; ++c) {               // range sums in time order
+                sv += st[3 * c];
+                s1 += st[3 * c + 1];
+                s2 += st[3 * c + 2];
+            }
+        __syncthreads();
     }
+    if (threadIdx.x != 0) return;
     if (POL == 1) {
         out[p0] = sv;
     } else if (POL == 2) {
@@ -880,8 +908,7 @@ int hot_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_
     k_Pt_hot<POL, HALF><<<(unsigned)(c1 - c0), kHotT, 0, stream>>>(
         t->d_hot_range, c0, t->d_pl, HALF ? t->d_half : t->d_cos, t->d_sin, d_tod_tb, t->d_hot_partial);
     CM2_LAUNCH_OK();
-    k_hot_combine<POL><<<(unsigned)((h1 - h0 + 63) / 64), 64, 0, stream>>>(t->d_hot_tiles, h0, h1 - h0,
-                                                                           t->d_hot_partial, d_out);
+    k_hot_combine<POL><<<(unsigned)(h1 - h0), 256, 0, stream>>>(t->d_hot_tiles, h0, t->d_hot_partial, d_out);
     CM2_LAUNCH_OK();
     return 0;
 }
@@ -1388,7 +1415,7 @@ int fx_parts_info(const cm2_tiles *t, int64_t *h_info)
 {
     h_info[0] = t->d_parts ? t->nparts : t->ntiles;
     h_info[1] = (int64_t)t->multi_tile.size();
-    h_info[2] = (int64_t)sizeof(double) * t->part_slots * t->tp * t->pol;
+    h_info[2] = (int64_t)sizeof(double) * (t->part_slots * t->tp * t->pol + (t->hot_chunk0.empty() ? 0 : 3 * t->hot_chunk0.back()));
     h_info[3] = (int64_t)(1000.0 * t->part_makespan + 0.5);
     return 0;
 }

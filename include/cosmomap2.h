@@ -21,7 +21,10 @@
  *   - one context per process per GPU.  Objects may be shared by host threads for APPLICATION
  *     calls once their lazily built parts exist (cm2_tiles_prepare_pt, cm2_noise_prepare_tiles,
  *     cm2_pointing_build_sell); construction and destruction are not thread-safe (the reference is
- *     single-threaded).
+ *     single-threaded).  Exception: a tile plan whose P^T uses scratch of the plan (tiles
+ *     split over workgroups on an uneven hit map, hot one-pixel tiles: cm2_tiles_pt_parts reports
+ *     both as "tiles split" / copy bytes > 0) must not run two P^T applications at the same time on
+ *     different streams; applications on one stream, or of different plans, are fine.
  */
 #ifndef COSMOMAP2_H
 #define COSMOMAP2_H
@@ -159,7 +162,8 @@ int cm2_tiles_set_pt_order(cm2_tiles *t, int fixed);
  * that was not prepared builds the lists on its first P^T under a lock.  No-op for the atomic form. */
 int cm2_tiles_prepare_pt(cm2_tiles *t, void *stream);
 /* Work items of the fixed-order P^T after cm2_tiles_prepare_pt: h_info[0..3] = workgroups per
- * application (= tiles when no tile is split), tiles that are split, bytes of the tile copies, and
+ * application (= tiles when no tile is split), tiles that are split, bytes of the plan's P^T scratch
+ * (tile copies of the split tiles, range sums of hot one-pixel tiles), and
  * 1000 x (simulated finish time of the items on two resident workgroups per CU / ideal). */
 int cm2_tiles_pt_parts(const cm2_tiles *t, int64_t *h_info);
 /* h_p0p1[0..1] = pixel range [p0, p1) covered by the tiles [tile_lo, tile_hi).  Tiles are uniform

@@ -24,10 +24,14 @@ ang = type("A", (), {})()
 ang.cos, ang.sin = torch.cos(2 * phi), torch.sin(2 * phi)
 del phi
 v = torch.rand(nt, generator=g, device=dev, dtype=torch.float64)
+if os.environ.get("PROBE_HOT"):                         # 5 % of the samples on one pixel
+    pix[torch.rand(nt, generator=g, device=dev) < 0.05] = npix // 3
 ref = None
 plans = (("whole tiles", {}), ("2 parts", {"CM2_TILE_BALANCE": "parts", "CM2_PT_PARTS": "100000"}),
          ("4 parts", {"CM2_TILE_BALANCE": "parts", "CM2_PT_PARTS": "49000"}), ("whole tiles again", {}))
-if os.environ.get("PROBE_UNEVEN"):
+if os.environ.get("PROBE_HOT"):
+    plans = (("default", {}), ("cut", {"CM2_TILE_BALANCE": "cut"}), ("default again", {}))
+elif os.environ.get("PROBE_UNEVEN"):
     plans = (("default", {}), ("cut", {"CM2_TILE_BALANCE": "cut"}), ("parts 200000", {"CM2_PT_PARTS": "200000"}),
              ("parts 120000", {"CM2_PT_PARTS": "120000"}), ("parts 54000", {"CM2_PT_PARTS": "54000"}),
              ("one workgroup per tile", {"CM2_TILE_BALANCE": "0"}), ("default again", {}))
