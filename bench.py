@@ -799,7 +799,10 @@ def main():
     # cache-hostile worst case; a telescope sweeps: every detector block rasters W = 1024 columns
     # back and forth, 4 samples per pixel, one row per sweep, starting at its own row.
     raster = None
-    if rank == 0 and world == 1 and lam and not args.no_raster and npix % 1024 == 0:
+    # (the secondary pointing models build a second and a third pointing plan beside the first: at more than
+    #  2.5e8 samples on one GPU -- C5 whole -- they are skipped, 1e9 samples x 3 plans do not fit 288 GB)
+    secondary = rank == 0 and world == 1 and lam and not args.no_raster and nt <= 250_000_000
+    if secondary and npix % 1024 == 0:
         Wc, dwell = 1024, 4
         Hr = npix // Wc
         tt = torch.arange(nt, device=dev, dtype=torch.int64)
@@ -827,70 +830,79 @@ def main():
 
     # ---- uneven hit map: half of the samples on a tenth of the map (tiles re-cut to equal load) --
     uneven = None
-    if rank == 0 and world == 1 and lam and not args.no_raster:
-        gen_u = torch.Generator(device=dev).manual_seed(20161203)
-        pix_u = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
-        hot = torch.rand(nt, generator=gen_u, device=dev) < 0.5
-        pix_u[hot] = pix_u[hot] % (npix // 10)
-        del hot
-        phi_u = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
-        ces_u = ProcessTimeSamples(pix_u, npix, pol=pol, phi=phi_u)
-        del phi_u
-        n_u = ces_u.get_new_pixel[0]
-        P_u = SparseLO(n_u, nt, pix_u, pol=pol, angle_processed=ces_u)
-        A_u = P_u.T * N * P_u
-        x_u = torch.rand(pol * n_u, generator=torch.Generator(device=dev).manual_seed(9), device=dev,
-                         dtype=torch.float64)
-        # the uniform step measured the same way in the same minute (an event pair around every single
-        # matvec; the headline ms_per_step is K matvecs back to back between two wall-clock reads and is
-        # 2-4 % shorter than this figure): the ratio of the two is the cost of the hit map
-        _, med_ref = ev_time(lambda: A_local * x, reps)
-        _, med_u = ev_time(lambda: A_u * x_u, reps)
-        T_u = L._sparse_tiles(P_u)
-        tb_u, tb2_u, out_u = D.empty(T_u.nvalid), D.empty(T_u.nvalid), D.empty(pol * n_u)
-        st_u = {}
-        if args.toeplitz == "fused":
-            su = seq_time([lambda: _hip.call("cm2_P_tiles_apply", T_u.h, D.ptr(x_u), D.ptr(tb_u), D.stream()),
-                           lambda: _hip.call("cm2_noise_apply_tiles", N._noise.h, T_u.h, D.ptr(tb_u),
-                                             D.ptr(tb2_u), D.stream()),
-                           lambda: _hip.call("cm2_Pt_tiles_apply", T_u.h, D.ptr(tb2_u), D.ptr(out_u), D.stream())], 5)
-            st_u = {"P": su[0][0], "N^-1": su[1][0], "P^T": su[2][0]}
-        del tb_u, tb2_u, out_u
-        uneven = {"pointing": "50 % of the samples on the first tenth of the map, the rest uniform",
-                  "tiles": int(T_u.ntiles), "widest_tile_pixels": int(T_u.tile_pixels), "pt_parts": T_u.pt_parts(),
-                  "ms_per_step": round(med_u, 4), "value": round(nt / (med_u * 1e-3), 1),
-                  "unit": "TOD samples/s", "uniform_ms_same_method": round(med_ref, 4),
-                  "over_uniform": round(med_u / med_ref - 1.0, 4),
-                  "stages_ms_in_sequence": {k: round(v, 4) for k, v in st_u.items()}}
-        del A_u, P_u, ces_u, pix_u, x_u, T_u
-        # a stare at a source: 5 % of the samples on ONE pixel.  The default fixed-order P^T sums
-        # such a run in fixed chunks (reproducible); "exact" walks it term by term with one thread.
-        pix_h = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
-        pix_h[torch.rand(nt, generator=gen_u, device=dev) < 0.05] = npix // 3
-        phi_h = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
-        ces_h = ProcessTimeSamples(pix_h, npix, pol=pol, phi=phi_h)
-        del phi_h
-        n_h = ces_h.get_new_pixel[0]
-        P_h = SparseLO(n_h, nt, pix_h, pol=pol, angle_processed=ces_h)
-        A_h = P_h.T * N * P_h
-        x_h = torch.rand(pol * n_h, generator=torch.Generator(device=dev).manual_seed(10), device=dev,
-                         dtype=torch.float64)
-        _, med_h = ev_time(lambda: A_h * x_h, reps)
-        T_h = L._sparse_tiles(P_h)
-        tb_h, out_h = D.empty(T_h.nvalid), D.empty(pol * n_h)
-        _hip.call("cm2_P_tiles_apply", T_h.h, D.ptr(x_h), D.ptr(tb_h), D.stream())
-        pt_ms = {}
-        for mode, name in ((1, "fixed_chunks"), (2, "exact_time_order")):
-            T_h.set_pt_order(mode)
-            _, pt_ms[name] = ev_time(lambda: _hip.call("cm2_Pt_tiles_apply", T_h.h, D.ptr(tb_h),
-                                                       D.ptr(out_h), D.stream()), 3)
-        T_h.set_pt_order(1)
-        uneven["hot_pixel"] = {"pointing": "5 % of the samples on one pixel, the rest uniform",
-                               "ms_per_step": round(med_h, 4), "over_uniform": round(med_h / med_ref - 1.0, 4),
-                               "tiles": int(T_h.ntiles),
-                               "pt_parts": T_h.pt_parts(),
-                               "PT_ms": {k: round(v, 4) for k, v in pt_ms.items()}}
-        del A_h, P_h, ces_h, pix_h, x_h, T_h, tb_h, out_h
+    if secondary:
+        try:
+            gen_u = torch.Generator(device=dev).manual_seed(20161203)
+            pix_u = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
+            hot = torch.rand(nt, generator=gen_u, device=dev) < 0.5
+            pix_u[hot] = pix_u[hot] % (npix // 10)
+            del hot
+            phi_u = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+            ces_u = ProcessTimeSamples(pix_u, npix, pol=pol, phi=phi_u)
+            del phi_u
+            n_u = ces_u.get_new_pixel[0]
+            P_u = SparseLO(n_u, nt, pix_u, pol=pol, angle_processed=ces_u)
+            A_u = P_u.T * N * P_u
+            x_u = torch.rand(pol * n_u, generator=torch.Generator(device=dev).manual_seed(9), device=dev,
+                             dtype=torch.float64)
+            # the uniform step measured the same way in the same minute (an event pair around every single
+            # matvec; the headline ms_per_step is K matvecs back to back between two wall-clock reads and is
+            # 2-4 % shorter than this figure): the ratio of the two is the cost of the hit map
+            _, med_ref = ev_time(lambda: A_local * x, reps)
+            _, med_u = ev_time(lambda: A_u * x_u, reps)
+            T_u = L._sparse_tiles(P_u)
+            tb_u, tb2_u, out_u = D.empty(T_u.nvalid), D.empty(T_u.nvalid), D.empty(pol * n_u)
+            st_u = {}
+            if args.toeplitz == "fused":
+                su = seq_time([lambda: _hip.call("cm2_P_tiles_apply", T_u.h, D.ptr(x_u), D.ptr(tb_u), D.stream()),
+                               lambda: _hip.call("cm2_noise_apply_tiles", N._noise.h, T_u.h, D.ptr(tb_u),
+                                                 D.ptr(tb2_u), D.stream()),
+                               lambda: _hip.call("cm2_Pt_tiles_apply", T_u.h, D.ptr(tb2_u), D.ptr(out_u), D.stream())], 5)
+                st_u = {"P": su[0][0], "N^-1": su[1][0], "P^T": su[2][0]}
+            del tb_u, tb2_u, out_u
+            uneven = {"pointing": "50 % of the samples on the first tenth of the map, the rest uniform",
+                      "tiles": int(T_u.ntiles), "widest_tile_pixels": int(T_u.tile_pixels), "pt_parts": T_u.pt_parts(),
+                      "ms_per_step": round(med_u, 4), "value": round(nt / (med_u * 1e-3), 1),
+                      "unit": "TOD samples/s", "uniform_ms_same_method": round(med_ref, 4),
+                      "over_uniform": round(med_u / med_ref - 1.0, 4),
+                      "stages_ms_in_sequence": {k: round(v, 4) for k, v in st_u.items()}}
+            del A_u, P_u, ces_u, pix_u, x_u, T_u
+            # a stare at a source: 5 % of the samples on ONE pixel.  The default fixed-order P^T sums
+            # such a run in fixed chunks (reproducible); "exact" walks it term by term with one thread.
+            pix_h = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
+            pix_h[torch.rand(nt, generator=gen_u, device=dev) < 0.05] = npix // 3
+            phi_h = theta0 + (2 * np.pi * 2.5 / 200.0) * torch.arange(nt, device=dev, dtype=torch.float64)
+            ces_h = ProcessTimeSamples(pix_h, npix, pol=pol, phi=phi_h)
+            del phi_h
+            n_h = ces_h.get_new_pixel[0]
+            P_h = SparseLO(n_h, nt, pix_h, pol=pol, angle_processed=ces_h)
+            A_h = P_h.T * N * P_h
+            x_h = torch.rand(pol * n_h, generator=torch.Generator(device=dev).manual_seed(10), device=dev,
+                             dtype=torch.float64)
+            _, med_h = ev_time(lambda: A_h * x_h, reps)
+            T_h = L._sparse_tiles(P_h)
+            tb_h, out_h = D.empty(T_h.nvalid), D.empty(pol * n_h)
+            _hip.call("cm2_P_tiles_apply", T_h.h, D.ptr(x_h), D.ptr(tb_h), D.stream())
+            pt_ms = {}
+            for mode, name in ((1, "fixed_chunks"), (2, "exact_time_order")):
+                T_h.set_pt_order(mode)
+                _, pt_ms[name] = ev_time(lambda: _hip.call("cm2_Pt_tiles_apply", T_h.h, D.ptr(tb_h),
+                                                           D.ptr(out_h), D.stream()), 3)
+            T_h.set_pt_order(1)
+            uneven["hot_pixel"] = {"pointing": "5 % of the samples on one pixel, the rest uniform",
+                                   "ms_per_step": round(med_h, 4), "over_uniform": round(med_h / med_ref - 1.0, 4),
+                                   "tiles": int(T_h.ntiles),
+                                   "pt_parts": T_h.pt_parts(),
+                                   "PT_ms": {k: round(v, 4) for k, v in pt_ms.items()}}
+            del A_h, P_h, ces_h, pix_h, x_h, T_h, tb_h, out_h
+        except (_hip.HipError, torch.cuda.OutOfMemoryError) as exc:      # auxiliary: reported, not fatal
+            # (at 1e9 samples on one GPU a second and third pointing plan do not always fit beside the first)
+            uneven = dict(uneven or {}, error="%s: %s" % (type(exc).__name__, str(exc)[:200]))
+            del exc
+            pix_u = phi_u = ces_u = P_u = A_u = x_u = T_u = tb_u = tb2_u = out_u = None     # (whatever existed)
+            pix_h = phi_h = ces_h = P_h = A_h = x_h = T_h = tb_h = out_h = None
+            torch.cuda.empty_cache()
+            D.release_cached_memory()
 
     fft_len = N.noise_info()["fft_len"] if lam else 0
 

@@ -137,6 +137,27 @@ def check(rc):
         raise HipError(msg.decode() if msg else "libcosmomap2_hip call failed (rc=%d)" % rc)
 
 
+def _free_torch_cache():
+    """torch's caching allocator and the library's block cache share the device and do not see each
+    other's idle memory (device._alloc handles the other direction)."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return False
+        torch.cuda.empty_cache()
+        return True
+    except Exception:          # pragma: no cover
+        return False
+
+
 def call(name, *args):
-    """Call an int-status entry point and raise HipError with cm2_last_error()."""
-    check(getattr(load(), name)(*args))
+    """Call an int-status entry point and raise HipError with cm2_last_error().  A call that ran out of
+    device memory is tried once more after torch has returned its idle blocks to the driver (the
+    library has released its own cached blocks before reporting the failure)."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        msg = load().cm2_last_error() or b""
+        if b"out of memory" in msg and _free_torch_cache():
+            rc = fn(*args)
+    check(rc)
