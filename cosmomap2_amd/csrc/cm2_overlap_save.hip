@@ -639,16 +639,19 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
         }
         __builtin_amdgcn_sched_barrier(0);
-        double vv[PT];
-#pragma unroll
-        for (int u = 0; u < PT; ++u) vv[u] = gather(ka[u]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PT; ++u) buf[q_word(qa, u) & 0x7FFFu] = keep(ka[u], vv[u]);
+        // Both halves' gathers are in flight together (2 PT loads per thread: the transform's registers
+        // are not live yet), half a is staged while half b is still on its way: two dependent round
+        // trips (lists, gathers) instead of three.  Five same-box alternations of bench.py: step 1.478
+        // against 1.507 ms (-1.9 %, every pair); one noisy pair had hidden it earlier in the round.
+        double va[PT], vv[PT];
         if constexpr (MODE == 2) rc_decode<PT>(qb, tab_lds + rmax, wbb, nvb, t, kb);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) va[u] = gather(ka[u]);
 #pragma unroll
         for (int u = 0; u < PT; ++u) vv[u] = gather(kb[u]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[q_word(qa, u) & 0x7FFFu] = keep(ka[u], va[u]);
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
