@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     uint32_t qs[ER / 2], ks[ER];
     uint32_t nvs = 0;
     int wbs = -1;
-    auto request_results = [&](int j, auto &qq, auto &kq, uint32_t &nv, int &wb) {
+    auto request_results = [&](int j, auto &qq, auto &kq, uint32_t &nv, int &wb, uint32_t *tdst) {
         if constexpr (MODE != 0) {
             // (the list number passes through an empty asm statement: an offset, not a pointer, see
             // ab_request; the list's addresses stay wave-uniform and its header words scalar loads)
@@ -794,13 +794,22 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             if constexpr (MODE == 2) {
                 nv = ls.hdr->nvalid;
                 wb = ls.hdr->wbase[wave];
-                tab_dma(ls.tab, tab_lds, rmax, wave, t);
+                tab_dma(ls.tab, tdst, rmax, wave, t);
             }
             q_request<ER>(ls.q, t, qq);
             (void)kq;         // (plain lists: the addresses are fetched behind the last pass, see below)
         }
     };
-    request_results(0, qs, ks, nvs, wbs);          // (its run table: published by the barriers of the next exchange)
+    // EARLY: the second result round's lists are requested behind the first round's staging barrier, so
+    // that they travel while the first round's results are stored (the barrier in front of the second
+    // round waits for the stores and the lists together: one round trip less per window).  Five
+    // same-box alternations of bench.py: step 1.407 against 1.446 ms (-2.7 %).  Not for plain lists
+    // with flat addressing (the 12 list words more spill 22 VGPRs there).
+    constexpr bool EARLY = MODE == 2 || (MODE == 1 && BUF);
+    uint32_t qs1[ER / 2];
+    uint32_t nv1 = 0;
+    int wb1 = -1;
+    request_results(0, qs, ks, nvs, wbs, tab_lds); // (its run table: published by the barriers of the next exchange)
     __builtin_amdgcn_sched_barrier(0);
     reg_inv<PT, 16, 0>(zr, zi, w_bi);
     if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
@@ -811,11 +820,18 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     OS_STAMP(4);
 #pragma unroll
     for (int j = 0; j < G::RR; ++j) {
-        const uint32_t *tabj = tab_lds;
+        const uint32_t *tabj = tab_lds + (EARLY && j > 0 ? rmax : 0);
         if (j > 0) {
-            __syncthreads();                         // the previous round's reads are done
-            request_results(j, qs, ks, nvs, wbs);
-            if constexpr (MODE == 2) __syncthreads();
+            __syncthreads();                         // the previous round's reads are done (EARLY: and round j's table is in)
+            if constexpr (EARLY) {
+#pragma unroll
+                for (int i = 0; i < ER / 2; ++i) qs[i] = qs1[i];
+                nvs = nv1;
+                wbs = wb1;
+            } else {
+                request_results(j, qs, ks, nvs, wbs, tab_lds);
+                if constexpr (MODE == 2) __syncthreads();
+            }
         }
         if constexpr (MODE == 2) rc_decode<ER>(qs, tabj, wbs, nvs, t, ks);
         double2 *__restrict__ sp = reinterpret_cast<double2 *>(buf) + t;
@@ -832,6 +848,8 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             for (int u = 0; u < ER; ++u) ks[u] = ld_list(ls.k + slot_of<ER>(t, u));
         }
         __syncthreads();
+        if constexpr (EARLY)
+            if (j + 1 < G::RR) request_results(j + 1, qs1, ks, nv1, wb1, tab_lds + rmax);
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int u = 0; u < ER; ++u) {
