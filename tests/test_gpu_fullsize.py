@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _full_size_vs_oracle(oracle, key, whole=False, host_solve=True):
+def _full_size_vs_oracle(oracle, key, whole=False, host_solve=True, hit_map=None):
     """whole: the configuration's TOTAL on this one GPU (C5: 1e9 samples in 64 blocks) instead of one
     GPU's share.  host_solve False: the oracle runs ProcessTimeSamples and ONE matvec (40 s of host
     time at 1e9 samples; a host PCG would take minutes) and the iteration count is tied to the
@@ -51,6 +51,19 @@ def _full_size_vs_oracle(oracle, key, whole=False, host_solve=True):
     bsize = nt // nb
     dev = torch.device("cuda", 0)
     inp = bench.synth_inputs(torch, dev, npix, nt, nb, lam, rank=0)
+    if hit_map is not None:
+        # the secondary hit maps of bench.py (`uneven_hit_map`): half of the samples on the first tenth of
+        # the map / 5 % of them on one pixel -- the plans that split heavy tiles over several workgroups
+        # and reduce a one-pixel tile by ranges (cm2_tiles_fixed.hip "parts", k_Pt_hot)
+        gen_u = torch.Generator(device=dev).manual_seed(20161203)
+        pix_u = torch.randint(0, npix, (nt,), generator=gen_u, device=dev, dtype=torch.int32)
+        if hit_map == "uneven":
+            dense = torch.rand(nt, generator=gen_u, device=dev) < 0.5
+            pix_u[dense] = pix_u[dense] % (npix // 10)
+            del dense
+        else:
+            pix_u[torch.rand(nt, generator=gen_u, device=dev) < 0.05] = npix // 3
+        inp["pix"] = pix_u
     pix, phi, d = inp["pix"], inp.pop("phi"), inp["d"]
     # host copies of the INPUTS, taken before ProcessTimeSamples flags the pixel stream in place
     pix_h, phi_h, d_h = pix.cpu().numpy(), phi.cpu().numpy(), d.cpu().numpy()
@@ -72,6 +85,10 @@ def _full_size_vs_oracle(oracle, key, whole=False, host_solve=True):
     if lam:
         T = L._sparse_tiles(P)
         assert T.pt_fixed and T.half_angle
+        if hit_map is not None:
+            parts = T.pt_parts()
+            assert parts["tiles_split"] >= 50 and parts["workgroups"] > T.ntiles + 300, parts
+            assert T.ntiles == (npix // T.tile_pixels) + (2 if hit_map == "hot_pixel" else 0), T.ntiles
     # ---- the oracle on the same inputs ----
     H = oracle.HostProblem(pol, npix, pix_h, phi_h, bsize, bands=inp["bands"], diag=inp["diag"])
     ro = H.ro
@@ -155,3 +172,13 @@ def test_c5_whole_on_one_gpu_equals_oracle(oracle):
     kernel, 32-bit sample addresses close to their range, 2.3e9 list entries.  ProcessTimeSamples and
     one matvec against the oracle on the host; the PCG count against the exact-order HIP path."""
     _full_size_vs_oracle(oracle, "c5", whole=True, host_solve=False)
+
+
+@pytest.mark.parametrize("hit_map", ["uneven", "hot_pixel"])
+def test_c4_uneven_hit_maps_equal_oracle_at_full_size(oracle, hit_map):
+    """C4 (nside 256 IQU, 1e8 samples, Toeplitz lambda 2048) on the two secondary hit maps of the bench line:
+    the plans whose fixed-order P^T shares heavy tiles out to several workgroups (and, for the hot pixel,
+    reduces a one-pixel tile of 5e6 samples by ranges) against the oracle's serial / all-cores run of the
+    same inputs -- one matvec 1e-12, identical PCG iteration count, map 1e-6."""
+    _full_size_vs_oracle(oracle, "c4", hit_map=hit_map)
+
