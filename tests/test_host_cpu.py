@@ -325,3 +325,45 @@ def test_host_problem_equals_the_serial_oracle(oracle):
     xh, info_h, its_h = H.solve(bh, rtol=1e-6)
     assert info == 0 and info_h == 0 and its_h == len(its)
     assert np.linalg.norm(xh - xs) / np.linalg.norm(xs) < 1e-9
+
+
+def test_library_call_is_retried_once_after_an_out_of_memory_failure(monkeypatch):
+    """_hip.call: a call that ran out of device memory is tried once more after torch's cached blocks went
+    back to the driver (the library has released its own before reporting); any other failure, and a
+    second out-of-memory failure, raise HipError with the library's message."""
+    from cosmomap2_amd import _hip
+
+    class Fake(object):
+        def __init__(self, results, message):
+            self.results, self.message, self.calls = list(results), message, 0
+
+        def cm2_last_error(self):
+            return self.message
+
+        def cm2_something(self, *args):
+            self.calls += 1
+            return self.results.pop(0)
+
+    freed = []
+    monkeypatch.setattr(_hip, "_free_torch_cache", lambda: freed.append(1) or True)
+    fake = Fake([1, 0], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    _hip.call("cm2_something", 1, 2)
+    assert fake.calls == 2 and freed == [1]
+    fake = Fake([1, 1], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError, match="out of memory"):
+        _hip.call("cm2_something")
+    assert fake.calls == 2
+    fake = Fake([1, 0], b"cm2_tiles_create: bad pol=7")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError, match="bad pol"):
+        _hip.call("cm2_something")
+    assert fake.calls == 1
+    # without a GPU there is nothing to free: no second attempt
+    monkeypatch.setattr(_hip, "_free_torch_cache", lambda: False)
+    fake = Fake([1, 0], b"x failed: out of memory")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError):
+        _hip.call("cm2_something")
+    assert fake.calls == 1
