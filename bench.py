@@ -97,6 +97,26 @@ def synth_inputs(torch, dev, npix, nt, nb, lam, rank=0):
     return dict(gen=gen, rng=rng, theta0=theta0, pix=pix, phi=phi, d=d, bands=bands, diag=diag)
 
 
+def hbm_budget_gb(nt_rank, n, r, arnoldi_steps, world, layout):
+    """Device memory one rank needs, from the per-sample table of DESIGN.md section 2 (measured at C5 whole:
+    profiles/r04_bench_c5_whole.json `hbm_memory`) and the map-domain vectors of either layout.  Printed for
+    the strong-scaling series so that the first multi-GPU run of a configuration cannot fail on memory."""
+    per_sample = {"inputs pix i32 + d f64": 12.0, "cos 2phi, sin 2phi": 16.0,
+                  "tile plan (pl u16, half angle f64, tb_dst u32)": 14.0,
+                  "fixed-order P^T lists": 12.2, "overlap-save lists": 5.1,
+                  "TOD scratch of the operator (two tile-order buffers)": 16.0,
+                  "transient: phi f64 + ProcessTimeSamples' pixel-sorted index": 28.0}
+    rows = n / world if layout == "rows" else n
+    vec = {"PCG vectors (x, r, p, z, q, b) + exchange buffers": 8.0 * (6 * rows + 2 * n),
+           "Arnoldi basis, 2 x (steps + 1) vectors": 8.0 * 2 * (arnoldi_steps + 1) * rows,
+           "Z, AZ": 8.0 * 2 * r * rows,
+           "per-pixel weights + M_BD blocks (13 arrays of npix)": 8.0 * 13 * n / 3}
+    samples = sum(per_sample.values()) * nt_rank
+    total = samples + sum(vec.values())
+    return {"samples_GB": round(samples / 1e9, 1), "map_domain_GB": round(sum(vec.values()) / 1e9, 1),
+            "total_GB": round(total / 1e9, 1), "fits_288_GB": bool(total < 0.9 * 288e9)}
+
+
 def git_head():
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
@@ -173,6 +193,13 @@ def main():
     ap.add_argument("--no-pcg", action="store_true", help="skip the PCG iteration count")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the full-size comparison of the timed path with the CPU oracle")
+    ap.add_argument("--parity-host-seconds", type=float, default=150.0,
+                    help="host time the oracle's PCG solves of the parity_full_size block may take (estimated "
+                         "from its first matvec); C5 whole needs about 400")
+    ap.add_argument("--parity-arnoldi", action="store_true",
+                    help="parity_full_size also runs the oracle's own Arnoldi (reference recurrence, "
+                         "interfaces/deflationlib.py:17-113) for --arnoldi-steps steps on the host and reports the "
+                         "principal angles between its Ritz space and the GPU's (minutes of host time)")
     ap.add_argument("--no-raster", action="store_true",
                     help="skip the secondary run with a coherent raster-scan pointing")
     ap.add_argument("--no-filters", action="store_true",
@@ -246,6 +273,12 @@ def main():
     def sync():
         torch.cuda.synchronize()
 
+    def strong_budget():
+        return {"bytes_per_sample_table": "DESIGN.md section 2",
+                **{"N=%d" % k: {lay: hbm_budget_gb(-(-cfg["total"] // k), pol * npix, args.deflation,
+                                                   args.arnoldi_steps, k, lay) for lay in ("replicated", "rows")}
+                   for k in (1, 2, 4, 8)}}
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -304,8 +337,11 @@ def main():
         # the distributed operator in both layouts of the map-domain vectors (same seed on every rank:
         # x is the same whole vector everywhere; x_rows = this rank's rows of it)
         sh = RowShards(npix_c, pol) if world > 1 else None
-        A_repl = ShardedLO(A_local) if world > 1 else A_local
-        A_rows = RowShardedNormalLO(A_local, sh) if world > 1 else A_local
+        # (persistent_output: results and exchange vectors live in buffers the operators keep -- no
+        #  allocation, zero-fill or copy per matvec, the same addresses for RCCL every time; the timed
+        #  loop, the PCG and the Arnoldi build consume A p before the next application)
+        A_repl = ShardedLO(A_local, persistent_output=True) if world > 1 else A_local
+        A_rows = RowShardedNormalLO(A_local, sh, persistent_output=True) if world > 1 else A_local
         x_rows = sh.local(x) if world > 1 else x
         A = A_rows if args.layout == "rows" else A_repl
         if lam and L._use_tiles(P):
@@ -397,6 +433,9 @@ def main():
                               # the collective choice the operator made (max over ranks of the shard sizes)
                               "allreduce_chunks": A.allreduce_chunks(nt),
                               "map_allreduces_per_matvec": A.collectives_issued // (args.steps + args.warmup)})
+        # per-rank device memory of THIS configuration's strong-scaling series (total cut over N ranks), both
+        # layouts: computed, not measured -- printed so that a first hardware run cannot fail on memory
+        dist_info["hbm_budget_per_rank_strong_scaling"] = strong_budget()
         # the same K steps in the OTHER layout of the map-domain vectors
         # (auxiliary: a failure here is reported in the line, it does not take the headline down.  Every
         # rank takes the same branch: an exception on one rank only would leave the others in a collective,
@@ -1017,20 +1056,93 @@ def main():
             # cpu_baseline_all_cores leg keeps fewer threads busy: fewer noise blocks than threads)
             parity["host_all_cores_samples_per_s"] = round(nt / t_mv, 1)
             del y, yo
-            if not args.no_pcg and pcg is not None and t_mv * (pcg["iters"] + 3) < 120.0:
+            budget = args.parity_host_seconds
+            if not args.no_pcg and pcg is not None and t_mv * (pcg["iters"] + 3) < budget:
                 bo = H.rhs(d_h)
                 b = P.T * (N * d)
                 parity["rhs_rel_l2"] = float(np.linalg.norm(b.cpu().numpy() - bo) / np.linalg.norm(bo))
+                t1 = time.perf_counter()
                 xo, info_o, its_o = H.solve(bo, rtol=1e-6, maxiter=500)
+                parity["host_pcg_seconds"] = round(time.perf_counter() - t1, 1)
+                budget -= time.perf_counter() - t1
                 itsg = []
                 xg, info_g = cosmomap2_amd.cg(A, b, M=Mbd, rtol=1e-6, maxiter=500, callback=lambda xk: itsg.append(1))
                 parity["pcg_iters_gpu"] = len(itsg)
                 parity["pcg_iters_oracle"] = int(its_o)
                 parity["pcg_iters_identical"] = bool(len(itsg) == its_o and info_g == 0 and info_o == 0)
                 parity["map_rel_l2"] = float(np.linalg.norm(xg.cpu().numpy() - xo) / np.linalg.norm(xo))
-                del b, xg, xo, bo
+                del xg
+                two_g = (pcg or {}).get("two_level")
+                if lam and args.deflation > 0 and two_g:
+                    # the configuration AS BASELINE STATES IT (C4, C5: two-level preconditioner, deflation
+                    # space of dimension 32): Z from the GPU's Arnoldi, everything after it by the oracle --
+                    # Az[:, i] = A Z[:, i], E = Z^T Az with the 'eig' pseudo-inverse, M2 = Mbd R + Zd E Zd^T
+                    # (src/test_M2_precond_onto_real_data.py:96-112, interfaces/linearoperators.py:969-1056)
+                    # and scipy's recurrence with M2
+                    r = args.deflation
+                    need = t_mv * (r + two_g["iters"] + 3)
+                    if need < budget:
+                        from cosmomap2_amd.interfaces import (DeflationLO, CoarseLO, TwoLevelPreconditionerLO,
+                                                              ritz_deflation_basis, apply_to_columns)
+                        t1 = time.perf_counter()
+                        Z, theta, AZ = ritz_deflation_basis(A, Mbd, b, r, args.arnoldi_steps, with_AZ=True)
+                        E = CoarseLO(Z, AZ, r, apply='eig')
+                        M2 = TwoLevelPreconditionerLO(Mbd, DeflationLO(Z), DeflationLO(AZ), E)
+                        its2 = []
+                        x2, info2 = cosmomap2_amd.cg(A, b, M=M2, rtol=1e-6, maxiter=500,
+                                                     callback=lambda xk: its2.append(1))
+                        Zh = Z.cpu().numpy()
+                        AZo, Eo, M2o = H.two_level(Zh, apply='eig')
+                        x2o, info2o, its2o = H.solve(bo, rtol=1e-6, maxiter=500, M=M2o)
+
+                        def rl2(a_, b_):
+                            return float(np.linalg.norm(np.asarray(a_) - b_) / np.linalg.norm(b_))
+                        tl = {"rank": r, "arnoldi_steps": args.arnoldi_steps,
+                              "AZ_rel_l2_r_matvecs": rl2(apply_to_columns(A, Z).cpu().numpy(), AZo),
+                              "AZ_rel_l2_arnoldi_relation": rl2(AZ.cpu().numpy(), AZo),
+                              "E_rel_l2": rl2(E.E, Eo.E), "E_pinv_rel_l2": rl2(E.invE, Eo.invE),
+                              "pcg_iters_gpu": len(its2), "pcg_iters_oracle": int(its2o),
+                              "pcg_iters_identical": bool(len(its2) == its2o and info2 == 0 and info2o == 0),
+                              "map_rel_l2": rl2(x2.cpu().numpy(), x2o),
+                              "map_rel_l2_vs_oracle_block_diagonal_solution": rl2(x2o, xo)}
+                        if args.parity_arnoldi:
+                            # the reference's OWN Arnoldi recurrence (modified Gram-Schmidt on Mbd*A, Mbd*b,
+                            # src/test_M2_precond_onto_real_data.py:42, deflationlib.py:17-113) on the host for
+                            # the same number of steps, Ritz pairs of its Hessenberg matrix (build_hess,
+                            # la.eigh as :43-46 does -- the symmetric part), smallest r: the angles between
+                            # that space and the GPU's Z say how far the two Krylov recurrences agree on the
+                            # deflation space (same Krylov space; Euclidean against M^-1-orthogonal Ritz
+                            # projection, so only converged Ritz vectors coincide)
+                            t2 = time.perf_counter()
+                            m_st = args.arnoldi_steps
+                            vs, hs, m_o = orc.arnoldi(lambda v: H.M(H.A(v)), H.M(bo), np.zeros(bo.shape[0]),
+                                                      tol=0.0, inner_m=m_st, exhausted="return")
+                            Hm = orc.build_hess(hs, m_o)
+                            th_o, U_o = np.linalg.eigh(0.5 * (Hm + Hm.T))
+                            V = np.column_stack(vs[:m_o])
+                            Zo = V.dot(U_o[:, np.argsort(th_o)[:r]])
+                            Qg, _ = np.linalg.qr(Zh)
+                            Qo, _ = np.linalg.qr(Zo)
+                            cosines = np.clip(np.linalg.svd(Qg.T.dot(Qo), compute_uv=False), 0.0, 1.0)
+                            ang = np.sort(np.arccos(cosines))
+                            tl["oracle_arnoldi"] = {
+                                "steps": int(m_o), "seconds": round(time.perf_counter() - t2, 1),
+                                "ritz_smallest_oracle": [float(v) for v in np.sort(th_o)[:4]],
+                                "ritz_smallest_gpu": [float(v) for v in np.sort(theta)[:4]],
+                                "principal_angles_rad_min_median_max": [float(ang[0]), float(np.median(ang)),
+                                                                        float(ang[-1])],
+                                "angles_below_1e-6": int(np.sum(ang < 1e-6)),
+                                "angles_below_1e-3": int(np.sum(ang < 1e-3))}
+                            del vs, V, Zo, Qg, Qo
+                        tl["seconds"] = round(time.perf_counter() - t1, 1)
+                        parity["two_level"] = tl
+                        del Z, AZ, E, M2, x2, Zh, AZo, Eo, M2o, x2o
+                    else:
+                        parity["two_level"] = "skipped (host build + solve would take %.0f s)" % need
+                del b, xo, bo
             else:
-                parity["pcg"] = "skipped (host solve would take %.0f s)" % (t_mv * ((pcg or {}).get("iters", 10) + 3))
+                parity["pcg"] = "skipped (host solve would take %.0f s; --parity-host-seconds %g)" % (
+                    t_mv * ((pcg or {}).get("iters", 10) + 3), budget)
         parity["seconds"] = round(time.perf_counter() - tq, 1)
         del H, pix_h, d_h
 
@@ -1039,7 +1151,8 @@ def main():
     mem = (ctypes.c_int64 * 4)()
     _hip.call("cm2_device_memory_info", mem)
     memory = {"library_live_GB": round(mem[0] / 1e9, 3), "library_cached_GB": round(mem[1] / 1e9, 3),
-              "torch_peak_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3)}
+              "torch_peak_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 3),
+              "computed_budget_per_rank_strong_scaling_GB": strong_budget()}
     if rank == 0:
         out = {
             "metric": "TOD samples/s through P^T N^-1 P",

@@ -150,14 +150,35 @@ def _free_torch_cache():
         return False
 
 
+ERR_OUT_OF_MEMORY = 3          # CM2_ERR_OUT_OF_MEMORY of include/cosmomap2.h
+
+# Entry points that may be called again after an out-of-memory failure: they build a new object (a failed
+# build frees what it had made) or overwrite their outputs from their inputs.  NOT in the list: the in-place
+# updates (cm2_axpy, cm2_scal, cm2_Z_axpy, cm2_panel_gemm with accumulate, cm2_pcg_update_*,
+# cm2_flag_samples, cm2_compact_*), which a second run would apply twice, and the drivers with callbacks
+# (cm2_pcg, cm2_pcg_sharded, cm2_arnoldi).
+RESTARTABLE = frozenset([
+    "cm2_pointing_create", "cm2_pointing_build_sell", "cm2_pointing_set_weights",
+    "cm2_P_apply", "cm2_Pt_apply", "cm2_PtNP_diag_apply",
+    "cm2_tiles_create", "cm2_tiles_prepare_pt", "cm2_P_tiles_apply", "cm2_Pt_tiles_apply",
+    "cm2_Pt_tiles_apply_range", "cm2_i32_time_to_tiles", "cm2_tod_time_to_tiles", "cm2_tod_tiles_to_time",
+    "cm2_noise_create_diag", "cm2_noise_create_toeplitz", "cm2_noise_apply", "cm2_noise_apply_tiles",
+    "cm2_noise_prepare_tiles", "cm2_noise_expand_diag", "cm2_PtNP_tiles_apply",
+    "cm2_weights_accumulate", "cm2_pixel_mask", "cm2_pixel_compact",
+    "cm2_bd_det_mask", "cm2_bdprecond_apply", "cm2_bd_apply",
+    "cm2_dot", "cm2_xmy", "cm2_Zt_apply", "cm2_Z_apply", "cm2_gemm_tn", "cm2_small_matvec", "cm2_gemm_atbt",
+    "cm2_transpose", "cm2_cos_sin_2phi", "cm2_m2_finish",
+    "cm2_filter_create", "cm2_filter_apply", "cm2_filter_apply_tiles",
+    "cm2_cutsky_to_fullsky", "cm2_fullsky_to_cutsky", "cm2_ground_bin_sums", "cm2_ground_subtract",
+])
+
+
 def call(name, *args):
-    """Call an int-status entry point and raise HipError with cm2_last_error().  A call that ran out of
-    device memory is tried once more after torch has returned its idle blocks to the driver (the
-    library has released its own cached blocks before reporting the failure)."""
+    """Call an int-status entry point and raise HipError with cm2_last_error().  A RESTARTABLE call that
+    returned CM2_ERR_OUT_OF_MEMORY is tried once more after torch has returned its idle blocks to the driver
+    (the library has released its own cached blocks before reporting the failure)."""
     fn = getattr(load(), name)
     rc = fn(*args)
-    if rc != 0:
-        msg = load().cm2_last_error() or b""
-        if b"out of memory" in msg and _free_torch_cache():
-            rc = fn(*args)
+    if rc == ERR_OUT_OF_MEMORY and name in RESTARTABLE and _free_torch_cache():
+        rc = fn(*args)
     check(rc)

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/cosmomap2.h"
@@ -27,13 +28,21 @@ hipError_t dev_free(void *p);
 template <typename T>
 static inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
 
+// Status codes of the C ABI (include/cosmomap2.h): CM2_ERR_HIP a HIP runtime call failed, CM2_ERR_ARGUMENT a
+// CM2_CHECK on arguments / object state failed, CM2_ERR_OUT_OF_MEMORY a device (or page-locked host) allocation
+// failed after the library had released its own cached blocks.  An out-of-memory failure also clears the
+// runtime's sticky last error, so that the next CM2_LAUNCH_OK() of this thread does not report it again.
 #define CM2_HIP(call)                                                                  \
     do {                                                                               \
         hipError_t e__ = (call);                                                       \
         if (e__ != hipSuccess) {                                                       \
             cm2::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),     \
                            __FILE__, __LINE__);                                        \
-            return 1;                                                                  \
+            if (e__ == hipErrorOutOfMemory) {                                          \
+                (void)hipGetLastError();                                               \
+                return CM2_ERR_OUT_OF_MEMORY;                                          \
+            }                                                                          \
+            return CM2_ERR_HIP;                                                        \
         }                                                                              \
     } while (0)
 
@@ -41,7 +50,7 @@ static inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_byt
     do {                                                                               \
         if (!(cond)) {                                                                 \
             cm2::set_error(__VA_ARGS__);                                               \
-            return 2;                                                                  \
+            return CM2_ERR_ARGUMENT;                                                   \
         }                                                                              \
     } while (0)
 
@@ -67,11 +76,15 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: granted[] (one
 // static array per kernel instance at the call site) remembers what each device was given, so the
 // runtime is asked once per device and again only when a launch needs more.
+// Application calls may come from several host threads (include/cosmomap2.h): the table is read and
+// written under one lock per translation unit, so a smaller request can never overwrite a larger grant.
 static inline hipError_t ensure_dynamic_lds(const void *func, size_t bytes, size_t (&granted)[64])
 {
+    static std::mutex mu;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> hold(mu);
     if (dev >= 0 && dev < 64 && granted[dev] >= bytes) return hipSuccess;
     e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) granted[dev] = bytes;

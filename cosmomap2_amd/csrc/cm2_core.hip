@@ -6,6 +6,7 @@
 #include <map>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -31,14 +32,28 @@ void set_error(const char *fmt, ...)
 // Both calls return when the copy is complete (the host buffer may be reused / is filled).
 namespace {
 constexpr size_t kStage = (size_t)1 << 20;
+// one page-locked block per host thread, returned when the thread ends (the main thread's block is left to
+// the process teardown: hipHostFree at static-destruction time races the runtime's own shutdown)
+struct StageBlock {
+    void *p = nullptr;
+    bool main_thread = false;
+    ~StageBlock()
+    {
+        if (p && !main_thread) (void)hipHostFree(p);
+    }
+};
 void *stage_buffer()
 {
-    static thread_local void *pinned = nullptr;
-    if (!pinned && hipHostMalloc(&pinned, kStage, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        pinned = nullptr;
+    static const std::thread::id first = std::this_thread::get_id();      // whoever copies first: in practice main
+    static thread_local StageBlock blk;
+    if (!blk.p) {
+        if (hipHostMalloc(&blk.p, kStage, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            blk.p = nullptr;
+        }
+        blk.main_thread = (std::this_thread::get_id() == first);
     }
-    return pinned;
+    return blk.p;
 }
 }  // namespace
 
@@ -153,7 +168,10 @@ hipError_t dev_malloc_bytes(void **p, size_t bytes)
         (void)hipGetLastError();
         cm2_release_cached_memory();
         e = hipMalloc(p, want);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();          // the failure is reported through e: do not leave it as the
+            return e;                         // runtime's last error for the next CM2_LAUNCH_OK() to find
+        }
     }
     std::lock_guard<std::mutex> hold(c.lock);
     c.live[*p] = {dev, want};

@@ -516,9 +516,11 @@ extern "C" int64_t cm2_tiles_span_samples(const cm2_tiles *t);
 
 static int noise_tiles_ready(cm2_noise *n, const cm2_tiles *tiles, const char *who, void *stream_)
 {
-    if (!n->fused && n->auto_method && n->lambda > 0 && cm2::fused_os_supported(n->lambda)) {
+    if (n->auto_method && n->method != CM2_TOEPLITZ_FUSED && n->lambda > 0 && cm2::fused_os_supported(n->lambda)) {
         // the method was left to the library and resolved to the direct sum (short band) for
-        // the time order; on a tile order the fused overlap-save kernel is the fast one
+        // the time order; on a tile order the fused overlap-save kernel is the fast one.  n->fused is
+        // only read and written under the operator's lock on this path (application calls of several
+        // host threads may meet here; the operators built with CM2_TOEPLITZ_FUSED set it at creation).
         std::lock_guard<std::mutex> lock(n->mu);
         if (!n->fused)
             if (int rc = cm2::fused_os_create(&n->fused, n->d_t, n->lambda, n->h_off, as_stream(stream_)))

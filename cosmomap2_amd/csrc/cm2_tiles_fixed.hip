@@ -1245,10 +1245,11 @@ int parts_plan(cm2_tiles *t, hipStream_t st)
     if (forced == 0) return 0;
     std::vector<int64_t> slice0, k0;
     fx_slices(t, t->fx_S, slice0, k0);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // The simulated machine is the MI355X this library is written for (kNumCU), NOT the live device: part
+    // boundaries change the order in which a pixel's terms are added, and the header promises that they
+    // depend on the plan only -- the same bits on any partition mode or device count.
     // (two workgroups per CU when their LDS fits twice, fx_max_slice)
-    const int slots = (fx_lds_bytes(t, t->fx_S) <= 79 * 1024 ? 2 : 1) * (cus > 0 ? cus : 256);
+    const int slots = (fx_lds_bytes(t, t->fx_S) <= 79 * 1024 ? 2 : 1) * kNumCU;
     std::vector<int64_t> load((size_t)t->ntiles, 0);
     int64_t total = 0;
     for (int64_t b = 0; b < t->ntiles; ++b) {

@@ -8,6 +8,8 @@ Vector kinds handled by the host classes:
   * torch cuda tensor (f64)  -- resident in HBM, no transfer
   * torch cpu tensor         -- only met in the gloo multi-process tests
 """
+import threading
+
 import numpy as np
 
 try:
@@ -57,15 +59,19 @@ def ptr(t):
 # runtime pins pageable host memory for copies of 1 MB and more, and when that memory is freed later the
 # kernel driver evicts the process's GPU queues for 10-30 ms (cm2_core.hip, profiles/r04_stall_probe.md).
 _STAGE_BYTES = 8 << 20
-_stage = {}
+_stage = threading.local()         # a pair of buffers per (host thread, device): copy_ releases the GIL, two
+                                   # threads in to_dev / to_host at once must not share staging memory
 
 
 def _stage_pair():
     d = torch.cuda.current_device()
-    if d not in _stage:
-        _stage[d] = [(torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
-                     for _ in range(2)]
-    return _stage[d]
+    pairs = getattr(_stage, "pairs", None)
+    if pairs is None:
+        pairs = _stage.pairs = {}
+    if d not in pairs:
+        pairs[d] = [(torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+                    for _ in range(2)]
+    return pairs[d]
 
 
 def _upload(arr):

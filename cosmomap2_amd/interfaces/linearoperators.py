@@ -305,18 +305,28 @@ class _TiledNormalLO(_DeviceOp):
         n = P.pol * P.ncols
         super(_TiledNormalLO, self).__init__(n, n, self._mult, symmetric=True)
 
-    def reduced_matvec(self, v, reducer, ngroups=4):
+    def reduced_matvec(self, v, reducer, ngroups=4, out=None):
         """``sum over ranks of (P^T N^-1 P) v`` with the cross-rank reduction of a finished
         part of the map overlapped with the back-projection of the next part: P^T runs tile
         group by tile group and ``reducer(view)`` (an asynchronous in-place sum, returning an
         object with ``wait()``) is started on each group's slice of the output as soon as its
         kernel is queued.  Returns None for a host vector (the caller then reduces the whole
-        result itself)."""
+        result itself).  ``out``: write into this device vector instead of a new one."""
         if not D.is_dev(v):
             return None
-        return self._mult(v, reducer=reducer, ngroups=int(ngroups))
+        return self._mult(v, reducer=reducer, ngroups=int(ngroups), out=out)
 
-    def _mult(self, v, reducer=None, ngroups=1):
+    def matvec_into(self, v, out):
+        """``out[:] = (P^T N^-1 P) v`` for device vectors, into memory the CALLER owns (a persistent
+        exchange buffer of the sharded layouts, sharding.py: no allocation and no copy per matvec, the
+        same addresses for the collective every time).  ``out``: contiguous float64 tensor of pol*npix."""
+        if not (D.is_dev(v) and D.is_dev(out)) or out.numel() != self.shape[0] or not out.is_contiguous() \
+                or out.dtype != D.torch.float64:
+            raise lp.ShapeError("matvec_into needs device vectors of %d doubles" % self.shape[0])
+        self._mult(v, out=out)
+        return out
+
+    def _mult(self, v, reducer=None, ngroups=1, out=None):
         P = self.P
         T = _sparse_tiles(P)
         x = D.f64(v)
@@ -351,7 +361,8 @@ class _TiledNormalLO(_DeviceOp):
             tod2 = self.noise._apply_all(tod)
             _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod2), D.ptr(d_tb), st)
             src = d_tb
-        out = D.empty(P.pol * P.ncols)
+        if out is None:
+            out = D.empty(P.pol * P.ncols)
         if reducer is None:
             _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(src), D.ptr(out), st)
             return D.like_input(out, v)

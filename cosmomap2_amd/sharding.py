@@ -140,14 +140,35 @@ class ShardedLO(lp.LinearOperator):
     map-domain operator) and all-reduces its output.  Vectors are replicated.
     """
 
-    def __init__(self, local_op, group=None):
+    def __init__(self, local_op, group=None, persistent_output=False):
+        """``persistent_output``: device results are written into ONE buffer the operator keeps (no
+        allocation per matvec, the same addresses for the all-reduce every time) and that buffer is what
+        ``matvec`` returns -- valid until the next application.  The PCG and Arnoldi drivers of this
+        package consume ``A p`` before they apply ``A`` again, so they may be given such an operator;
+        a caller that keeps results across applications must not set it."""
         self.local_op = local_op
         self.group = group
+        self.persistent_output = bool(persistent_output)
+        self._out = None
         self._chunks = None              # collective choice, made at the first matvec
         self.collectives_issued = 0      # map all-reduces issued so far (tests compare ranks)
         n = local_op.shape[0]
         super(ShardedLO, self).__init__(n, n, self._mult, symmetric=True,
                                         device_ok=lp.supports_device(local_op))
+
+    def _single(self, method):
+        """The one compiled operator behind ``local_op`` if it has ``method`` (the tile-order chain's
+        ``reduced_matvec`` / ``matvec_into``), else None."""
+        plan = getattr(self.local_op, "_compiled", None)
+        ops = plan() if plan is not None else [self.local_op]
+        return ops[0] if len(ops) == 1 and hasattr(ops[0], method) else None
+
+    def _out_buffer(self, x):
+        if not (self.persistent_output and D.is_dev(x)):
+            return None
+        if self._out is None or self._out.device != x.device:
+            self._out = torch.empty(self.shape[0], dtype=torch.float64, device=x.device)
+        return self._out
 
     def allreduce_chunks(self, nloc=None):
         """Number of tile groups whose all-reduces are overlapped with the back-projection.  The
@@ -178,24 +199,33 @@ class ShardedLO(lp.LinearOperator):
             return None
         if _trivial(self.group) and not os.environ.get("CM2_ALLREDUCE_CHUNKS"):
             return None
-        plan = getattr(self.local_op, "_compiled", None)
-        ops = plan() if plan is not None else [self.local_op]
-        if len(ops) != 1 or not hasattr(ops[0], "reduced_matvec"):
+        op = self._single("reduced_matvec")
+        if op is None:
             return None
-        chunks = self.allreduce_chunks(int(getattr(getattr(ops[0], "P", None), "nrows", 0)))
+        chunks = self.allreduce_chunks(int(getattr(getattr(op, "P", None), "nrows", 0)))
         if chunks <= 1:
             return None
         group = self.group
         self.collectives_issued += chunks
-        return ops[0].reduced_matvec(
+        out = self._out_buffer(x)
+        kw = {} if out is None else {"out": out}
+        return op.reduced_matvec(
             x, lambda view: dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True),
-            chunks)
+            chunks, **kw)
 
     def _mult(self, x):
         y = self._overlapped(x)
         if y is not None:
             return y
-        y = self.local_op.matvec(x)
+        out = self._out_buffer(x)
+        op = self._single("matvec_into") if out is not None else None
+        if op is not None:
+            y = op.matvec_into(x, out)
+        else:
+            y = self.local_op.matvec(x)
+            if out is not None and D.is_dev(y):
+                out.copy_(y)
+                y = out
         if isinstance(y, np.ndarray):
             y = np.ascontiguousarray(y)
         elif not y.is_contiguous():
@@ -260,6 +290,44 @@ class RowShards(object):
                                                 op=torch.distributed.ReduceOp.SUM, group=self.group)
         return out
 
+    # -- persistent exchange buffers of the matvec (device tensors only).  `gather` / `reduce_scatter`
+    #    above return fresh memory and zero-fill / copy whole padded vectors: right for the odd call
+    #    (collecting a solution), three map-sized passes plus allocator traffic when done per matvec.
+    def exchange_buffers(self, device):
+        """(gathered, to_sum): two vectors of ``rows * world`` doubles kept for the life of the object.
+        ``gathered`` receives the all-gather (every rank's padded rows: the padding is 0 because every
+        rank's padded rows are); the local operator writes its whole-map result into ``to_sum[:n]``,
+        whose padding ``[n:]`` is zeroed once, here, and never written again."""
+        bufs = getattr(self, "_xbuf", None)
+        if bufs is None or bufs[0].device != device:
+            g = torch.empty(self.rows * self.world, dtype=torch.float64, device=device)
+            t = torch.zeros(self.rows * self.world, dtype=torch.float64, device=device)
+            bufs = self._xbuf = (g, t)
+        return bufs
+
+    def gather_view(self, loc):
+        """All-gather of the ranks' rows into the persistent buffer; returns its first ``n`` entries (a
+        VIEW, valid until the next call).  One rank: ``loc`` itself."""
+        if _trivial(self.group):
+            return loc[:self.n] if len(loc) != self.n else loc
+        g, _ = self.exchange_buffers(loc.device)
+        torch.distributed.all_gather_into_tensor(g, loc if loc.is_contiguous() else loc.contiguous(),
+                                                 group=self.group)
+        return g[:self.n]
+
+    def reduce_scatter_buffer(self, device, out=None):
+        """This rank's rows of the sum over ranks of the ``to_sum`` buffers; ``out``: the (rows,) vector
+        to receive them (default: a new one)."""
+        _, t = self.exchange_buffers(device)
+        if out is None:
+            out = torch.empty(self.rows, dtype=torch.float64, device=device)
+        if _trivial(self.group):
+            out.zero_()
+            out[:self.hi - self.lo] = t[self.lo:self.hi]
+            return out
+        torch.distributed.reduce_scatter_tensor(out, t, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        return out
+
     def allreduce_(self, t):
         """In-place sum over ranks (dot products, Z^T r)."""
         return allreduce_sum_(t, self.group)
@@ -273,19 +341,42 @@ class RowShardedNormalLO(lp.LinearOperator):
     """``A`` on row-sharded vectors: all-gather, this rank's ``P_k^T N_k^-1 P_k``, reduce-scatter.
     Input and output are the rank's (padded) rows."""
 
-    def __init__(self, local_op, shards):
+    def __init__(self, local_op, shards, persistent_output=False):
+        """Device vectors go through the shards' persistent exchange buffers: all-gather into one,
+        the local operator writes its whole-map result straight into the other (``matvec_into`` of the
+        tile-order operator; one copy for any other operator), reduce-scatter out of it -- no
+        zero-fill, no copy and no map-sized allocation per matvec.  ``persistent_output``: the rank's
+        result rows are also written into a kept vector, which is what ``matvec`` returns (valid
+        until the next application; see ShardedLO)."""
         self.local_op, self.shards = local_op, shards
+        self.persistent_output = bool(persistent_output)
+        self._out = None
         if local_op.shape[0] != shards.n:
             raise lp.ShapeError("operator has %d rows, the shards cover %d" % (local_op.shape[0], shards.n))
         super(RowShardedNormalLO, self).__init__(shards.rows, shards.rows, self._mult, symmetric=True,
                                                  device_ok=lp.supports_device(local_op))
 
     def _mult(self, p_loc):
-        full = self.shards.gather(p_loc)
-        if not isinstance(full, np.ndarray) and not full.is_contiguous():
-            full = full.contiguous()
-        y = self.local_op.matvec(full)
-        return self.shards.reduce_scatter(y)
+        sh = self.shards
+        if not D.is_dev(p_loc):
+            full = sh.gather(p_loc)
+            if not isinstance(full, np.ndarray) and not full.is_contiguous():
+                full = full.contiguous()
+            return sh.reduce_scatter(self.local_op.matvec(full))
+        full = sh.gather_view(p_loc)
+        _, to_sum = sh.exchange_buffers(p_loc.device)
+        plan = getattr(self.local_op, "_compiled", None)
+        ops = plan() if plan is not None else [self.local_op]
+        if len(ops) == 1 and hasattr(ops[0], "matvec_into"):
+            ops[0].matvec_into(full, to_sum[:sh.n])
+        else:
+            to_sum[:sh.n].copy_(self.local_op.matvec(full))
+        out = None
+        if self.persistent_output:
+            if self._out is None or self._out.device != p_loc.device:
+                self._out = torch.empty(sh.rows, dtype=torch.float64, device=p_loc.device)
+            out = self._out
+        return sh.reduce_scatter_buffer(p_loc.device, out=out)
 
 
 class _SlicedWeights(object):

@@ -10,7 +10,13 @@
  * `inline(code, ...)` call is shown in INTEGRATION.md.
  *
  * Conventions
- *   - every function returns 0 on success, non-zero on failure;
+ *   - every function returns 0 on success, non-zero on failure: CM2_ERR_HIP (1) a HIP runtime call
+ *     failed, CM2_ERR_ARGUMENT (2) an argument or the state of an object was refused, CM2_ERR_OUT_OF_MEMORY
+ *     (3) a device allocation failed even after the library gave back its own cached blocks -- the one
+ *     failure a host may answer by freeing device memory of its own and calling again, PROVIDED the entry
+ *     point overwrites its outputs (every *_create, *_prepare_*, *_apply; not the in-place updates
+ *     cm2_axpy, cm2_scal, cm2_Z_axpy, cm2_panel_gemm(accumulate), cm2_pcg_update_*, cm2_flag_samples, nor
+ *     the drivers cm2_pcg, cm2_pcg_sharded, cm2_arnoldi);
  *     cm2_last_error() returns a static, thread-local message for the last failure;
  *   - pointers named d_* are DEVICE pointers, h_* are HOST pointers;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
@@ -44,6 +50,10 @@ extern "C" {
  * sum; CM2_PT_ORDER=exact / CM2_WEIGHTS_ORDER=exact or cm2_set_exact_order(1) restore the serial
  * order), cm2_pcg calls its callback after the next iteration's work is queued. */
 #define CM2_ABI_VERSION 2
+/* status codes (added in round 5 behind the same "non-zero on failure" contract: no version change) */
+#define CM2_ERR_HIP 1
+#define CM2_ERR_ARGUMENT 2
+#define CM2_ERR_OUT_OF_MEMORY 3
 
 const char *cm2_last_error(void);
 int cm2_abi_version(void);

@@ -359,9 +359,11 @@ def m2_apply(mbd, Z, AZ, coarse, r):
 # --------------------------------------------------------------------------
 # a13  arnoldi / build_hess / build_Z  (interfaces/deflationlib.py:17-184)
 # --------------------------------------------------------------------------
-def arnoldi(matvec, b, x0, tol=1e-5, inner_m=30):
+def arnoldi(matvec, b, x0, tol=1e-5, inner_m=30, exhausted="raise"):
     """Modified Gram-Schmidt Arnoldi with the reference's stop rule
-    abs(v_new[j]*h_{j+1,j}) <= tol (:101) and RuntimeError at inner_m (:111-112)."""
+    abs(v_new[j]*h_{j+1,j}) <= tol (:101) and RuntimeError at inner_m (:111-112).
+    exhausted="return" (bench.py's Ritz-space comparison only): hand back (vs, hs, inner_m) after
+    inner_m steps instead of raising, so that a fixed number of steps can be compared."""
     if not np.isfinite(b).all():
         raise ValueError("RHS must contain only finite numbers")
     b_norm = norm2(b)
@@ -388,6 +390,8 @@ def arnoldi(matvec, b, x0, tol=1e-5, inner_m=30):
         vs.append(v_new)
         hs.append(hcur)
         if j == inner_m:
+            if exhausted == "return":
+                return vs, hs, j
             raise RuntimeError("Convergence not achieved within the Arnoldi algorithm")
 
 
@@ -727,9 +731,25 @@ class HostProblem(object):
     def rhs(self, d):
         return self.A.Pt(self.A.N(_f64(d)))
 
-    def solve(self, b, rtol=1e-6, maxiter=500):
+    def solve(self, b, rtol=1e-6, maxiter=500, M=None):
         """(x, info, iterations counted as callback invocations -- the way the reference's scripts
-        count them, src/test_BD_precond_onto_real_data.py:41-47)."""
+        count them, src/test_BD_precond_onto_real_data.py:41-47).  M: another preconditioner
+        (default M_BD), e.g. the one `two_level` returns."""
         its = []
-        x, info = cg(self.A, b, rtol=rtol, maxiter=maxiter, M=self.M, callback=lambda xk: its.append(1))
+        x, info = cg(self.A, b, rtol=rtol, maxiter=maxiter, M=self.M if M is None else M,
+                     callback=lambda xk: its.append(1))
         return x, info, len(its)
+
+    def two_level(self, Z, apply='eig'):
+        """The reference's two-level build for a GIVEN deflation basis Z (n x r), all on the host
+        (src/test_M2_precond_onto_real_data.py:96-112): Az[:, i] = A * Z[:, i] -- r applications of
+        this problem's own A --, E = CoarseLO(Z, Az, r, apply) (interfaces/linearoperators.py:
+        1018-1027, `Coarse` above), M2 = Mbd*R + Zd*E*Zd.T with R = I - AZd*E*Zd.T (`m2_apply`,
+        with DeflationLO.mult / rmult of :1041-1056).  Returns (Az, Coarse, M2 as a callable)."""
+        Z = np.asfortranarray(Z, dtype=np.float64)                 # contiguous columns, like the z list
+        r = Z.shape[1]
+        Az = np.empty_like(Z)
+        for i in range(r):                                         # :98-101
+            Az[:, i] = self.A(Z[:, i])
+        co = Coarse(Z, Az, r, apply=apply)
+        return Az, co, (lambda v: m2_apply(self.M, Z, Az, co, v))

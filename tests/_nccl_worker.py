@@ -93,6 +93,26 @@ def main():
                                   callback=lambda v: its_r.append(1), dot_reduce=sh.allreduce_)
     assert info_r == 0 and len(its_r) == len(its_ref), (len(its_r), len(its_ref))
     assert torch.equal(sh.gather(xr), x_ref)
+    # ---- persistent exchange buffers (round 5), through RCCL: not one torch allocation inside a loop
+    #      of matvecs of either layout, the same output address every time, the bits of y_ref
+    def allocations():
+        st = torch.cuda.memory_stats()
+        return (st["allocation.all.allocated"], st["segment.all.allocated"])
+    for name, keep, vec in (("rows", RowShardedNormalLO(A_local, sh, persistent_output=True), x_loc),
+                            ("replicated", ShardedLO(A_local, persistent_output=True), x)):
+        for chunks in ("1", "4"):
+            os.environ["CM2_ALLREDUCE_CHUNKS"] = chunks
+            y_k = keep * vec
+            ptr_k = y_k.data_ptr()
+            assert torch.equal(y_k, y_ref), (name, chunks)
+            torch.cuda.synchronize()
+            a0 = allocations()
+            for _ in range(5):
+                y_k = keep * vec
+            torch.cuda.synchronize()
+            assert allocations() == a0, (name, chunks, "torch allocations inside the matvec loop", a0, allocations())
+            assert y_k.data_ptr() == ptr_k and torch.equal(y_k, y_ref), (name, chunks)
+    os.environ["CM2_ALLREDUCE_CHUNKS"] = "4"
     print("RCCL-1RANK-OK backend %s, %d collectives on map slices, PCG %d iterations "
           "(replicated) / %d (row-sharded), bit-identical to the single-process solve"
           % (dist.get_backend(), A.collectives_issued, len(its), len(its_r)), flush=True)

@@ -34,6 +34,7 @@ def test_two_ranks_share_one_gpu():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "SHARDED-OK" in res.stdout, res.stdout[-2000:]
     assert "ROWSHARDED-OK" in res.stdout, res.stdout[-2000:]
+    assert "PERSISTENT-OK" in res.stdout, res.stdout[-2000:]
 
 
 def test_one_rank_rccl_group():

@@ -327,6 +327,43 @@ def test_host_problem_equals_the_serial_oracle(oracle):
     assert np.linalg.norm(xh - xs) / np.linalg.norm(xs) < 1e-9
 
 
+def test_host_problem_two_level_build_has_the_reference_invariants(oracle):
+    """oracle.HostProblem.two_level (the host-side two-level build of tests/test_gpu_fullsize.py and bench.py's
+    parity_full_size.two_level) on a small raster-like problem: the invariants the reference's script prints
+    (src/test_M2_precond_onto_real_data.py:112-117: M2 A z_i = z_i, ||R A z_i|| <= 1e-10) hold, PCG with M2
+    reaches the M_BD solution in no more iterations; and oracle.arnoldi(exhausted="return") hands back the
+    same vectors and Hessenberg columns the raising form had built before it raised."""
+    rng = np.random.default_rng(6)
+    nt, npix, nb, pol = 40000, 300, 4, 1
+    d, pairs, phi, t, diag = oracle.system_setup(rng, nt, npix, nb)
+    pairs = ((np.arange(nt) // 7) % npix).astype(np.int32)            # a coherent scan: slow modes exist
+    kk = np.arange(30)
+    bands = [(1.0 + 0.1 * b) * np.exp(-kk / 9.0) for b in range(nb)]
+    H = oracle.HostProblem(pol, npix, pairs.copy(), phi, nt // nb, bands=bands, threads=2)
+    b = H.rhs(d)
+    vs, hs, m = oracle.arnoldi(lambda v: H.M(H.A(v)), H.M(b), np.zeros(b.size), tol=0.0, inner_m=12,
+                               exhausted="return")
+    assert m == 12 and len(vs) == 13 and len(hs) == 12
+    with pytest.raises(RuntimeError):
+        oracle.arnoldi(lambda v: H.M(H.A(v)), H.M(b), np.zeros(b.size), tol=0.0, inner_m=12)
+    V = np.column_stack(vs[:m])
+    assert np.abs(V.T.dot(V) - np.eye(m)).max() < 1e-8
+    Hm = oracle.build_hess(hs, m)
+    th, U = np.linalg.eigh(0.5 * (Hm + Hm.T))
+    r = 4
+    Z = V.dot(U[:, np.argsort(th)[:r]])
+    Az, co, M2 = H.two_level(Z, apply='eig')
+    for i in range(r):
+        assert np.linalg.norm(Az[:, i] - H.A(Z[:, i])) == 0.0
+        assert np.allclose(M2(Az[:, i]), Z[:, i])                       # M2 A z_i = z_i
+        y = co.mult(oracle.deflation_rmult(Z, Az[:, i]))
+        assert oracle.norm2(Az[:, i] - oracle.deflation_mult(Az, y)) <= 1e-10 * oracle.norm2(Az[:, i])   # R A z_i = 0
+    x1, info1, its1 = H.solve(b, rtol=1e-8)
+    x2, info2, its2 = H.solve(b, rtol=1e-8, M=M2)
+    assert info1 == 0 and info2 == 0 and its2 <= its1
+    assert np.linalg.norm(x2 - x1) / np.linalg.norm(x1) < 1e-6
+
+
 def test_library_call_is_retried_once_after_an_out_of_memory_failure(monkeypatch):
     """_hip.call: a call that ran out of device memory is tried once more after torch's cached blocks went
     back to the driver (the library has released its own before reporting); any other failure, and a
@@ -346,24 +383,48 @@ def test_library_call_is_retried_once_after_an_out_of_memory_failure(monkeypatch
 
     freed = []
     monkeypatch.setattr(_hip, "_free_torch_cache", lambda: freed.append(1) or True)
-    fake = Fake([1, 0], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
+    monkeypatch.setattr(_hip, "RESTARTABLE", frozenset(["cm2_something"]))
+    oom = _hip.ERR_OUT_OF_MEMORY
+    fake = Fake([oom, 0], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
     monkeypatch.setattr(_hip, "load", lambda: fake)
     _hip.call("cm2_something", 1, 2)
     assert fake.calls == 2 and freed == [1]
-    fake = Fake([1, 1], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
+    fake = Fake([oom, oom], b"d_temp.alloc(n) failed: out of memory (cm2_x.hip:1)")
     monkeypatch.setattr(_hip, "load", lambda: fake)
     with pytest.raises(_hip.HipError, match="out of memory"):
         _hip.call("cm2_something")
     assert fake.calls == 2
-    fake = Fake([1, 0], b"cm2_tiles_create: bad pol=7")
-    monkeypatch.setattr(_hip, "load", lambda: fake)
-    with pytest.raises(_hip.HipError, match="bad pol"):
-        _hip.call("cm2_something")
-    assert fake.calls == 1
-    # without a GPU there is nothing to free: no second attempt
-    monkeypatch.setattr(_hip, "_free_torch_cache", lambda: False)
-    fake = Fake([1, 0], b"x failed: out of memory")
+    # the status code decides, not the text of the message
+    fake = Fake([1, 0], b"hipLaunchKernel failed: out of memory")
     monkeypatch.setattr(_hip, "load", lambda: fake)
     with pytest.raises(_hip.HipError):
         _hip.call("cm2_something")
     assert fake.calls == 1
+    fake = Fake([2, 0], b"cm2_tiles_create: bad pol=7")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError, match="bad pol"):
+        _hip.call("cm2_something")
+    assert fake.calls == 1
+    # an entry point that updates in place is never run twice
+    monkeypatch.setattr(_hip, "RESTARTABLE", frozenset())
+    fake = Fake([oom, 0], b"x failed: out of memory")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError):
+        _hip.call("cm2_something")
+    assert fake.calls == 1
+    monkeypatch.setattr(_hip, "RESTARTABLE", frozenset(["cm2_something"]))
+    # without a GPU there is nothing to free: no second attempt
+    monkeypatch.setattr(_hip, "_free_torch_cache", lambda: False)
+    fake = Fake([oom, 0], b"x failed: out of memory")
+    monkeypatch.setattr(_hip, "load", lambda: fake)
+    with pytest.raises(_hip.HipError):
+        _hip.call("cm2_something")
+    assert fake.calls == 1
+
+
+def test_restartable_entry_points_exist_and_exclude_the_in_place_updates():
+    from cosmomap2_amd import _hip
+    assert _hip.RESTARTABLE <= set(_hip.PROTOTYPES)
+    for name in ("cm2_axpy", "cm2_scal", "cm2_Z_axpy", "cm2_panel_gemm", "cm2_pcg_update_p", "cm2_pcg_update_xr",
+                 "cm2_flag_samples", "cm2_pcg", "cm2_pcg_sharded", "cm2_arnoldi", "cm2_compact_f64"):
+        assert name not in _hip.RESTARTABLE
