@@ -648,8 +648,13 @@ class AllCoresMatvec(object):
     the diagonal blocks of BlockLO(offdiag=False) as one multiply.  `blocksize`: one int or the
     per-block sizes."""
 
-    def __init__(self, pol, npix, pix, cos, sin, blocksize, bands, threads, diag=None):
+    def __init__(self, pol, npix, pix, cos, sin, blocksize, bands, threads, diag=None, piece=1 << 20):
+        """piece: a noise block longer than this is convolved in pieces of that many outputs, each read
+        with a halo of lambda - 1 samples from INSIDE the block (nothing beyond the block's ends: the
+        zero boundary of linearoperators.py:592-593) -- the same sums, and every host thread has work
+        when a shard holds a few long detector blocks (C5: 8 blocks of 15 625 000 samples)."""
         from concurrent.futures import ThreadPoolExecutor
+        self.piece = int(piece)
         self.pol, self.npix, self.threads = pol, int(npix), int(threads)
         self.pix, self.cos, self.sin = _i32(pix), _f64(cos), _f64(sin)
         self.nt = self.pix.size
@@ -660,7 +665,10 @@ class AllCoresMatvec(object):
             self.kernels = [np.concatenate([np.asarray(b)[:0:-1], np.asarray(b)]) for b in bands]
         else:
             self.kernels = None
-        self.scratch = np.empty(self.threads * pol * self.npix)
+        # P^T: one private map per thread, summed afterwards -- at most ~4 GB of them (at nside 512 a map is
+        # 75 MB: 256 private maps would cost far more to clear and to sum than the scatter itself takes)
+        self.pt_threads = max(1, min(self.threads, int(4e9 // (8 * pol * max(self.npix, 1))) or 1))
+        self.scratch = np.empty(self.pt_threads * pol * self.npix)
         self.pool = ThreadPoolExecutor(min(self.threads, 64))
 
     def P(self, x):
@@ -675,18 +683,24 @@ class AllCoresMatvec(object):
         from scipy.signal import fftconvolve
         out_tod = np.empty(self.nt)
 
-        def one(b):
+        def one(job):
+            b, p0, p1, a, e = job
+            halo = (len(self.kernels[b]) - 1) // 2                       # lambda - 1
+            lo, hi = max(a, p0 - halo), min(e, p1 + halo)
+            out_tod[p0:p1] = fftconvolve(tod[lo:hi], self.kernels[b], mode="same")[p0 - lo:p1 - lo]
+        jobs = []
+        for b in range(len(self.kernels)):
             a, e = int(self.offs[b]), min(int(self.offs[b + 1]), self.nt)
-            if e > a:
-                out_tod[a:e] = fftconvolve(tod[a:e], self.kernels[b], mode="same")
-        list(self.pool.map(one, range(len(self.kernels))))
+            for p0 in range(a, e, self.piece):
+                jobs.append((b, p0, min(p0 + self.piece, e), a, e))
+        list(self.pool.map(one, jobs))
         return out_tod
 
     def Pt(self, tod):
         out = np.empty(self.pol * self.npix)
         lib_omp().orc_omp_Pt_apply(self.pol, ctypes.c_int64(self.nt), ctypes.c_int64(self.npix),
                                    self.pix.ctypes.data_as(_I32), _d(self.cos), _d(self.sin),
-                                   _d(_f64(tod)), _d(out), _d(self.scratch), self.threads)
+                                   _d(_f64(tod)), _d(out), _d(self.scratch), self.pt_threads)
         return out
 
     def __call__(self, x):

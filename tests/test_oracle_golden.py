@@ -226,6 +226,13 @@ def test_all_cores_baseline_equals_serial_oracle(oracle):
     for threads in (1, 3):
         y = oracle.AllCoresMatvec(pol, npix, pairs, c, s, nt // nb, bands, threads)(x)
         assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-13
+    # a block convolved in pieces (with halos from inside the block only): the same operator, also when a
+    # piece is shorter than the band and when the last piece of a block is ragged
+    tod = rng.standard_normal(nt)
+    ref_n = oracle.blocklo_mult(nt // nb, bands, True, tod)
+    for piece in (1 << 20, 4096, 1000, 17):
+        y = oracle.AllCoresMatvec(pol, npix, pairs, c, s, nt // nb, bands, 3, piece=piece).N(tod)
+        assert np.linalg.norm(y - ref_n) / np.linalg.norm(ref_n) < 1e-13, piece
 
 
 @pytest.mark.parametrize("pol", [1, 2, 3])
