@@ -102,8 +102,9 @@ def build(force=False, verbose=True, allow_spills=None):
     bad = KR.offenders(rows)
     if bad:
         msg = "default-path kernels spill registers: " + ", ".join(
-            "%s (%d VGPRs spilled, %d B/lane scratch)" % (r["kernel"], r.get("vgpr_spill", 0),
-                                                         r.get("scratch_bytes_per_lane", 0)) for r in bad)
+            "%s (%d VGPRs, %d SGPRs spilled, %d B/lane scratch)" % (
+                r["kernel"], r.get("vgpr_spill", 0), r.get("sgpr_spill", 0),
+                r.get("scratch_bytes_per_lane", 0)) for r in bad)
         if allow_spills if allow_spills is not None else os.environ.get("CM2_ALLOW_SPILLS"):
             print("WARNING: " + msg, file=sys.stderr)
         else:

@@ -310,8 +310,14 @@ struct ListArgs {
 // loop of unknown length the compiler cannot count the requests in flight and every later wait for
 // an OLDER load becomes s_waitcnt vmcnt(0), i.e. a wait for the table and the list words as well.
 constexpr int kTabRows = 8;
-__device__ __forceinline__ void tab_dma(const uint32_t *gtab, uint32_t *tab_lds, int rmax, int wave, int t)
+__device__ __forceinline__ void tab_dma(const uint32_t *gtab, uint32_t *tab_lds, int rmax, int wave_, int t)
 {
+    // (the wave index passes through an empty asm statement at every call: the eight wave-uniform tests below
+    //  are then scalar compares made where they are used -- shared between the window lists at the top of the
+    //  kernel and the result lists at its end they were eight 64-bit masks kept across the whole transform,
+    //  16 SGPRs spilled to VGPR lanes in the default instantiation)
+    int wave = wave_;
+    asm volatile("" : "+s"(wave));
     const uint32_t *g = gtab + 64 * wave + (t & 63);
 #pragma unroll
     for (int i = 0; i < kTabRows; ++i)
@@ -519,10 +525,18 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     auto list_args = [&](int l) {
         ListArgs la;
         const int64_t e0 = (int64_t)win * G::PER + G::list_off(l);
-        la.k = lst_k ? lst_k + e0 : nullptr;
-        la.q = lst_q ? lst_q + e0 : nullptr;
-        la.hdr = hdrs ? hdrs + ((int64_t)win * G::NLIST + l) : nullptr;
-        la.tab = tabs ? tabs + ((int64_t)win * G::NLIST + l) * rmax : nullptr;
+        // (no null tests: the launcher hands every MODE the arrays it reads -- a test made here is a 64-bit
+        //  mask the compiler keeps from the first use of a list to the last, across the whole transform)
+        la.k = nullptr;
+        la.q = nullptr;
+        la.hdr = nullptr;
+        la.tab = nullptr;
+        if constexpr (MODE == 1) la.k = lst_k + e0;
+        if constexpr (MODE == 1 || MODE == 2) la.q = lst_q + e0;
+        if constexpr (MODE == 2) {
+            la.hdr = hdrs + ((int64_t)win * G::NLIST + l);
+            la.tab = tabs + ((int64_t)win * G::NLIST + l) * rmax;
+        }
         return la;
     };
 

@@ -25,6 +25,11 @@ NO_SPILL = [r"\bk_os_real<", r"\bk_P_tiles", r"\bk_Pt_tiles", r"\bk_Pt_hot", r"\
             r"\bk_P_time", r"\bk_Zt_partial_wide", r"\bk_m2_finish_wide", r"\bk_gemm_tn_mfma", r"\bk_panel_gemm_mfma",
             r"\bk_Z_axpy_wide", r"\bk_filter_windows"]
 
+# kernels that must not spill SGPRs to VGPR lanes either: the overlap-save instantiations the default dispatch
+# reaches below 4 GB of TOD (at 246-254 of 256 VGPRs a lane register spent on spilled scalars is one too many);
+# the flat-addressing forms of the plain and run-coded lists (<32, 1, false>, <32, 2, false>) keep 44 / 56
+NO_SGPR_SPILL = [r"\bk_os_real<32, 0, false>", r"\bk_os_real<32, [123], true>", r"\bk_os_real<32, 3, false>"]
+
 _FIELDS = {"VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
            "LDS Size [bytes/block]": "lds_bytes"}
@@ -90,6 +95,9 @@ def offenders(rows):
         if any(re.search(p, r["kernel"]) for p in NO_SPILL):
             if r.get("vgpr_spill", 0) or r.get("scratch_bytes_per_lane", 0):
                 bad.append(r)
+                continue
+        if any(re.search(p, r["kernel"]) for p in NO_SGPR_SPILL) and r.get("sgpr_spill", 0):
+            bad.append(r)
     return bad
 
 

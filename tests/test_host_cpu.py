@@ -287,6 +287,11 @@ def test_kernel_resource_table_of_the_shipped_build():
     bad = KR.offenders([dict(unit="u", kernel="k_os_real<32, 2, true>", vgpr_spill=8, scratch_bytes_per_lane=36),
                         dict(unit="u", kernel="k_helper", vgpr_spill=3)])
     assert [r["kernel"] for r in bad] == ["k_os_real<32, 2, true>"]
+    # SGPRs spilled to VGPR lanes count for the overlap-save instantiations of the default dispatch only
+    bad = KR.offenders([dict(unit="u", kernel="k_os_real<32, 2, true>", sgpr_spill=16),
+                        dict(unit="u", kernel="k_os_real<32, 2, false>", sgpr_spill=56),
+                        dict(unit="u", kernel="k_tile_rank", sgpr_spill=129)])
+    assert [r["kernel"] for r in bad] == ["k_os_real<32, 2, true>"]
     rows = KR.load_all()
     names = {r["kernel"] for r in rows}
     for k in ("k_os_real<32, 0, false>", "k_os_real<32, 2, true>", "k_os_real<32, 3, false>", "k_P_tiles<3, true>",
@@ -294,6 +299,7 @@ def test_kernel_resource_table_of_the_shipped_build():
         assert k in names, k
     assert not KR.offenders(rows)
     assert not any(r.get("vgpr_spill", 0) or r.get("scratch_bytes_per_lane", 0) for r in KR.own_kernels(rows))
+    assert not [r for r in rows if r["kernel"] == "k_os_real<32, 2, true>" and r.get("sgpr_spill", 0)]
 
 
 def test_host_problem_equals_the_serial_oracle(oracle):
