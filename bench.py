@@ -117,6 +117,29 @@ def hbm_budget_gb(nt_rank, n, r, arnoldi_steps, world, layout):
             "total_GB": round(total / 1e9, 1), "fits_288_GB": bool(total < 0.9 * 288e9)}
 
 
+def device_state():
+    """What rocm-smi says about the card this process runs on (compute / memory partition mode, VRAM in use,
+    clocks): recorded with every line because the SAME commit measured 11.3 ms and 8.1 ms for N^-1 at C5 whole on
+    two boxes of the same pool (profiles/r05_c5_whole.md) -- a property of the box, not of the run."""
+    out = {}
+    try:
+        res = subprocess.run(["rocm-smi", "--showcomputepartition", "--showmemorypartition", "--showmeminfo", "vram",
+                              "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        cards = json.loads(res.stdout)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        out["cards_listed"] = len([k for k in cards if k.startswith("card")])
+        keep = ("partition", "vram", "sclk", "mclk")
+        for name, card in sorted(cards.items()):
+            if not name.startswith("card"):
+                continue
+            out[name] = {k.strip(): v for k, v in card.items() if any(w in k.lower() for w in keep)}
+        if vis:
+            out["visible_devices"] = vis
+    except Exception as exc:                                  # noqa: BLE001
+        out["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:120])
+    return out
+
+
 def git_head():
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
@@ -1180,6 +1203,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "hbm_memory": memory,
+            "device_state": device_state(),
             "setup_seconds": round(t_setup, 2),
             "setup_split_seconds": {k: round(v, 3) for k, v in S_setup.items()},
             "commit": git_head(),

@@ -92,6 +92,12 @@ struct cm2_tiles {
     int64_t *d_hot_range = nullptr;              // [chunks][2] first / one-past-last TB position
     int64_t *d_hot_tiles = nullptr;              // [nhot][3] first pixel, first chunk, chunk count
     double *d_hot_partial = nullptr;             // [chunks][3]
+    // FUSED form (round 5): the ranges of a hot tile are work items at the end of the main launch and their
+    // sums are added up by the last range to finish (cm2_tiles_fixed.hip, FxFused)
+    void *d_fx_fused = nullptr;                  // FxFused (device copy)
+    int *d_hot_range_tile = nullptr;             // [chunks] index of the range's tile in d_hot_tiles
+    unsigned int *d_fx_count = nullptr;          // [nhot] arrival counters, zeroed before every launch
+    size_t fx_count_bytes = 0;
 };
 
 namespace cm2 {

@@ -66,6 +66,159 @@ constexpr int kFxChunk = 32;
 constexpr int kFxChunkMinDefault = 256;
 constexpr int kFxMaxChunks = 128;       // per slice: S / kFxChunk + long runs <= 64 + 8
 
+// ------------------------------------------------------------------- fused form -----
+// The ranges of the hot tiles (a one-pixel tile of very many samples is reduced by ranges of kHotChunk samples)
+// used to be two more launches behind the main one (k_Pt_hot: 306 workgroups for a 5e6-sample pixel, 22 us;
+// k_hot_combine, 7 us).  They are work items at the END of the main launch's grid now, and the last range of a
+// tile to finish adds the tile's range sums.  Who is last depends on the dispatch; WHAT is added and in which
+// order does not (range after range, as k_hot_combine did): the same bits, whoever does it.  Measured at C4
+// with 5 % of the samples on one pixel (profiles/r05_pt_fused.md): P^T 0.402-0.411 against 0.440-0.449 ms.
+// The copies of SPLIT tiles stay with k_parts_combine: adding them in the main launch as well (the tile's last
+// part to finish reads the other parts' copies) was built and measured -- P^T of the uneven hit map 0.438-0.446
+// against 0.423-0.428 ms: one workgroup reading k copies at the tail of the launch loses to a short, wide
+// kernel -- and removed.
+// Hand-off between workgroups inside a launch (cdna_hip_programming.md, Guideline 16, counter form with
+// write-through payload): the producer stores its three sums sc1 (no release fence: a release writes back the
+// XCD's whole L2), drains them, ONE lane does a relaxed agent-scope fetch_add on the tile's counter; the
+// workgroup that draws the last ticket: agent-scope acquire fence by one lane, drain, barrier, then plain loads
+// of the others' sums.  The counters are zeroed by a memset in front of every launch (fx_launch_inst).
+struct FxFused {
+    unsigned int *count;            // [nhot] arrival counters
+    const int64_t *hot_range;       // [ranges][2] first / one-past-last TB position
+    const int *hot_range_tile;      // [ranges] index in hot_tiles
+    const int64_t *hot_tiles;       // [nhot][3] first pixel, first range, ranges
+    double *hot_partial;            // [ranges][3]
+    const uint16_t *pl;             // TB-order streams of the plan (hot ranges read them directly)
+    const double *a_tb, *b_tb;
+};
+
+constexpr int kHotChunk = 16384, kHotT = 1024;          // samples per range, (virtual) threads per range
+// (1024 threads: 306 workgroups of 256 left the chip with one wave per SIMD, 45 us for 5e6 samples)
+
+// a handed-off double: WRITE-THROUGH (sc1) store, so that the producer needs no release fence
+__device__ __forceinline__ void fx_publish(double *p, double x)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, x),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool fx_last_arriver(unsigned int *counter, unsigned int expected, int *lds_flag, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its (sc1) stores
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old + 1u == expected) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
+// One range of a hot tile (kHotChunk consecutive samples of ONE pixel) by one workgroup of kFxT = 512
+// threads doing the work of k_Pt_hot's 1024: thread t is the virtual threads t and t + 512, each adding the
+// terms at positions vt, vt + 1024, ... of the range in that order; the 1024 sums are combined by the same
+// halving tree.  Then the last range of the tile adds the tile's range sums in time order (k_hot_combine).
+template <int POL, bool HALF>
+__device__ __forceinline__ void fx_hot_item(const FxFused &z, int64_t c, const double *__restrict__ v_tb,
+                                            double *__restrict__ out, double *sm, int tid)
+{
+    double *red = sm;                                        // [3][kHotT]
+    const int64_t k0 = z.hot_range[2 * c], k1 = z.hot_range[2 * c + 1];
+    double sv[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    constexpr int U = 4;
+    for (int64_t kk = k0 + tid; kk < k1; kk += (int64_t)U * kHotT) {
+        double v[2][U], a[2][U], b2[2][U];
+        uint16_t w[2][U];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = kk + (int64_t)hh * kFxT + (int64_t)u * kHotT;
+                const int64_t kc = k < k1 ? k : k1 - 1;
+                v[hh][u] = v_tb[kc];
+                a[hh][u] = POL > 1 ? z.a_tb[kc] : 0.0;
+                b2[hh][u] = (POL > 1 && !HALF) ? z.b_tb[kc] : 0.0;
+                w[hh][u] = (POL > 1 && HALF) ? z.pl[kc] : (uint16_t)0;
+            }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (kk + (int64_t)hh * kFxT + (int64_t)u * kHotT >= k1) continue;
+                sv[hh] += v[hh][u];
+                if (POL > 1) {
+                    double cc, ss;
+                    if (HALF) {
+                        const double h = a[hh][u], h2 = h * h, inv = 1.0 / (1.0 + h2);
+                        cc = (1.0 - h2) * inv;
+                        ss = (h + h) * inv;
+                        if (w[hh][u] & 0x8000u) cc = -cc;
+                    } else {
+                        cc = a[hh][u];
+                        ss = b2[hh][u];
+                    }
+                    s1[hh] += v[hh][u] * cc;
+                    s2[hh] += v[hh][u] * ss;
+                }
+            }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        red[tid + hh * kFxT] = sv[hh];
+        red[kHotT + tid + hh * kFxT] = s1[hh];
+        red[2 * kHotT + tid + hh * kFxT] = s2[hh];
+    }
+    __syncthreads();
+    for (int h = kHotT / 2; h >= 1; h >>= 1) {
+        if (tid < h) {
+            red[tid] += red[tid + h];
+            red[kHotT + tid] += red[kHotT + tid + h];
+            red[2 * kHotT + tid] += red[2 * kHotT + tid + h];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        fx_publish(z.hot_partial + 3 * c, red[0]);
+        fx_publish(z.hot_partial + 3 * c + 1, red[kHotT]);
+        fx_publish(z.hot_partial + 3 * c + 2, red[2 * kHotT]);
+    }
+    const int h = z.hot_range_tile[c];
+    const int64_t p0 = z.hot_tiles[3 * h], c0 = z.hot_tiles[3 * h + 1], nc = z.hot_tiles[3 * h + 2];
+    int *flag = reinterpret_cast<int *>(red + 3 * kHotT);
+    if (!fx_last_arriver(z.count + h, (unsigned int)nc, flag, tid)) return;
+    // the tile's range sums in time order (k_hot_combine): staged 256 ranges at a time, one thread adds
+    double *st = red;
+    double tv = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int64_t base = 0; base < nc; base += 256) {
+        const int64_t n = nc - base < 256 ? nc - base : 256;
+        for (int64_t i = tid; i < 3 * n; i += kFxT) st[i] = z.hot_partial[3 * (c0 + base) + i];
+        __syncthreads();
+        if (tid == 0)
+            for (int64_t q = 0; q < n; ++q) {
+                tv += st[3 * q];
+                t1 += st[3 * q + 1];
+                t2 += st[3 * q + 2];
+            }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    if (POL == 1) {
+        out[p0] = tv;
+    } else if (POL == 2) {
+        out[2 * p0] = t1;
+        out[2 * p0 + 1] = t2;
+    } else {
+        out[3 * p0] = tv;
+        out[3 * p0 + 1] = t1;
+        out[3 * p0 + 2] = t2;
+    }
+}
+
 // ------------------------------------------------------------------- kernel --------
 template <int POL, bool HALF, int VPT>
 __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
@@ -76,7 +229,7 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     const uint32_t *__restrict__ tent, const double *__restrict__ ta,
     const double *__restrict__ tb, const double *__restrict__ v_tb, double *__restrict__ out,
     uint32_t chunk_min, const uint8_t *__restrict__ hot, const int4 *__restrict__ parts,
-    int part0, double *__restrict__ scratch)
+    int part0, double *__restrict__ scratch, const FxFused *__restrict__ fz, int nmain, int64_t hot_c0)
 {
     constexpr int D = kFxDepth;
     constexpr bool ANG = POL > 1, TWO = POL > 1 && !HALF;
@@ -91,6 +244,10 @@ __global__ __launch_bounds__(kFxT, 4) void k_Pt_tiles_fixed(
     double *vbuf1 = vbuf0 + VPT * kFxT;
     double *part = vbuf1 + VPT * kFxT;                   // 3 x kFxMaxChunks chunk sums of hot runs
     const int tid = threadIdx.x;
+    if (fz && (int)blockIdx.x >= nmain) {                // fused form: the ranges of the hot tiles come last
+        fx_hot_item<POL, HALF>(*fz, hot_c0 + ((int)blockIdx.x - nmain), v_tb, out, sm, tid);
+        return;
+    }
     // the workgroup's work: a whole tile, or (plans with parts) some consecutive slices of one, summed
     // into a scratch copy of the tile that k_parts_combine adds to the other parts' copies
     int b = tile0 + (int)blockIdx.x, nsl = 0;
@@ -348,7 +505,6 @@ __global__ __launch_bounds__(256) void k_parts_combine(const int64_t *__restrict
 // then adds the range sums of a tile in time order and writes the pixel.  Every boundary and every
 // order depends on the bucket's length only: reproducible bit for bit, independent of the rest of
 // the hit map; a regrouping of the serial sum, ~1e-16 relative per level away from it.
-constexpr int kHotChunk = 16384, kHotT = 1024;          // (1024 threads: 306 workgroups of 256 left the chip with one wave per SIMD, 45 us for 5e6 samples)
 constexpr int64_t kHotMin = kHotTileMin;                // samples that make a one-pixel tile hot
 static_assert(kHotMin == 2 * kHotChunk, "hot tiles: at least two ranges");
 
@@ -848,7 +1004,7 @@ size_t fx_lds_bytes(const cm2_tiles *t, int S)
 void hot_release(cm2_tiles *t)
 {
     void **ptrs[] = {(void **)&t->d_hot_flag, (void **)&t->d_hot_range, (void **)&t->d_hot_tiles,
-                     (void **)&t->d_hot_partial};
+                     (void **)&t->d_hot_partial, (void **)&t->d_hot_range_tile};
     for (void **q : ptrs) {
         if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
@@ -863,6 +1019,7 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
     hot_release(t);
     std::vector<uint8_t> flag((size_t)t->ntiles, 0);
     std::vector<int64_t> range, tiles;
+    std::vector<int> range_tile;                             // (fused form: which hot tile a range belongs to)
     t->hot_chunk0.assign(1, 0);
     for (int64_t b = 0; b < t->ntiles; ++b) {
         const int64_t n = t->tile_count[(size_t)b];
@@ -880,6 +1037,7 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
         tiles.push_back(t->tile_p0[(size_t)b]);
         tiles.push_back(c0);
         tiles.push_back((int64_t)range.size() / 2 - c0);
+        range_tile.resize(range.size() / 2, (int)t->hot_tile.size());
         t->hot_tile.push_back(b);
         t->hot_chunk0.push_back((int64_t)range.size() / 2);
     }
@@ -891,6 +1049,8 @@ int hot_plan(cm2_tiles *t, hipStream_t st)
     CM2_HIP(cm2::upload(t->d_hot_flag, flag.data(), flag.size(), st));
     CM2_HIP(cm2::upload(t->d_hot_range, range.data(), sizeof(int64_t) * range.size(), st));
     CM2_HIP(cm2::upload(t->d_hot_tiles, tiles.data(), sizeof(int64_t) * tiles.size(), st));
+    CM2_HIP(cm2::dev_malloc(&t->d_hot_range_tile, sizeof(int) * range_tile.size()));
+    CM2_HIP(cm2::upload(t->d_hot_range_tile, range_tile.data(), sizeof(int) * range_tile.size(), st));
     CM2_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -920,7 +1080,7 @@ void fx_release(cm2_tiles *t)
                      (void **)&t->d_fx_ga, (void **)&t->d_fx_gb, (void **)&t->d_fx_trun,
                      (void **)&t->d_fx_tent, (void **)&t->d_fx_ta, (void **)&t->d_fx_tb,
                      (void **)&t->d_parts, (void **)&t->d_multi,
-                     (void **)&t->d_part_buf};
+                     (void **)&t->d_part_buf, (void **)&t->d_fx_fused, (void **)&t->d_fx_count};
     for (void **q : ptrs) {
         if (*q) (void)cm2::dev_free(*q);
         *q = nullptr;
@@ -1339,25 +1499,67 @@ int parts_plan(cm2_tiles *t, hipStream_t st)
     return 0;
 }
 
+// The device-side description of the fused form (FxFused) and its arrival counters, after hot_plan: one
+// counter per hot tile, in a block of their own padded to 16 bytes (zeroed by one memset in front of every
+// launch).  CM2_PT_FUSE=0 keeps the separate kernels.
+int fused_plan(cm2_tiles *t, hipStream_t st)
+{
+    if (const char *e = getenv("CM2_PT_FUSE"))
+        if (atoi(e) == 0) return 0;
+    const size_t nhot = t->hot_tile.size();
+    if (nhot == 0) return 0;
+    t->fx_count_bytes = (sizeof(unsigned int) * nhot + 15) / 16 * 16;
+    CM2_HIP(cm2::dev_malloc(&t->d_fx_count, t->fx_count_bytes));
+    FxFused z;
+    memset(&z, 0, sizeof(z));
+    z.count = t->d_fx_count;
+    z.hot_range = t->d_hot_range;
+    z.hot_range_tile = t->d_hot_range_tile;
+    z.hot_tiles = t->d_hot_tiles;
+    z.hot_partial = t->d_hot_partial;
+    z.pl = t->d_pl;
+    z.a_tb = t->d_half ? t->d_half : t->d_cos;
+    z.b_tb = t->d_sin;
+    FxFused *dz = nullptr;
+    CM2_HIP(cm2::dev_malloc(&dz, sizeof(FxFused)));
+    t->d_fx_fused = dz;
+    CM2_HIP(cm2::upload(dz, &z, sizeof(FxFused), st));
+    CM2_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 template <int POL, bool HALF, int VPT>
 int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t tile_lo,
                    int64_t tile_hi, hipStream_t stream)
 {
-    const size_t lds = fx_lds_bytes(t, t->fx_S);
-    static size_t granted[64] = {0};
-    CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
     // plans with parts (and not the exact order): the workgroups are the parts of the tiles in range, in
     // tile (= address) order; then the copies of the split tiles are added up
     const bool parts = t->d_parts && t->pt_fixed != 2;
     const int64_t q0 = parts ? t->tile_part0[(size_t)tile_lo] : tile_lo;
     const int64_t q1 = parts ? t->tile_part0[(size_t)tile_hi] : tile_hi;
-    k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(q1 - q0), kFxT, lds, stream>>>(
+    // fused form: the hot tiles' ranges inside [tile_lo, tile_hi) are further workgroups of this launch
+    const bool fused = t->d_fx_fused && t->pt_fixed != 2;
+    int64_t hc0 = 0, hc1 = 0;
+    if (fused && t->d_hot_flag) {
+        int64_t h0 = 0, h1 = (int64_t)t->hot_tile.size();
+        while (h0 < h1 && t->hot_tile[(size_t)h0] < tile_lo) ++h0;
+        while (h1 > h0 && t->hot_tile[(size_t)h1 - 1] >= tile_hi) --h1;
+        hc0 = t->hot_chunk0[(size_t)h0];
+        hc1 = t->hot_chunk0[(size_t)h1];
+    }
+    size_t lds = fx_lds_bytes(t, t->fx_S);
+    if (hc1 > hc0 && lds < sizeof(double) * (3 * (size_t)kHotT + 2)) lds = sizeof(double) * (3 * (size_t)kHotT + 2);
+    static size_t granted[64] = {0};
+    CM2_HIP(ensure_dynamic_lds((const void *)k_Pt_tiles_fixed<POL, HALF, VPT>, lds, granted));
+    if (fused) CM2_HIP(hipMemsetAsync(t->d_fx_count, 0, t->fx_count_bytes, stream));
+    k_Pt_tiles_fixed<POL, HALF, VPT><<<(int)(q1 - q0 + hc1 - hc0), kFxT, lds, stream>>>(
         t->tp, t->d_tile_p0, (int)tile_lo, t->d_fx_sk, t->d_fx_slice0, t->d_fx_meta,
         t->d_fx_gent, reinterpret_cast<const double2 *>(t->d_fx_ga),
         reinterpret_cast<const double2 *>(t->d_fx_gb), t->d_fx_trun, t->d_fx_tent, t->d_fx_ta,
         t->d_fx_tb, d_tod_tb, d_out,
         t->pt_fixed == 2 ? 0xFFFFFFFFu : (uint32_t)kFxChunkMinDefault,
-        t->pt_fixed == 2 ? nullptr : t->d_hot_flag, parts ? t->d_parts : nullptr, (int)q0, t->d_part_buf);
+        t->pt_fixed == 2 ? nullptr : t->d_hot_flag, parts ? t->d_parts : nullptr, (int)q0, t->d_part_buf,
+        fused ? static_cast<const FxFused *>(t->d_fx_fused) : nullptr, (int)(q1 - q0), hc0);
     CM2_LAUNCH_OK();
     if (parts) {
         int64_t m0 = 0, m1 = (int64_t)t->multi_tile.size();
@@ -1370,7 +1572,7 @@ int fx_launch_inst(const cm2_tiles *t, const double *d_tod_tb, double *d_out, in
             CM2_LAUNCH_OK();
         }
     }
-    if (t->pt_fixed != 2 && t->d_hot_flag)
+    if (t->pt_fixed != 2 && t->d_hot_flag && !fused)
         return hot_launch<POL, HALF>(t, d_tod_tb, d_out, tile_lo, tile_hi, stream);
     return 0;
 }
@@ -1496,6 +1698,7 @@ int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
     if (!t->d_hot_flag && t->hot_chunk0.empty()) {
         if (int rc = hot_plan(t, st)) return rc;
         if (int rc = parts_plan(t, st)) return rc;
+        if (int rc = fused_plan(t, st)) return rc;
     }
     mark.ok = true;
     *use = true;

@@ -369,3 +369,13 @@ def test_heavy_tiles_are_shared_out_to_several_workgroups(cm, oracle, monkeypatc
         np.testing.assert_array_equal(apply(T1, v1), want)
     T1.set_pt_order(1)
     np.testing.assert_array_equal(apply(T1, v1), got)
+    # round 5: the copies of a split tile are added by the tile's last part to finish and the hot tile's ranges
+    # are work items of the same launch (one launch; who adds depends on the dispatch, what is added and in
+    # which order does not) -- the separate kernels of round 4 (CM2_PT_FUSE=0) give the same bits, and so do
+    # many applications in a row (the arrival counters are zeroed in front of every launch)
+    monkeypatch.setenv("CM2_PT_FUSE", "0")
+    P2, T2, v2 = plan()
+    np.testing.assert_array_equal(apply(T2, v2), got)
+    for _ in range(20):
+        _hip.call("cm2_Pt_tiles_apply", T1.h, D.ptr(v1), D.ptr(pieces), st)
+    np.testing.assert_array_equal(pieces.cpu().numpy(), got)
