@@ -117,6 +117,43 @@ def hbm_budget_gb(nt_rank, n, r, arnoldi_steps, world, layout):
             "total_GB": round(total / 1e9, 1), "fits_288_GB": bool(total < 0.9 * 288e9)}
 
 
+def measure_traffic(kernel_regex, child_args, timeout=420):
+    """HBM traffic of one kernel per launch from the PMC counters, measured by THIS run: two child processes of this
+    script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need a pass each: the TCC block has four counter
+    slots, FETCH_SIZE takes three, WRITE_SIZE two -- /opt/skills/guides/MI355X_MICROARCH.md, rocprofv3 PMC slots;
+    counters only, no other trace domain than the kernel trace).  The children repeat the workload with few steps
+    and every extra leg switched off; the median over the kernel's launches is taken.  Both counters are KiB per
+    dispatch; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so traffic = 2 * FETCH_SIZE + WRITE_SIZE
+    (the guide's HBM section).  Children are started with subprocess (never exec), program after `--` is python3."""
+    import csv
+    import glob
+    import statistics
+    import tempfile
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--kernel-include-regex", kernel_regex, "-d", d,
+                   "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr and kernel_regex in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                raise RuntimeError("rocprofv3 --pmc %s gave no row for %s (rc %d): %s"
+                                   % (ctr, kernel_regex, res.returncode, (res.stderr or res.stdout)[-300:]))
+            got[ctr] = {"bytes": statistics.median(vals) * 1024.0, "launches": len(vals)}
+    return 2.0 * got["FETCH_SIZE"]["bytes"] + got["WRITE_SIZE"]["bytes"], got
+
+
+def under_profiler():
+    keys = " ".join(k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")))
+    return bool(keys) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def device_state():
     """What rocm-smi says about the card this process runs on (compute / memory partition mode, VRAM in use,
     clocks): recorded with every line because the SAME commit measured 11.3 ms and 8.1 ms for N^-1 at C5 whole on
@@ -223,6 +260,9 @@ def main():
                     help="parity_full_size also runs the oracle's own Arnoldi (reference recurrence, "
                          "interfaces/deflationlib.py:17-113) for --arnoldi-steps steps on the host and reports the "
                          "principal angles between its Ritz space and the GPU's (minutes of host time)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child runs (copied from the newest "
+                         "committed profile instead); implied by --no-cpu and inside a profiled run")
     ap.add_argument("--no-raster", action="store_true",
                     help="skip the secondary run with a coherent raster-scan pointing")
     ap.add_argument("--no-filters", action="store_true",
@@ -274,6 +314,7 @@ def main():
     import cosmomap2_amd
     from cosmomap2_amd import device as D
     from cosmomap2_amd import _hip
+    from cosmomap2_amd.build import library_stamp
     from cosmomap2_amd.interfaces import SparseLO, BlockLO, BlockDiagonalPreconditionerLO
     from cosmomap2_amd.interfaces import linearoperators as L
     from cosmomap2_amd.utilities import ProcessTimeSamples
@@ -610,17 +651,41 @@ def main():
     # rocprofv3 passes of their own, so the figure is NOT measured in this run: it is copied from
     # the newest committed summary of this command (profiles/make_summary.py), only when workload
     # and size are the same, and labelled with that profile's file and commit.
-    try:
-        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_c4.json"))
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-        if pmc["workload"] == cfg["label"] and pmc["nt_per_gpu"] == nt:
-            for kname, rec in pmc["kernels"].items():
-                if kname in dom and rec.get("hbm_traffic_bytes"):
-                    roofline["traffic"] = rec["hbm_traffic_bytes"]
-                    roofline["traffic_source"] = "profiles/" + pmcs[-1]
-                    roofline["traffic_source_commit"] = pmc.get("commit")
-    except Exception:
-        pass
+    dom_regex = next((k for k in ("k_os_real", "k_PtNP_sell", "k_P_tiles", "k_Pt_tiles_fixed") if k in dom), None)
+    if (rank == 0 and world == 1 and dom_regex and not (args.no_traffic or args.no_cpu) and not under_profiler()):
+        # measured by this run: two rocprofv3 --pmc children of the same workload (FETCH_SIZE, WRITE_SIZE)
+        child = ["--config", args.config, "--scaling", args.scaling, "--gpus", "1", "--steps", "3", "--warmup", "1",
+                 "--toeplitz", args.toeplitz, "--no-cpu", "--no-filters", "--no-raster", "--no-pcg", "--no-parity",
+                 "--no-traffic", "--deflation", "0"]
+        if args.nt:
+            child += ["--nt", str(args.nt)]
+        if args.lam:
+            child += ["--lam", str(args.lam)]
+        try:
+            t_tr = time.perf_counter()
+            traffic, passes = measure_traffic(dom_regex, child)
+            roofline.update({"traffic": traffic, "traffic_measured_in_run": True,
+                             "traffic_passes": {"FETCH_SIZE_bytes": passes["FETCH_SIZE"]["bytes"],
+                                                "WRITE_SIZE_bytes": passes["WRITE_SIZE"]["bytes"],
+                                                "launches_per_pass": passes["FETCH_SIZE"]["launches"],
+                                                "formula": "2 * FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts "
+                                                           "128-byte requests at 64 bytes)",
+                                                "seconds": round(time.perf_counter() - t_tr, 1)}})
+        except Exception as exc:                              # noqa: BLE001  (auxiliary: falls back to the copy)
+            roofline["traffic_measurement_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if roofline["traffic"] is None:
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_c4.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+            if pmc["workload"] == cfg["label"] and pmc["nt_per_gpu"] == nt:
+                for kname, rec in pmc["kernels"].items():
+                    if kname in dom and rec.get("hbm_traffic_bytes"):
+                        roofline["traffic"] = rec["hbm_traffic_bytes"]
+                        roofline["traffic_source"] = "profiles/" + pmcs[-1]
+                        roofline["traffic_source_commit"] = pmc.get("commit")
+                        roofline["traffic_source_sources_sha16"] = pmc.get("library_sources_sha16")
+        except Exception:
+            pass
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
     stage_report = {}
     for k, v in stages.items():
@@ -1204,6 +1269,7 @@ def main():
             "cpu_baseline_all_cores": cpu_all,
             "hbm_memory": memory,
             "device_state": device_state(),
+            "library": library_stamp(),
             "setup_seconds": round(t_setup, 2),
             "setup_split_seconds": {k: round(v, 3) for k, v in S_setup.items()},
             "commit": git_head(),

@@ -29,6 +29,33 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-ffp-contract=
 FMA_OK = {"cm2_overlap_save.hip"}
 
 
+STAMP = os.path.join(HERE, "libcosmomap2_hip.sources.sha16")
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers the library is built from, in name
+    order.  Written next to the library at link time and printed by bench.py beside the hash of the sources
+    present at run time: a profile or a bench line says which sources its kernels came from even where there
+    is no .git (the GPU boxes), and profiles/make_summary.py refuses counters taken from another build."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(HERE, "..", "include", "*.h")), key=os.path.basename)
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_stamp():
+    """{"at_build": hash stored when the library was linked (None: no stamp), "now": hash of the sources present}"""
+    at_build = open(STAMP).read().strip() if os.path.exists(STAMP) else None
+    if os.environ.get("CM2_LIB_PATH"):                     # a variant build loaded for an A/B run: no stamp
+        at_build = "variant:" + os.path.basename(os.environ["CM2_LIB_PATH"])
+    return {"sources_sha16_at_build": at_build, "sources_sha16_now": source_hash(),
+            "library_matches_sources": at_build is not None and at_build == source_hash()}
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -89,6 +116,11 @@ def build(force=False, verbose=True, allow_spills=None):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(STAMP, "w") as fh:
+            fh.write(source_hash() + "\n")
+    elif not os.path.exists(STAMP):
+        with open(STAMP, "w") as fh:                       # (a library linked before the stamp existed, up to date)
+            fh.write(source_hash() + "\n")
     rows = KR.load_all()
     if jobs:
         prof = os.path.join(HERE, "..", "profiles")

@@ -15,15 +15,9 @@ struct cm2_tiles {
     std::vector<int64_t> tile_p0;   // [ntiles+1] first pixel of every tile (host)
     int64_t *d_tile_p0 = nullptr;
     int64_t ntiles = 0, nitems = 0;
-    // SPANS (round 4; OFF by default: see span_chunks in cm2_tiles.hip for what was measured).  The tile
-    // order can be cut in time: samples are then ordered [span][tile][time], a span
-    // being `span_samples` consecutive time samples (a whole number of the partition's 8192-sample
-    // chunks).  A window of the overlap-save kernel then finds its 16384 samples in ONE region of
-    // span_samples doubles (8 MB at C4) that the neighbouring windows consume while it is cache
-    // resident, instead of in one run per tile spread over the whole 0.8 GB buffer; P / P^T walk a
-    // tile's SEGMENTS (its samples of one span: ~2000 consecutive addresses) with the tile in LDS.
-    // nspans = 1 is the global tile order of rounds 1-3.  segment (span sp, tile b) = addresses
-    // [seg_off[sp * ntiles + b], seg_off[sp * ntiles + b + 1]).
+    // The tables below keep the general [span][tile][time] form of round 4's span order with ONE span (the
+    // global tile order; the option itself was measured out and removed in round 5, cm2_tiles.hip): segment
+    // (0, tile b) = the tile's whole bucket, addresses [seg_off[b], seg_off[b + 1]).
     int64_t nspans = 1, span_samples = 0;
     std::vector<int64_t> seg_off;   // [nspans * ntiles + 1] (host)
     int64_t *d_seg_off = nullptr;
@@ -106,9 +100,6 @@ int fx_launch(const cm2_tiles *t, const double *d_tod_tb, double *d_out, int64_t
               int64_t tile_hi, hipStream_t stream);
 void fx_free(cm2_tiles *t);
 int64_t fx_designed_bytes(const cm2_tiles *t);
-// mean groups per slice of the fixed-order lists and the fraction of slices with more groups than the
-// workgroup has threads, counted on every 8th slice of the plan's segments (slice length: fx_max_slice)
-int fx_groups_estimate(const cm2_tiles *t, hipStream_t st, double *mean_groups, double *over);
 int fx_parts_info(const cm2_tiles *t, int64_t *h_info);   // cm2_tiles_pt_parts
 int fx_max_slice(const cm2_tiles *t);      // longest slice (samples) the fixed-order kernel's LDS budget allows
 bool fx_serial_build();                    // CM2_FX_BUILD=serial (the reference builders: global tile order only)

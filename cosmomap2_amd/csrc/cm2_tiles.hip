@@ -703,34 +703,13 @@ extern "C" int cm2_tiles_destroy(cm2_tiles *t)
     return 0;
 }
 
-// Chunks of 8192 samples per span (CM2_TILE_SPAN = samples per span; unset or 0: ONE span, the
-// global tile order -- the default).
-//
-// Measured at C4 on one box, same run (profiles/r04_spans_ab.md): with spans of ~9.4e5 samples (a
-// tile's segment = about one slice of the fixed-order P^T: 0.9 x longest slice x ntiles, the value
-// CM2_TILE_SPAN=auto selects) the overlap-save kernel goes from 0.770 to 0.735 ms -- its windows
-// find their samples in one cache-resident 8 MB region -- and k_P_tiles from 0.352 to 0.385 ms: its
-// three streams are cut into 4-15 KB pieces, one per segment.  Step 1.447-1.477 against 1.474 ms: no
-// net gain on the reference generator's uniform pointing, and a loss on a raster scan (1.38 -> 1.45 ms:
-// most segments of a tile are empty or long) and on the uneven hit maps (+1 %).  The probe that
-// preceded the implementation (profiles/r04_chunk_sizes_c4.jsonl, N^-1 alone on plain lists: 0.884 ->
-// 0.798 ms at 2^20 samples per span, 0.819 / 0.805 / 0.812 / 0.821 at 2^18 / 2^19 / 2^21 / 2^22) had
-// promised twice that on the overlap-save side.  The order is therefore OFF by default; everything
-// downstream of it (segment-walking P / P^T, per-slice addresses of the fixed-order lists, the two
-// window sets of the overlap-save lists) stays in place, tested, behind the switch.
-static int64_t span_chunks(const cm2_tiles *t, int64_t nchunks)
-{
-    const char *e = getenv("CM2_TILE_SPAN");
-    if (!e || cm2::fx_serial_build()) return nchunks;
-    int64_t span = atoll(e);
-    if (!strcmp(e, "auto")) span = (int64_t)(0.9 * (double)cm2::fx_max_slice(t)) * t->ntiles;
-    if (span <= 0) return nchunks;
-    int64_t G = (span + kSplitChunk / 2) / kSplitChunk;
-    if (G < 2) G = 2;                                    // (a window of 16384 samples touches <= 2 spans)
-    if (2 * G > nchunks) return nchunks;                 // fewer than two whole spans: not worth a cut
-    return G;
-}
-
+// The tile order cut in time ([span][tile][time], rounds 4-5) is GONE as an option: measured again in round 5
+// with spans sized for the Infinity Cache (profiles/r05_spans_removed.md: C4 step 1.41 ms on the global order
+// against 1.43 / 1.48 / 1.57 with spans of 9.4e5 / 1.7e7 / 8.4e6 samples; C5 share 1.99 against 2.05-2.06; at
+// C5 whole N^-1 did not move at all) it never paid, and round 4's switch (CM2_TILE_SPAN), its automatic span
+// length and its 71 tests were removed.  What remains of it is the GENERAL form of the tables the kernels walk --
+// segment (span, tile) with ONE span: a tile's segment is its whole bucket, `seg_off` is the tile offsets,
+// every work item is one tile's address range -- which costs nothing and is what the builders were tested on.
 extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const double *d_cos,
                                 const double *d_sin, int64_t nt, int64_t npix, int pol,
                                 int tile_pixels, int64_t slice_samples, void *stream_)
@@ -764,7 +743,6 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     DevTemp<uint32_t> packed, cnt_t;                           // multisplit: tile << 16 | rank; counts -> bases
     const int64_t nchunks = (nt + kSplitChunk - 1) / kSplitChunk;
     int64_t G = nchunks;                                       // chunks per span (nchunks: one span)
-    int64_t G_override = 0;                                    // a span length corrected by the measured lists
     DevTemp<int64_t> d_off;
     DevTemp<char> d_temp;
     DevTemp<unsigned int> d_bad;
@@ -826,9 +804,7 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     auto partition = [&](const int64_t *d_p0) -> int {
         d_off.release();
         sorted = use_sort || t->ntiles > kSplitMaxTiles || t->ntiles * nchunks + 1 >= ((int64_t)1 << 31);
-        // spans need the multisplit (its counts are what orders them) and the LDS builders of the
-        // fixed-order lists; the sort paths keep the global tile order
-        G = sorted ? nchunks : (G_override ? G_override : span_chunks(t, nchunks));
+        G = nchunks;                                        // one span: the global tile order
         t->nspans = (nchunks + G - 1) / G;
         if (t->nspans < 1) t->nspans = 1;
         t->span_samples = G * kSplitChunk;
@@ -1052,28 +1028,6 @@ extern "C" int cm2_tiles_create(cm2_tiles **out, const int32_t *d_pix, const dou
     return 0;
     };
     if (int rc = place()) return rc;
-    // Spans: the span length was chosen for segments of ~0.9 x (longest slice) samples, assuming the
-    // fixed-order P^T packs such a slice into fewer groups than the workgroup has threads.  A dense
-    // hit map (many hits per pixel and slice: long runs, more groups per sample) breaks that: the
-    // lists of a sample of the segments are counted (the counting pass of the list builder on every
-    // 8th slice) and, where the mean exceeds 0.95 x 512 groups or more than a tenth of the slices
-    // exceed 512, the span is shortened in proportion and the order rebuilt (3 ms at 1e8 samples).
-    if (t->nspans > 1 && t->pt_fixed && !G_override && getenv("CM2_TILE_SPAN") &&
-        !strcmp(getenv("CM2_TILE_SPAN"), "auto")) {
-        double mean = 0.0, over = 0.0;
-        if (int rc = cm2::fx_groups_estimate(t, stream, &mean, &over)) return rc;
-        double shrink = 1.0;
-        if (mean > 0.95 * 512.0) shrink = 0.92 * 512.0 / mean;
-        if (over > 0.10 && shrink > 0.875) shrink = 0.875;
-        if (shrink < 1.0) {
-            G_override = (int64_t)((double)G * shrink);
-            if (G_override < 2) G_override = 2;
-            if (int rc = partition(balance ? d_p0.p : nullptr)) return rc;
-            if (int rc = publish_segments()) return rc;
-            if (int rc = place()) return rc;
-        }
-    }
-
     // work items: a tile's segments in span order, gathered until they hold >= slice_samples samples; a
     // segment longer than that (one span: the whole bucket) is cut into address ranges
     std::vector<int32_t> it_tile;

@@ -1595,11 +1595,6 @@ void fx_free(cm2_tiles *t) { fx_release(t); }
 
 bool fx_serial_build() { return fx_serial(); }
 
-int fx_groups_estimate(const cm2_tiles *t, hipStream_t st, double *mean_groups, double *over)
-{
-    return fx_estimate(t, fx_max_slice(t), st, mean_groups, over);
-}
-
 // longest slice the kernel can stage beside the tile: 4 values a thread at most, and short enough for
 // two workgroups per CU (<= 79 KB each) whenever some slice length allows that
 int fx_max_slice(const cm2_tiles *t)

@@ -133,12 +133,9 @@ int cm2_PtNP_diag_apply(const cm2_pointing *p, const double *d_x, double *d_out,
  * a2-a3 (throughput form)  Tile-bucketed TOD order
  *   Samples grouped by pixel tile (stable, so time order inside a tile); the tile's
  *   slice of the map is staged in LDS, so P and P^T stream HBM with no random access.
- *   CM2_TILE_SPAN = samples (or "auto") cuts the order in time as well -- [span][tile][time], a span
- *   being a whole number of 8192-sample chunks -- so that a window of the overlap-save kernel finds
- *   its samples in one cache-resident region; measured neutral on uniform pointing and slower on
- *   raster scans, hence off by default.  The order is internal: TB-ordered TODs are only ever produced
- *   and consumed by the entry points of this section and cm2_noise_apply_tiles /
- *   cm2_filter_apply_tiles.
+ *   The order is internal: TB-ordered TODs are only ever produced and consumed by the entry points of
+ *   this section and cm2_noise_apply_tiles / cm2_filter_apply_tiles.  (Round 4's option to cut the
+ *   order in time as well, CM2_TILE_SPAN, never paid and was removed in round 5.)
  *   Same loops as above (linearoperators.py:483-489, :509-516).  P^T by default adds every
  *   pixel's terms in time order from 0 like the serial loop (one workgroup per tile, per-slice
  *   lists sorted by (pixel, time), no atomics: bitwise reproducible); cm2_tiles_set_pt_order(t, 0)
@@ -155,7 +152,8 @@ int cm2_tiles_destroy(cm2_tiles *t);
  * sin = 2h/(1+h^2), absolute error ~2e-16, and read 8 bytes less per sample), 1 if P^T sums in
  * fixed (time) order, the plan's id (unique per plan in this process), slice length of the
  * fixed-order lists (0 until the first P^T builds them), the bytes one fixed-order P^T is
- * designed to read (TOD + padded lists), the number of spans and the samples per span */
+ * designed to read (TOD + padded lists), then 1 and the padded sample count (the two fields of the
+ * span order removed in round 5: one span = the global tile order) */
 int cm2_tiles_info(const cm2_tiles *t, int64_t *h_info);
 /* fixed == 1 (default): P^T adds each pixel's terms in time order (the reference's order,
  * reproducible bit for bit), except that a pixel hit more than 256 times inside one slice of a
@@ -260,8 +258,8 @@ int cm2_noise_info(const cm2_noise *n, int64_t *h_info);
  * ToeplitzLO.mult is a NumPy loop, interfaces/linearoperators.py:582-595): h_info[0] = complex points
  * per thread of the one-real-window kernel (32), h_info[1] = list format of the most recently used
  * tile plan (1 plain, 2 run-coded lists cut by time, 3 run-coded lists cut by address ("inverse"),
- * 0 = no lists built yet), h_info[2] = window length in samples, h_info[3] = windows of that plan that
- * reach into two spans of its [span][tile][time] order (plain lists, a small launch of their own);
+ * 0 = no lists built yet), h_info[2] = window length in samples, h_info[3] = 0 (was: windows across
+ * two spans of the span order removed in round 5);
  * *h_bytes_per_sample = HBM bytes per TOD sample the kernel is built to move (lists + gathered windows +
  * results).  Environment switches,
  * read ONCE when the operator is created: CM2_OS_LISTS = auto (default: rc below 768 pixel tiles,

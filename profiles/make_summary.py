@@ -29,8 +29,31 @@ HOT = ["k_P_tiles", "k_overlap_save", "k_os_real", "k_Pt_tiles_fixed", "k_Pt_til
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
     bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
-    if not bench.get("commit"):                      # the GPU box has no .git: the caller knows
-        bench["commit"] = os.environ.get("CM2_PROFILE_COMMIT")
+    # Which sources did the profiled kernels come from?  Every bench line carries the hash of the kernel sources
+    # its library was linked from (cosmomap2_amd/build.py `source_hash`).  The summary is REFUSED unless the
+    # un-profiled line and the three profiled processes (kt / fetch / write logs) all ran one build, that build
+    # is the working tree's, and the working tree's kernel sources are committed -- then, and only then, `commit`
+    # is a true statement about the counters.
+    import subprocess
+    sys.path.insert(0, os.path.dirname(here))
+    from cosmomap2_amd.build import source_hash
+    want = source_hash()
+    seen = {"bench_default.json": (bench.get("library") or {}).get("sources_sha16_at_build")}
+    for log in ("kt.log", "fetch.log", "write.log"):
+        lines = [l for l in open(os.path.join(src, log)) if l.startswith('{"metric"')]
+        seen[log] = (json.loads(lines[-1]).get("library") or {}).get("sources_sha16_at_build") if lines else None
+    if any(v != want for v in seen.values()):
+        sys.exit("make_summary: REFUSED -- the runs under %s were made with other kernel sources than the working "
+                 "tree's (%s): %r" % (src, want, seen))
+    dirty = subprocess.run(["git", "status", "--porcelain", "--", "cosmomap2_amd/csrc", "include"],
+                           cwd=os.path.dirname(here), capture_output=True, text=True).stdout.strip()
+    if dirty:
+        sys.exit("make_summary: REFUSED -- uncommitted kernel sources:\n" + dirty)
+    commit = subprocess.run(["git", "log", "-1", "--format=%h", "--", "cosmomap2_amd/csrc", "include"],
+                            cwd=os.path.dirname(here), capture_output=True, text=True).stdout.strip()
+    bench["commit"] = commit
+    bench["library_sources_sha16"] = want
+    os.environ["CM2_PROFILE_COMMIT"] = commit
     json.dump(bench, open(os.path.join(here, tag + "_bench_c4.json"), "w"), indent=1)
     newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
     ks = newest(os.path.join(src, "kt", "**", "*_kernel_stats.csv"))
@@ -77,6 +100,7 @@ def main(src, tag):
                             "algorithmic_bytes": alg[h]}
     out = {"workload": bench["config"]["workload"], "nt_per_gpu": nt, "kernels": table,
            "commit": os.environ.get("CM2_PROFILE_COMMIT") or bench.get("commit"),
+           "library_sources_sha16": want,
            "note": "hbm_traffic_bytes = 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE "
                    "correction); separate --pmc passes"}
     json.dump(out, open(os.path.join(here, tag + "_pmc_c4.json"), "w"), indent=1)

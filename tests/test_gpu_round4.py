@@ -173,121 +173,6 @@ def test_release_cached_memory_returns_everything(cm):
 
 
 # ---------------------------------------------------------------------------------------------
-# SPANS: the tile order cut in time, [span][tile][time] (cm2_tiles.h).  Plans below 2^22 samples keep
-# one span by default, so the whole tile-path suite above this size runs on the global order; here the
-# same checks -- they are the functions of tests/test_gpu_parity.py / test_gpu_round2.py themselves --
-# run with CM2_TILE_SPAN forcing spans of 2 and 8 chunks of 8192 samples: P bit-exact, the fixed-order
-# P^T bit-exact against the oracle's serial loop (a tile's slices are its segments, span after span =
-# in time), tile ranges, the atomic form, N^-1 on the tile order with every list format (windows
-# inside one span: lists written from that span's segment table; windows across two spans: plain
-# lists from the segmented sort, a launch of their own), PCG iteration counts equal to the oracle's.
-# ---------------------------------------------------------------------------------------------
-def _spans_are_on(cm, span):
-    P, T = _plan(cm, 99, nt=200000, npix=3000, tp=256)
-    assert T.nspans == -(-200000 // span) and T.span_samples == span, (T.nspans, T.span_samples)
-
-
-@pytest.mark.parametrize("span", [16384, 65536])
-@pytest.mark.parametrize("pol,angles", [(3, "half"), (3, "full"), (1, "half"), (2, "full")])
-@pytest.mark.parametrize("nt,npix,tp", [(300000, 5000, 2048), (400000, 70000, 1024), (40000, 20, 64)])
-def test_tiled_pointing_on_spans(cm, oracle, monkeypatch, span, pol, angles, nt, npix, tp):
-    import test_gpu_parity as TP
-    monkeypatch.setenv("CM2_TILE_SPAN", str(span))
-    _spans_are_on(cm, span)
-    TP.test_tiled_pointing(cm, oracle, monkeypatch, pol, nt, npix, tp, angles)
-
-
-@pytest.mark.parametrize("span", [16384, 32768])
-@pytest.mark.parametrize("lists", ["plain", "rc", "inv"])
-@pytest.mark.parametrize("flat", [False, True])
-@pytest.mark.parametrize("tp,lam,npix", [(1024, 300, 70000), (2048, 2049, 70000), (64, 40, 200000)])
-def test_overlap_save_on_spans(cm, oracle, monkeypatch, span, lists, flat, tp, lam, npix):
-    import test_gpu_parity as TP
-    monkeypatch.setenv("CM2_TILE_SPAN", str(span))
-    TP.test_overlap_save_kernel_variants(cm, oracle, monkeypatch, lists, flat, tp, lam, npix)
-
-
-@pytest.mark.parametrize("lists,tp", [("rc", 1024), ("plain", 1024), ("rc", 256)])      # (274 tiles: the sorted
-# lists of a plan with spans may have two runs per tile, and stay run-coded up to 1024 tiles)
-def test_overlap_save_lists_on_spans_direct_equal_sorted(cm, oracle, monkeypatch, lists, tp):
-    import test_gpu_parity as TP
-    monkeypatch.setenv("CM2_TILE_SPAN", "16384")
-    TP.test_overlap_save_lists_written_directly_equal_the_sorted_ones(cm, oracle, monkeypatch, lists, tp)
-
-
-def test_windows_across_spans_get_their_own_lists(cm):
-    """With spans of 16384 samples nearly every window of 16384 samples reaches into two spans; with
-    spans of 2^17 one window in ten does: both sets are exercised, and the operator is the one of
-    the global order to rounding."""
-    from cosmomap2_amd import _hip, device as D
-    import os
-    t = cm.torch
-    nt = 600000
-    N = _noise(cm, nt, nblk=3, lam=700)
-    tod = D.f64(np.random.default_rng(3).standard_normal(nt))
-    for span, lo, hi in ((0, 0, 0), (16384, 30, 60), (131072, 3, 12)):
-        os.environ["CM2_TILE_SPAN"] = str(span)
-        try:
-            P, T = _plan(cm, 7, nt=nt, npix=20000, tp=512)
-        finally:
-            del os.environ["CM2_TILE_SPAN"]
-        a, b, back = D.empty(T.nvalid), D.empty(T.nvalid), D.empty(nt)
-        _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(tod), D.ptr(a), D.stream())
-        _hip.call("cm2_noise_apply_tiles", N._noise.h, T.h, D.ptr(a), D.ptr(b), D.stream())
-        _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(b), D.ptr(back), D.stream())
-        # (flagged samples are not part of the tile order: they enter N^-1 as zeros and come back as zeros)
-        pix_ok = (P._d_pix >= 0).to(t.float64)
-        want = N * (tod * pix_ok)
-        err = float(((back - want) * pix_ok).norm() / want.norm())
-        info = N.tile_kernel_info()
-        assert lo <= info["os_windows_across_spans"] <= hi, info
-        assert err < 1e-12, (span, err)
-
-
-@pytest.mark.parametrize("span", [16384, 65536])
-def test_pcg_counts_and_hot_pixels_on_spans(cm, oracle, monkeypatch, span):
-    import test_gpu_parity as TP
-    import test_gpu_round2 as T2
-    monkeypatch.setenv("CM2_TILE_SPAN", str(span))
-    TP.test_tiled_path_pcg_iteration_count_equals_oracle(cm, oracle, monkeypatch, 3, 40, "half", 0.03)
-    TP.test_tiled_path_pcg_iteration_count_equals_oracle(cm, oracle, monkeypatch, 3, 40, "full", 0.0)
-    TP.test_hot_pixel_is_summed_in_fixed_chunks(cm, oracle)
-    T2.test_uneven_hit_map_gets_balanced_tiles_and_the_same_bits(cm, oracle, monkeypatch)
-    TP.test_filter_chain_on_tile_order(cm)
-
-
-def test_span_auto_follows_the_measured_lists(cm, oracle, monkeypatch):
-    """CM2_TILE_SPAN=auto: the span is chosen for segments of ~0.9 x the longest slice, and shortened
-    when the fixed-order lists of such segments would need more groups than the workgroup has
-    threads (a dense hit map: 29 hits per pixel and segment here).  Whatever the span, P and the
-    fixed-order P^T give the oracle's bits."""
-    from types import SimpleNamespace
-    from cosmomap2_amd import _hip, device as D
-    from cosmomap2_amd.interfaces import linearoperators as L
-    monkeypatch.setenv("CM2_TILE_SPAN", "auto")
-    monkeypatch.setenv("CM2_TILE_ANGLES", "full")
-    rng = np.random.default_rng(17)
-    nt, npix, pol, tp = 3_000_000, 2000, 3, 64
-    pairs = rng.integers(0, npix, nt).astype(np.int32)
-    pairs[rng.random(nt) < 0.02] = -1
-    phi = 0.3 + 0.0785 * np.arange(nt)
-    c, s = np.cos(2 * phi), np.sin(2 * phi)
-    P = cm.I.SparseLO(npix, nt, pairs, pol=pol, angle_processed=SimpleNamespace(cos=c, sin=s))
-    T = L._sparse_tiles(P, tile_pixels=tp, slice_samples=4096)
-    assert T.nspans > 4
-    seg = T.span_samples / float(T.ntiles)
-    assert seg < 0.8 * 2048, (T.span_samples, T.ntiles)            # shortened below the 0.9 x 2048 first guess
-    x = rng.standard_normal(pol * npix)
-    v = rng.standard_normal(nt)
-    d_tb, tod, v_tb, out = D.empty(T.nvalid), D.empty(nt), D.empty(T.nvalid), D.empty(pol * npix)
-    _hip.call("cm2_P_tiles_apply", T.h, D.ptr(D.f64(x)), D.ptr(d_tb), D.stream())
-    _hip.call("cm2_tod_tiles_to_time", T.h, D.ptr(d_tb), D.ptr(tod), D.stream())
-    np.testing.assert_array_equal(tod.cpu().numpy(), oracle.sparse_mult(pol, pairs, c, s, x))
-    _hip.call("cm2_tod_time_to_tiles", T.h, D.ptr(D.f64(v)), D.ptr(v_tb), D.stream())
-    _hip.call("cm2_Pt_tiles_apply", T.h, D.ptr(v_tb), D.ptr(out), D.stream())
-    np.testing.assert_array_equal(out.cpu().numpy(), oracle.sparse_rmult(pol, npix, pairs, c, s, v))
-
-
 @pytest.mark.parametrize("parts,pol,angles,hot_pixel", [("6000", 3, "full", False), ("20000", 3, "half", False),
                                                       ("6000", 1, "half", False), ("9000", 2, "full", False),
                                                       ("6000", 3, "full", True), (None, 3, "half", False)])
