@@ -149,6 +149,30 @@ def measure_traffic(kernel_regex, child_args, timeout=420):
     return 2.0 * got["FETCH_SIZE"]["bytes"] + got["WRITE_SIZE"]["bytes"], got
 
 
+class Heartbeat(object):
+    """A line on stderr every `period` seconds while a long host-side leg runs (the oracle's PCG at 1e9 samples takes
+    minutes: a GPU box takes seven silent minutes for a hang and ends the run)."""
+
+    def __init__(self, what, period=60.0):
+        import threading
+        self.what, self.period, self.t0 = what, period, time.perf_counter()
+        self.stop = threading.Event()
+        self.th = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        while not self.stop.wait(self.period):
+            print("bench.py: %s, %.0f s so far" % (self.what, time.perf_counter() - self.t0), file=sys.stderr, flush=True)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join()
+        return False
+
+
 def under_profiler():
     keys = " ".join(k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")))
     return bool(keys) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -283,6 +307,31 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, before torch is imported
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # roofline.traffic: the two rocprofv3 --pmc passes are CHILD processes of this script, started HERE -- before
+    # this process imports torch or touches the GPU (a process that has initialised the GPU must not be the ancestor
+    # of an exec chain on this pool: rocprofv3 is a launcher that re-execs its target).  The dominant kernel of a
+    # configuration is known from its noise model; the result is matched against the measured one below.
+    traffic_pre = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_traffic or args.no_cpu)
+            and not under_profiler()):
+        pre_regex = "k_os_real" if (CONFIGS[args.config]["lam"] and args.toeplitz == "fused") else (
+            "k_PtNP_sell" if not CONFIGS[args.config]["lam"] else None)
+        child = ["--config", args.config, "--scaling", args.scaling, "--gpus", "1", "--steps", "3", "--warmup", "1",
+                 "--toeplitz", args.toeplitz, "--no-cpu", "--no-filters", "--no-raster", "--no-pcg", "--no-parity",
+                 "--no-traffic", "--deflation", "0"]
+        if args.nt:
+            child += ["--nt", str(args.nt)]
+        if args.lam:
+            child += ["--lam", str(args.lam)]
+        if pre_regex:
+            t_tr = time.perf_counter()
+            try:
+                traffic, passes = measure_traffic(pre_regex, child)
+                traffic_pre = {"regex": pre_regex, "traffic": traffic, "passes": passes,
+                               "seconds": round(time.perf_counter() - t_tr, 1)}
+            except Exception as exc:                          # noqa: BLE001  (auxiliary: falls back to the copy)
+                traffic_pre = {"regex": pre_regex, "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     import torch
     import torch.distributed as dist
@@ -651,28 +700,24 @@ def main():
     # rocprofv3 passes of their own, so the figure is NOT measured in this run: it is copied from
     # the newest committed summary of this command (profiles/make_summary.py), only when workload
     # and size are the same, and labelled with that profile's file and commit.
-    dom_regex = next((k for k in ("k_os_real", "k_PtNP_sell", "k_P_tiles", "k_Pt_tiles_fixed") if k in dom), None)
-    if (rank == 0 and world == 1 and dom_regex and not (args.no_traffic or args.no_cpu) and not under_profiler()):
-        # measured by this run: two rocprofv3 --pmc children of the same workload (FETCH_SIZE, WRITE_SIZE)
-        child = ["--config", args.config, "--scaling", args.scaling, "--gpus", "1", "--steps", "3", "--warmup", "1",
-                 "--toeplitz", args.toeplitz, "--no-cpu", "--no-filters", "--no-raster", "--no-pcg", "--no-parity",
-                 "--no-traffic", "--deflation", "0"]
-        if args.nt:
-            child += ["--nt", str(args.nt)]
-        if args.lam:
-            child += ["--lam", str(args.lam)]
-        try:
-            t_tr = time.perf_counter()
-            traffic, passes = measure_traffic(dom_regex, child)
-            roofline.update({"traffic": traffic, "traffic_measured_in_run": True,
+    if traffic_pre is not None:
+        # measured by this run (the two rocprofv3 --pmc children at the top of main), if they profiled the kernel
+        # that turned out to be the dominant one
+        if "error" in traffic_pre:
+            roofline["traffic_measurement_error"] = traffic_pre["error"]
+        elif traffic_pre["regex"] in dom:
+            passes = traffic_pre["passes"]
+            roofline.update({"traffic": traffic_pre["traffic"], "traffic_measured_in_run": True,
                              "traffic_passes": {"FETCH_SIZE_bytes": passes["FETCH_SIZE"]["bytes"],
                                                 "WRITE_SIZE_bytes": passes["WRITE_SIZE"]["bytes"],
                                                 "launches_per_pass": passes["FETCH_SIZE"]["launches"],
                                                 "formula": "2 * FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts "
                                                            "128-byte requests at 64 bytes)",
-                                                "seconds": round(time.perf_counter() - t_tr, 1)}})
-        except Exception as exc:                              # noqa: BLE001  (auxiliary: falls back to the copy)
-            roofline["traffic_measurement_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+                                                "how": "two child processes of bench.py under rocprofv3 --pmc, started "
+                                                       "before this process touched the GPU",
+                                                "seconds": traffic_pre["seconds"]}})
+        else:
+            roofline["traffic_measurement_error"] = "profiled %s, dominant kernel is %s" % (traffic_pre["regex"], dom)
     if roofline["traffic"] is None:
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_c4.json"))
@@ -1123,6 +1168,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu:
         from oracle import oracle as orc
         tq = time.perf_counter()
+        beat = Heartbeat("parity_full_size: the oracle on the host")
+        beat.__enter__()
         inp2 = synth_inputs(torch, dev, npix, nt, nb, lam, rank)
         pix_h, phi_h, d_h = inp2["pix"].cpu().numpy(), inp2["phi"].cpu().numpy(), inp2["d"].cpu().numpy()
         bands_h, diag_h = inp2["bands"], inp2["diag"]
@@ -1232,6 +1279,7 @@ def main():
                 parity["pcg"] = "skipped (host solve would take %.0f s; --parity-host-seconds %g)" % (
                     t_mv * ((pcg or {}).get("iters", 10) + 3), budget)
         parity["seconds"] = round(time.perf_counter() - tq, 1)
+        beat.__exit__()
         del H, pix_h, d_h
 
     # device memory at the end of the run: what the library's objects hold, what it keeps cached, and

@@ -282,6 +282,7 @@ typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 template <int E>
 __device__ __forceinline__ void q_request(const uint16_t *q, int t, uint32_t (&qq)[E / 2])
 {
+    asm volatile("" : "+v"(t));               // (the lane's list offset is recomputed per list, not kept: see tab_dma)
     const v2u_t *p = reinterpret_cast<const v2u_t *>(q) + (E / 4) * 64 * (t >> 6) + (t & 63);
 #pragma unroll
     for (int i = 0; i < E / 4; ++i) {
@@ -318,6 +319,9 @@ __device__ __forceinline__ void tab_dma(const uint32_t *gtab, uint32_t *tab_lds,
     //  16 SGPRs spilled to VGPR lanes in the default instantiation)
     int wave = wave_;
     asm volatile("" : "+s"(wave));
+    // (and the thread index through a "+v": the lane's 64-bit table offset is recomputed at every call -- three
+    //  VALU instructions -- instead of being kept, or spilled, from the window lists to the result lists)
+    asm volatile("" : "+v"(t));
     const uint32_t *g = gtab + 64 * wave + (t & 63);
 #pragma unroll
     for (int i = 0; i < kTabRows; ++i)
@@ -392,85 +396,130 @@ __device__ __forceinline__ void idecode(uint32_t fw, const uint32_t *__restrict_
     }
 }
 
-// ---- the partner exchange and the spectrum product ------------------------------------------------
+// ---- the partner exchange and the spectrum product: pairing by HALF PLANES (round 5) ------------------
 // Z'[k] = alpha Z[k] + i beta conj(Z[N-k]):  re' = alpha re + beta pim,  im' = alpha im + beta pre.
-// Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3; its
-// partner is published at P3 index A_e(t) - m of the padded plane (see the header comment).
-// (alpha, beta) reach the registers in batches of BA bins, one batch after the other (the table
-// loads are L2 hits that take a microsecond on a chip busy with gathers).
-template <int PT> struct PairBatch { static constexpr int BA = 4; };
-
-template <int PT, int BA>
-__device__ __forceinline__ void ab_request(const double2 *ab, int m0, double2 (&c)[BA])
+// Frequency (e, d3) of a thread sits in register slot 16 e + brev16(d3), P3 index m = 16 e + d3.
+// Rounds 3-4 published the real plane, read the partner's 32 real parts into registers (64 VGPRs), published the
+// imaginary plane and walked the bins with ONE batch of four (alpha, beta) pairs in flight: eight dependent table
+// loads a window, seven of them exposed (19 k of the window's 109 k clocks).  Here a thread publishes only its
+// UPPER slots (P3 index 16..31), both parts, in the one plane buffer -- real part at 33 t + 16 + j, imaginary
+// part at 33 t + j -- and the holder of the LOWER slot of a bin pair (k, N - k) computes BOTH outputs: it has
+// Z[k] in registers, reads Z[N-k] from the partner's published slots, writes Z'[N-k] back to the same two words
+// (no other thread touches them), and the partner reads its new upper slots back behind one barrier.  No partner
+// array in registers: the coefficients travel in TWO batches of eight bin pairs (16 double2 = the partner
+// array's 64 registers), the first requested in front of the publication: one exposed round trip instead of
+// seven; three barriers instead of four; the same LDS reads, 32 more LDS writes per thread.  (All 32 double2 at
+// once, into the upper slots' registers that are dead between publication and read-back, was tried: the
+// register allocator spills 100 VGPRs.)  Five same-box alternations of bench.py: N^-1 0.673 against 0.696 ms
+// (every pair), step 1.378 against 1.390 (four of five pairs); profiles/r05_os_half_plane_pairing_ab.jsonl.
+//   t >= 8: (t, m < 16) pairs with (263 - t, 31 - m): lower <-> upper.
+//   t <  8 (frequency digit d1 = 0: 8 threads of wave 0): lower slots pair with LOWER slots (thread 8 - t, slot
+//   15 - m; thread 0 with itself, slot 16 - m; bins 0 and N/2 with themselves) and upper with upper (thread
+//   7 - t, slot 47 - m).  They also publish their lower slots (xbuf: 2 x 8 x 16 doubles behind the run tables),
+//   compute their own 32 bins from the published ORIGINALS (nobody writes to their slots: the partners of
+//   threads >= 8 are threads 8..255) with the same two batches of loads -- their "partner" coefficients are their
+//   own upper bins' -- and skip the read-back.
+template <int PT, int BP>                   // BP: bin pairs per coefficient batch (8; 4 where registers are shortest)
+__device__ __forceinline__ void partner_filter_half(double (&zr)[PT], double (&zi)[PT], double *__restrict__ buf,
+                                                    double *__restrict__ xbuf, int t,
+                                                    const double2 *__restrict__ ab_own,
+                                                    const double2 *__restrict__ ab_blk)
 {
-    // the OFFSET passes through an empty asm statement: the loads have no other dependency and
-    // would otherwise all be hoisted to one place (4 VGPRs per bin).  The pointer itself must keep its
-    // provenance: a laundered pointer is loaded from with FLAT instructions, and one pending flat load
-    // turns every later wait into s_waitcnt vmcnt(0) lgkmcnt(0) (flat loads may return out of order)
-    int o = m0 * kT;
-    asm volatile("" : "+v"(o));
+    static_assert(PT == 32, "half-plane pairing: 32 points per thread");
+    constexpr int H = PT / 2;
+    double *__restrict__ wp = buf + reg_base<PT, 3>(t);                  // 33 t
+    const bool special = t < 8;
+    // the coefficients of bin 31 - m: the partner's (general case) or this thread's own upper bin (special case)
+    // -- ONE load sequence serves both cases
+    const double2 *__restrict__ ab_prt = ab_blk + (special ? t : 263 - t);
+    double2 ca[BP], cb[BP];
+    auto request = [&](int m0) {
+        int o = m0 * kT;
+        asm volatile("" : "+v"(o));           // (an offset, not a pointer: see ab_request)
 #pragma unroll
-    for (int i = 0; i < BA; ++i) c[i] = ab[o + i * kT];
-}
-
-template <int PT, int BA>
-__device__ __forceinline__ void partner_filter(double (&zr)[PT], double (&zi)[PT], double *__restrict__ buf,
-                                               int t, const double2 *__restrict__ ab, double2 (&c)[BA])
-{
-    double *__restrict__ wp = buf + reg_base<PT, 3>(t);
-    int A0, A1;
-    if (PT == 32) {
-        const int gen = 33 * (263 - t) + 31;
-        A0 = t >= 8 ? gen : (t == 0 ? 16 : 33 * (8 - t) + 15);
-        A1 = t >= 8 ? gen : 33 * (7 - t) + 47;
-    } else {
-        const int tp = t >= 16 ? 271 - t : 16 - t;
-        A0 = t == 0 ? 16 : 16 * tp + (tp >> 1) + 15;
-        A1 = A0;
-    }
-    const double *__restrict__ r0 = buf + A0;
-    const double *__restrict__ r1 = buf + A1;
-    const bool self0 = (t == 0);            // bin k = 0 (and N/2 through the formula) pairs with itself
-    // the first batch of (alpha, beta) is requested here: it arrives behind the three exchanges below
-    // instead of costing the first of the eight dependent L2 round trips of the loop
-    ab_request<PT, BA>(ab, 0, c);
+        for (int i = 0; i < BP; ++i) {
+            ca[i] = ab_own[o + i * kT];
+            cb[i] = ab_prt[(PT - 1) * kT - o - i * kT];
+        }
+    };
+    request(0);                               // arrives behind the publication and its barrier
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < PT; ++m) wp[m] = zr[reg_slot<16>(m)];
-    __syncthreads();
-    double pr[PT];
+    for (int j = 0; j < H; ++j) {
+        wp[H + j] = zr[reg_slot<16>(H + j)];
+        wp[j] = zi[reg_slot<16>(H + j)];
+    }
+    if (special) {
 #pragma unroll
-    for (int m = 0; m < PT; ++m) {
-        const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
-        pr[m] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
+        for (int j = 0; j < H; ++j) {
+            xbuf[t * H + j] = zr[reg_slot<16>(j)];
+            xbuf[(8 + t) * H + j] = zi[reg_slot<16>(j)];
+        }
     }
     __syncthreads();
+    if (!special) {
+        double *__restrict__ pp = buf + 33 * (263 - t) + 31;             // partner slot 31 - m: re at pp[-m], im at pp[-16 - m]
 #pragma unroll
-    for (int m = 0; m < PT; ++m) wp[m] = zi[reg_slot<16>(m)];
-    __syncthreads();
+        for (int m0 = 0; m0 < H; m0 += BP) {
+            if (m0 > 0) request(m0);
 #pragma unroll
-    for (int m0 = 0; m0 < PT; m0 += BA) {
-        if (m0 > 0) ab_request<PT, BA>(ab, m0, c);
+            for (int i0 = 0; i0 < BP; i0 += 4) {
+                double pre[4], pim[4];
 #pragma unroll
-        for (int i0 = 0; i0 < BA; i0 += 4) {
-            double pim[4];
+                for (int i = 0; i < 4; ++i) {
+                    pre[i] = pp[-(m0 + i0 + i)];
+                    pim[i] = pp[-H - (m0 + i0 + i)];
+                }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i0 + i;
-                const double *__restrict__ rp = (m < 16 ? r0 : r1) - m;
-                pim[i] = (m == 0) ? (self0 ? buf[0] : rp[0]) : rp[0];
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + i0 + i, sl = reg_slot<16>(m);
+                    const double a = ca[i0 + i].x, b = ca[i0 + i].y, ap = cb[i0 + i].x, bp = cb[i0 + i].y;
+                    const double nr = a * zr[sl] + b * pim[i];
+                    const double ni = a * zi[sl] + b * pre[i];
+                    const double qr = ap * pre[i] + bp * zi[sl];         // Z'[N-k] = alpha' Z[N-k] + i beta' conj(Z[k])
+                    const double qi = ap * pim[i] + bp * zr[sl];
+                    zr[sl] = nr;
+                    zi[sl] = ni;
+                    pp[-m] = qr;
+                    pp[-H - m] = qi;
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i0 + i;
-                const int s = reg_slot<16>(m);
-                const double nr = c[i0 + i].x * zr[s] + c[i0 + i].y * pim[i];
-                const double ni = c[i0 + i].x * zi[s] + c[i0 + i].y * pr[m];
-                zr[s] = nr;
-                zi[s] = ni;
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // the eight threads whose partner bins sit in the same half: every own bin from published originals
+        // (lower bin m with ca, upper bin 31 - m with cb: the same two batches of loads as the other threads)
+        const int tl = t == 0 ? 0 : 8 - t;                               // lower slots' partner thread
+        const double *__restrict__ up = buf + 33 * (7 - t) + 47;         // upper: re at up[-m], im at up[-m - 16]
+#pragma unroll
+        for (int m0 = 0; m0 < H; m0 += BP) {
+            if (m0 > 0) request(m0);
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int m = m0 + i, sl = reg_slot<16>(m);
+                const int ms = t == 0 ? (m == 0 ? 0 : H - m) : H - 1 - m;
+                const double pre_ = xbuf[tl * H + ms], pim_ = xbuf[(8 + tl) * H + ms];
+                const double nr = ca[i].x * zr[sl] + ca[i].y * pim_;
+                const double ni = ca[i].x * zi[sl] + ca[i].y * pre_;
+                zr[sl] = nr;
+                zi[sl] = ni;
+                const int mu = PT - 1 - m, su = reg_slot<16>(mu);       // the upper bin 31 - m
+                const double ure = up[-mu], uim = up[-mu - H];
+                // (its own upper originals are read back from the slots it published, so that the upper registers
+                //  are dead from the publication on for every lane of the wave: liveness is per register)
+                zr[su] = cb[i].x * wp[mu] + cb[i].y * uim;
+                zi[su] = cb[i].x * wp[mu - H] + cb[i].y * ure;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (!special) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            zr[reg_slot<16>(H + j)] = wp[H + j];
+            zi[reg_slot<16>(H + j)] = wp[j];
+        }
     }
     __syncthreads();
 }
@@ -704,14 +753,15 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     if constexpr (PT == 32) reg_fwd<PT, 16, 16>(zr, zi, w_b);
     reg_exchange<PT, 2, 3, 16>(zr, buf, t);
     reg_exchange<PT, 2, 3, 16>(zi, buf, t);
-    constexpr int BA = PairBatch<PT>::BA;
     const double2 *ab = AB + (int64_t)wd.blk * N + t;
-    double2 cab[BA];
     dft_sub<PT, 16, 0>(zr, zi);
     if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi);
     OS_STAMP(2);
     // ---- pairing with bin N-k and the spectrum product ----
-    partner_filter<PT, BA>(zr, zi, buf, t, ab, cab);
+    // (plain lists with flat addressing -- more than 2048 pixel tiles AND buffers of 4 GB and more -- hold 32
+    //  address words beside the transform: batches of four bin pairs there, or three VGPRs spill)
+    partner_filter_half<PT, (MODE == 1 && !BUF) ? 4 : 8>(zr, zi, buf, reinterpret_cast<double *>(tab_lds + 2 * rmax),
+                                                         t, ab, AB + (int64_t)wd.blk * N);
     OS_STAMP(3);
     // ---- inverse: radix 16 (decimation in time on the bit-reversed data), radix 16, radix PT ----
     dit_sub<PT, 16, 0>(zi, zr);
@@ -1529,7 +1579,9 @@ static int os_launch_t(const FusedOS *f, const WinDesc *d_wins, int64_t nwin, co
 {
     using G = G32;
     const int rmax = ls ? ls->rmax : 0;
-    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)rmax : 0);
+    // (exchange plane, the two run tables of a list pair, 2 KB for the lower slots of the eight self-paired threads
+    //  of the half-plane pairing)
+    const size_t lds = sizeof(double) * (size_t)G::LDSD + (MODE >= 2 ? sizeof(uint32_t) * 2 * (size_t)rmax : 0) + 2048;
     static size_t granted[64] = {0};
     CM2_HIP(ensure_dynamic_lds((const void *)k_os_real<kPT, MODE, BUF>, lds, granted));
     if (nwin == 0) return 0;
