@@ -183,9 +183,15 @@ def device_state():
     clocks): recorded with every line because the SAME commit measured 11.3 ms and 8.1 ms for N^-1 at C5 whole on
     two boxes of the same pool (profiles/r05_c5_whole.md) -- a property of the box, not of the run."""
     out = {}
+    if under_profiler():
+        # (rocm-smi is a `#!/usr/bin/env python3` script: under rocprofv3 the profiler's preloaded library initialises
+        #  the GPU in every process of that exec chain, and a process that has initialised the GPU must not exec)
+        return {"skipped": "inside a profiled run"}
     try:
-        res = subprocess.run(["rocm-smi", "--showcomputepartition", "--showmemorypartition", "--showmeminfo", "vram",
-                              "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        import shutil
+        smi = os.path.realpath(shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi")
+        res = subprocess.run([sys.executable, smi, "--showcomputepartition", "--showmemorypartition", "--showmeminfo",
+                              "vram", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
         cards = json.loads(res.stdout)
         vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
         out["cards_listed"] = len([k for k in cards if k.startswith("card")])

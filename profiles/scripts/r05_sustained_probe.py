@@ -90,7 +90,8 @@ def sample_clocks():
     while not stop.is_set():
         t = time.perf_counter()
         try:
-            o = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            o = subprocess.run([sys.executable, os.path.realpath("/opt/rocm/bin/rocm-smi"), "--showclocks", "--json"],
+                               capture_output=True, text=True, timeout=5).stdout
             d = json.loads(o)
             card = next(iter(d.values()))
             clocks.append((round(t - t_start, 2), {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower()}))
