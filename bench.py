@@ -1250,7 +1250,7 @@ def main():
                             # the reference's OWN Arnoldi recurrence (modified Gram-Schmidt on Mbd*A, Mbd*b,
                             # src/test_M2_precond_onto_real_data.py:42, deflationlib.py:17-113) on the host for
                             # the same number of steps, Ritz pairs of its Hessenberg matrix (build_hess,
-                            # la.eigh as :43-46 does -- the symmetric part), smallest r: the angles between
+                            # la.eigh(H) as :43-46 does: the lower triangle), smallest r: the angles between
                             # that space and the GPU's Z say how far the two Krylov recurrences agree on the
                             # deflation space (same Krylov space; Euclidean against M^-1-orthogonal Ritz
                             # projection, so only converged Ritz vectors coincide)
@@ -1259,7 +1259,7 @@ def main():
                             vs, hs, m_o = orc.arnoldi(lambda v: H.M(H.A(v)), H.M(bo), np.zeros(bo.shape[0]),
                                                       tol=0.0, inner_m=m_st, exhausted="return")
                             Hm = orc.build_hess(hs, m_o)
-                            th_o, U_o = np.linalg.eigh(0.5 * (Hm + Hm.T))
+                            th_o, U_o = np.linalg.eigh(Hm)          # (as the reference: la.eigh(H) reads the lower triangle)
                             V = np.column_stack(vs[:m_o])
                             Zo = V.dot(U_o[:, np.argsort(th_o)[:r]])
                             Qg, _ = np.linalg.qr(Zh)
