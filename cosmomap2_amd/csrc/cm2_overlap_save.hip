@@ -434,8 +434,12 @@ __device__ __forceinline__ void partner_filter_half(double (&zr)[PT], double (&z
     const double2 *__restrict__ ab_prt = ab_blk + (special ? t : 263 - t);
     double2 ca[BP], cb[BP];
     auto request = [&](int m0) {
+        // The OFFSET passes through an empty asm statement: the loads have no other dependency and would otherwise
+        // all be hoisted to one place.  The pointer itself must keep its provenance: a laundered pointer is loaded
+        // from with FLAT instructions, and one pending flat load turns every later wait into s_waitcnt vmcnt(0)
+        // lgkmcnt(0) (flat loads may return out of order).
         int o = m0 * kT;
-        asm volatile("" : "+v"(o));           // (an offset, not a pointer: see ab_request)
+        asm volatile("" : "+v"(o));
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             ca[i] = ab_own[o + i * kT];
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         // ---- inverse result list: rounds of RLEN slots of the result window's address-sorted order ----
         constexpr int ER3 = G::RLEN / kT, NP = PT - 8;   // slots per thread and round; points with results
         // (the list number passes through an empty asm statement -- an offset, not a pointer, see
-        // ab_request: the requests below have no other dependency and would be hoisted to the top)
+        // partner_filter_half: the requests below have no other dependency and would be hoisted to the top)
         int l1 = 1;
         asm volatile("" : "+s"(l1));
         const IListHdr *h1 = ihdrs + (int64_t)win * 2 + l1;
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     auto request_results = [&](int j, auto &qq, auto &kq, uint32_t &nv, int &wb, uint32_t *tdst) {
         if constexpr (MODE != 0) {
             // (the list number passes through an empty asm statement: an offset, not a pointer, see
-            // ab_request; the list's addresses stay wave-uniform and its header words scalar loads)
+            // partner_filter_half; the list's addresses stay wave-uniform and its header words scalar loads)
             int lj = 2 + j;
             asm volatile("" : "+s"(lj));
             const ListArgs ls = list_args(lj);
