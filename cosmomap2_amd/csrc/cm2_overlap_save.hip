@@ -703,6 +703,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         }
         if constexpr (MODE == 2) {
             __syncthreads();
+            OS_STAMP(6);                             // (diagnostic build: lists and run tables have arrived)
             rc_decode<PT>(qa, tab_lds, wba, nva, t, ka);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PT; ++u) buf[q_word(qa, u) & 0x7FFFu] = keep(ka[u], va[u]);
+        OS_STAMP(7);                                 // (diagnostic build: the first half's gathers have arrived)
         __syncthreads();
         {
             const double2 *__restrict__ sp = reinterpret_cast<const double2 *>(buf) + t;
