@@ -1630,7 +1630,18 @@ int64_t fx_designed_bytes(const cm2_tiles *t)
 // often a pixel is hit twice inside a slice, so it is measured: a trial plan with S = 1536 gives
 // the groups per slice, S is then set for ~0.92 x 512 groups and the plan rebuilt
 // (CM2_PT_SLICE = samples fixes S).
+static int fx_plan_build(const cm2_tiles *tc, hipStream_t st, bool *use);
+
 int fx_plan(const cm2_tiles *tc, hipStream_t st, bool *use)
+{
+    const int rc = fx_plan_build(tc, st, use);
+    // running out of device memory is transient: the failure is not remembered, so that the call may be made
+    // again after the host has freed memory (cosmomap2_amd/_hip.py does that once; a build starts from scratch)
+    if (rc == CM2_ERR_OUT_OF_MEMORY) const_cast<cm2_tiles *>(tc)->fx_failed = 0;
+    return rc;
+}
+
+static int fx_plan_build(const cm2_tiles *tc, hipStream_t st, bool *use)
 {
     cm2_tiles *t = const_cast<cm2_tiles *>(tc);
     *use = false;
