@@ -175,7 +175,9 @@ def test_release_cached_memory_returns_everything(cm):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("parts,pol,angles,hot_pixel", [("6000", 3, "full", False), ("20000", 3, "half", False),
                                                       ("6000", 1, "half", False), ("9000", 2, "full", False),
-                                                      ("6000", 3, "full", True), (None, 3, "half", False)])
+                                                      ("6000", 3, "full", True), (None, 3, "half", False),
+                                                      ("6000", 1, "half", True), ("9000", 2, "half", True),
+                                                      ("9000", 2, "full", True)])
 def test_heavy_tiles_are_shared_out_to_several_workgroups(cm, oracle, monkeypatch, parts, pol, angles, hot_pixel):
     """Uneven hit map, uniform tiles, the slices of the heavy tiles summed by several workgroups and
     their tile copies added in time order (cm2_tiles.h "PARTS").  Against the oracle's serial loop
