@@ -89,6 +89,18 @@ struct Geo {
 // s_memtime at its phase boundaries into a buffer of 8 words per window (profiles/scripts/
 // os_stamps.py).  Every lane stores: a branch at a phase boundary splits the kernel's one basic
 // block and costs the register allocator 70-150 spilled VGPRs, which would time a different kernel.
+// TIMING-ONLY builds (wrong results, never shipped; profiles/r05_os_memory_vs_compute.md): -DCM2_OS_TIMING=1 compiles
+// the transforms, their LDS exchanges and the pairing out -- what is left is the window's memory side (lists, run
+// tables, gathers, staging, result lists, stores) exactly as the kernel issues it.
+#ifndef CM2_OS_TIMING
+#define CM2_OS_TIMING 0
+#endif
+#if CM2_OS_TIMING & 1
+#define OS_XF(...) do { } while (0)
+#else
+#define OS_XF(...) do { __VA_ARGS__; } while (0)
+#endif
+
 #ifdef CM2_OS_STAMPS
 static unsigned long long *g_os_stamps_host = nullptr;      // set by cm2_os_debug_stamps
 static unsigned long long *os_stamp_buf()                   // never NULL: a dummy when none is wanted
@@ -752,31 +764,32 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     const double2 w_b = Wtw[PT * (t & 15)];          // n = 256: exp(-2 pi i (t & 15) / 256)
 
     // ---- forward: radix PT, radix 16, radix 16 ----
-    reg_fwd<PT, PT, 0>(zr, zi, w_a);
-    reg_exchange<PT, 1, 2, PT>(zr, buf, t);
-    reg_exchange<PT, 1, 2, PT>(zi, buf, t);
-    reg_fwd<PT, 16, 0>(zr, zi, w_b);
-    if constexpr (PT == 32) reg_fwd<PT, 16, 16>(zr, zi, w_b);
-    reg_exchange<PT, 2, 3, 16>(zr, buf, t);
-    reg_exchange<PT, 2, 3, 16>(zi, buf, t);
+    OS_XF(reg_fwd<PT, PT, 0>(zr, zi, w_a));
+    OS_XF(reg_exchange<PT, 1, 2, PT>(zr, buf, t));
+    OS_XF(reg_exchange<PT, 1, 2, PT>(zi, buf, t));
+    OS_XF(reg_fwd<PT, 16, 0>(zr, zi, w_b));
+    OS_XF(if constexpr (PT == 32) reg_fwd<PT, 16, 16>(zr, zi, w_b));
+    OS_XF(reg_exchange<PT, 2, 3, 16>(zr, buf, t));
+    OS_XF(reg_exchange<PT, 2, 3, 16>(zi, buf, t));
     const double2 *ab = AB + (int64_t)wd.blk * N + t;
-    dft_sub<PT, 16, 0>(zr, zi);
-    if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi);
+    OS_XF(dft_sub<PT, 16, 0>(zr, zi));
+    OS_XF(if constexpr (PT == 32) dft_sub<PT, 16, 16>(zr, zi));
     OS_STAMP(2);
     // ---- pairing with bin N-k and the spectrum product ----
     // (plain lists with flat addressing -- more than 2048 pixel tiles AND buffers of 4 GB and more -- hold 32
     //  address words beside the transform: batches of four bin pairs there, or three VGPRs spill)
-    partner_filter_half<PT, (MODE == 1 && !BUF) ? 4 : 8>(zr, zi, buf, reinterpret_cast<double *>(tab_lds + 2 * rmax),
-                                                         t, ab, AB + (int64_t)wd.blk * N);
+    OS_XF(partner_filter_half<PT, (MODE == 1 && !BUF) ? 4 : 8>(zr, zi, buf, reinterpret_cast<double *>(tab_lds + 2 * rmax),
+                                                               t, ab, AB + (int64_t)wd.blk * N));
+    (void)ab;
     OS_STAMP(3);
     // ---- inverse: radix 16 (decimation in time on the bit-reversed data), radix 16, radix PT ----
-    dit_sub<PT, 16, 0>(zi, zr);
-    if constexpr (PT == 32) dit_sub<PT, 16, 16>(zi, zr);
+    OS_XF(dit_sub<PT, 16, 0>(zi, zr));
+    OS_XF(if constexpr (PT == 32) dit_sub<PT, 16, 16>(zi, zr));
     // the inverse passes read their twiddles again (through a second pointer to the same table,
     // so that nothing of the forward passes stays live across the pairing step)
     const double2 w_bi = Wtw_inv[PT * (t & 15)], w_ai = Wtw_inv[t];
-    reg_exchange<PT, 3, 2, 0>(zr, buf, t);
-    reg_exchange<PT, 3, 2, 0>(zi, buf, t);
+    OS_XF(reg_exchange<PT, 3, 2, 0>(zr, buf, t));
+    OS_XF(reg_exchange<PT, 3, 2, 0>(zi, buf, t));
     // The result lists of round 0 are requested HERE, in front of the middle inverse pass: a run table
     // travels by LDS-DMA, and while one is in flight every workgroup barrier waits for it (s_waitcnt
     // vmcnt(0) in front of s_barrier) -- so the request is issued right behind a barrier, with the
@@ -811,11 +824,11 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
             for (int m = 0; m < NP; ++m) rp[m] = rl[t0 + kT * m];
         }
         __builtin_amdgcn_sched_barrier(0);
-        reg_inv<PT, 16, 0>(zr, zi, w_bi);
-        if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
-        reg_exchange<PT, 2, 1, 16>(zr, buf, t);
-        reg_exchange<PT, 2, 1, 16>(zi, buf, t);
-        reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
+        OS_XF(reg_inv<PT, 16, 0>(zr, zi, w_bi));
+        OS_XF(if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi));
+        OS_XF(reg_exchange<PT, 2, 1, 16>(zr, buf, t));
+        OS_XF(reg_exchange<PT, 2, 1, 16>(zi, buf, t));
+        OS_XF(reg_inv<PT, PT, 0>(zr, zi, w_ai));   // result slot m at index brev<PT>(m)
         OS_STAMP(4);
 #pragma unroll
         for (int j = 0; j < G::RR; ++j) {
@@ -881,11 +894,11 @@ __global__ __launch_bounds__(kT, PT == 16 ? 4 : 2) void k_os_real(
     int wb1 = -1;
     request_results(0, qs, ks, nvs, wbs, tab_lds); // (its run table: published by the barriers of the next exchange)
     __builtin_amdgcn_sched_barrier(0);
-    reg_inv<PT, 16, 0>(zr, zi, w_bi);
-    if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi);
-    reg_exchange<PT, 2, 1, 16>(zr, buf, t);
-    reg_exchange<PT, 2, 1, 16>(zi, buf, t);
-    reg_inv<PT, PT, 0>(zr, zi, w_ai);                // result slot m at index brev<PT>(m)
+    OS_XF(reg_inv<PT, 16, 0>(zr, zi, w_bi));
+    OS_XF(if constexpr (PT == 32) reg_inv<PT, 16, 16>(zr, zi, w_bi));
+    OS_XF(reg_exchange<PT, 2, 1, 16>(zr, buf, t));
+    OS_XF(reg_exchange<PT, 2, 1, 16>(zi, buf, t));
+    OS_XF(reg_inv<PT, PT, 0>(zr, zi, w_ai));   // result slot m at index brev<PT>(m)
     // ---- store: y[2 (t + 256 m)] = zr, y[.. + 1] = zi for m in [4, PT - 4), RSLOTS slots a round --
     OS_STAMP(4);
 #pragma unroll
